@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's own `nn` / `utils` packages and `transforms/fc_precomp.py`
+unmodified -- with the tiny import stubs in tests/golden/_refstubs standing in for the
+third-party torch_scatter / torch_geometric packages this image lacks -- feeds them seeded
+synthetic inputs and stores inputs, parameters, outputs and autograd gradients.
+
+The fixtures are data only (inputs + expected outputs); no reference source is copied.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('FIELDCONV_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(HERE, '_refstubs'))
+sys.path.insert(0, REF)            # reference's top-level `nn`, `utils` must win over site-packages
+
+import nn as refnn                  # noqa: E402  (reference package)
+
+_spec = importlib.util.spec_from_file_location('ref_fc_precomp', os.path.join(REF, 'transforms', 'fc_precomp.py'))
+ref_fc_precomp = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_fc_precomp)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_c(g, *shape, dtype=torch.cfloat):
+    rdt = torch.float32 if dtype == torch.cfloat else torch.float64
+    return torch.complex(torch.randn(*shape, generator=g, dtype=rdt), torch.randn(*shape, generator=g, dtype=rdt))
+
+
+def random_graph(g, N, k, drop=0.15):
+    """Random in-neighbourhoods with ragged degrees (some targets end up with no edges),
+    then ordered by source like the reference's real data."""
+    dst = torch.arange(N).repeat_interleave(k)
+    src = torch.randint(0, N, (N * k,), generator=g)
+    keep = torch.rand(N * k, generator=g) > drop
+    keep &= dst != 3                      # target 3 has no in-edges at all
+    src, dst = src[keep], dst[keep]
+    perm = torch.randperm(src.numel(), generator=g)
+    src, dst = src[perm], dst[perm]
+    order = torch.argsort(src, stable=True)
+    return torch.stack((src[order], dst[order]), dim=1)
+
+
+def features_with_zeros(g, N, C, dtype=torch.cfloat):
+    x = rand_c(g, N, C, dtype=dtype)
+    x[1, :] = 0                                    # a whole zero row
+    x[5, 0] = 0
+    x[6, 1] = complex(3e-8, -5e-8)                 # inside the origin box
+    x[7, 2] = complex(9.9e-8, 2e-7)                # just outside (one component above eps)
+    x[8, 0] = complex(-1e-7, 0.0)                  # exactly on the box edge: not "zero" (strict <)
+    x[9, 1] = complex(0.0, 2.5)
+    x[10, 0] = complex(-1.5, 0.0)                  # angle = pi branch
+    return x
+
+
+def fieldconv_cases(out):
+    N, k, I, O = 40, 6, 5, 7
+    for seed in (0, 1):
+        for ftype in ((0, 1, 2) if seed == 0 else (1,)):
+            for (B, R) in ((1, 3), (2, 6), (3, 6)):
+                for dt in ((torch.cfloat, torch.cdouble) if (seed == 0 and B == 2) else (torch.cfloat,)):
+                    g = torch.Generator().manual_seed(1000 * seed + 100 * ftype + 10 * B + R)
+                    torch.manual_seed(1000 * seed + 100 * ftype + 10 * B + R)
+                    edges = random_graph(g, N, k)
+                    E = edges.shape[0]
+                    x = features_with_zeros(g, N, I, dtype=dt).requires_grad_(True)
+                    sten = rand_c(g, E, R, 2 * B + 1, dtype=dt) * 0.3
+                    conv = refnn.FieldConv(I, O, band_limit=B, n_rings=R, ftype=ftype)
+                    if dt == torch.cdouble:
+                        conv = conv.double()
+                    y = conv(x, edges, sten)
+                    gy = rand_c(g, N, O, dtype=dt)
+                    params = dict(conv.named_parameters())
+                    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=gy)
+                    tag = f'fieldconv_s{seed}_t{ftype}_B{B}_R{R}_' + ('f64' if dt == torch.cdouble else 'f32')
+                    rec = dict(x=np_(x), edges=np_(edges), sten=np_(sten), y=np_(y), gy=np_(gy), gx=np_(grads[0]),
+                               zonal=np_(conv.zonal), spherical=np_(conv.spherical), phase=np_(conv.phase),
+                               ftype=ftype, B=B, R=R)
+                    for (name, _), gval in zip(params.items(), grads[1:]):
+                        rec['g_' + name] = np_(gval)
+                    out[tag] = rec
+
+
+def synthetic_logmap(g, N, k, eps):
+    edges = random_graph(g, N, k, drop=0.1)
+    E = edges.shape[0]
+    logMag = torch.rand(E, generator=g) * eps * 1.15           # ~13% fall outside the support
+    R = 6
+    knots = torch.sqrt(torch.arange(R) / (R - 1.0)) * eps
+    logMag[0] = 0.0                                            # r = 0
+    logMag[1] = eps                                            # r = eps exactly (kept, r<=1)
+    logMag[2] = eps * 1.0001                                   # dropped
+    logMag[3] = knots[2]                                       # knot-exact radius
+    logMag[4] = knots[4]
+    logAng = (torch.rand(E, generator=g) * 2 - 1) * np.pi
+    xp = torch.polar(torch.ones(E), (torch.rand(E, generator=g) * 2 - 1) * np.pi)
+    w = (1.0 / N) * (1 + 0.1 * torch.rand(N, 1, generator=g))
+    return edges, logMag, logAng, xp, w
+
+
+class _Data:
+    pass
+
+
+def precomp_cases(out):
+    for seed, (B, R) in enumerate(((2, 6), (1, 3), (3, 5))):
+        g = torch.Generator().manual_seed(77 + seed)
+        N, k, eps = 50, 7, 0.2
+        edges, logMag, logAng, xp, w = synthetic_logmap(g, N, k, eps)
+        d = _Data()
+        d.logMag, d.logAng, d.w, d.supp_edges, d.xp = logMag, logAng, w, edges, xp
+        e2, sten, ln, wxp = ref_fc_precomp.FCPrecomp(B, R, eps)(d)
+        out[f'precomp_{seed}'] = dict(edges=np_(edges), logMag=np_(logMag), logAng=np_(logAng), xp=np_(xp), w=np_(w),
+                                      B=B, R=R, eps=eps, out_edges=np_(e2), out_sten=np_(sten), out_ln=np_(ln),
+                                      out_wxp=np_(wxp))
+
+
+def geo_stencil(g, N, k, B, R, eps=0.2):
+    edges, logMag, logAng, xp, w = synthetic_logmap(g, N, k, eps)
+    d = _Data()
+    d.logMag, d.logAng, d.w, d.supp_edges, d.xp = logMag, logAng, w, edges, xp
+    return ref_fc_precomp.FCPrecomp(B, R, eps)(d)
+
+
+def block_cases(out):
+    N, k = 48, 9
+    for idx, (frontload, Cin, Cout, ftype) in enumerate(((False, 6, 8, 1), (True, 6, 8, 1), (False, 4, 4, 0), (False, 5, 3, 2))):
+        B, R = 2, 6
+        g = torch.Generator().manual_seed(300 + idx)
+        torch.manual_seed(300 + idx)
+        edges, sten, ln, wxp = geo_stencil(g, N, k, B, R)
+        x = features_with_zeros(g, N, Cin).requires_grad_(True)
+        blk = refnn.FCResNetBlock(Cin, Cout, band_limit=B, n_rings=R, ftype=ftype, frontload=frontload)
+        with torch.no_grad():
+            blk.nonlin1.bias.copy_(torch.randn(blk.nonlin1.bias.shape, generator=g) * 0.05)
+            blk.nonlin2.bias.copy_(torch.randn(blk.nonlin2.bias.shape, generator=g) * 0.05)
+        y = blk(x, edges, sten)
+        gy = rand_c(g, N, Cout)
+        params = dict(blk.named_parameters())
+        grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=gy)
+        rec = dict(x=np_(x), edges=np_(edges), sten=np_(sten), y=np_(y), gy=np_(gy), gx=np_(grads[0]),
+                   frontload=int(frontload), Cin=Cin, Cout=Cout, ftype=ftype, B=B, R=R)
+        for name, t in blk.state_dict().items():
+            rec['p_' + name] = np_(t)
+        for (name, _), gval in zip(params.items(), grads[1:]):
+            rec['g_' + name] = np_(gval)
+        out[f'block_{idx}'] = rec
+
+
+def pointwise_cases(out):
+    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(5)
+    N, I, O = 40, 6, 9
+    x = features_with_zeros(g, N, I).requires_grad_(True)
+    lin = refnn.TangentLin(I, O)
+    y = lin(x)
+    gy = rand_c(g, N, O)
+    gx, gRe, gIm = torch.autograd.grad(y, [x, lin.Re, lin.Im], grad_outputs=gy)
+    out['tangent_lin'] = dict(x=np_(x), Re=np_(lin.Re), Im=np_(lin.Im), y=np_(y), gy=np_(gy), gx=np_(gx), gRe=np_(gRe), gIm=np_(gIm))
+
+    x = features_with_zeros(g, N, I)
+    x[12, 3] = complex(0.05, 0.02)      # |x| + b < 0 with the bias below -> clipped to zero
+    x[13, 3] = complex(-0.02, 0.01)
+    x = x.requires_grad_(True)
+    nl = refnn.TangentNonLin(I)
+    with torch.no_grad():
+        nl.bias.copy_(torch.tensor([[0.3, -0.2, 0.0, -0.1, 0.5, -1.0]]))
+    y = nl(x)
+    gy = rand_c(g, N, I)
+    gx, gb = torch.autograd.grad(y, [x, nl.bias], grad_outputs=gy)
+    out['tangent_nonlin'] = dict(x=np_(x), bias=np_(nl.bias), y=np_(y), gy=np_(gy), gx=np_(gx), gbias=np_(gb))
+
+
+def echo_lift_cases(out):
+    B, R = 2, 6
+    N, k = 40, 9
+    g = torch.Generator().manual_seed(900)
+    torch.manual_seed(900)
+    edges, sten, ln, wxp = geo_stencil(g, N, k, B, R)
+
+    # ECHO descriptor alone
+    C, nb = 4, 2
+    x = features_with_zeros(g, N, C).requires_grad_(True)
+    echo = refnn.ECHO(C, nb)
+    d = echo(x, edges, ln, wxp)
+    gd = torch.randn(d.shape, generator=g)
+    gx, = torch.autograd.grad(d, [x], grad_outputs=gd)
+    out['echo'] = dict(x=np_(x), edges=np_(edges), ln=np_(ln), wxp=np_(wxp), n_bins=nb, y=np_(d), gy=np_(gd), gx=np_(gx),
+                       dMap=np_(echo.dMap))
+
+    # ECHOBlock
+    Cin, Cout, ndes = 6, 5, 4
+    x = features_with_zeros(g, N, Cin).requires_grad_(True)
+    blk = refnn.ECHOBlock(Cin, Cout, n_des=ndes, n_bins=2, band_limit=B, n_rings=R, ftype=1)
+    y = blk(x, edges, sten, ln, wxp)
+    gy = torch.randn(y.shape, generator=g)
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=gy)
+    rec = dict(x=np_(x), edges=np_(edges), sten=np_(sten), ln=np_(ln), wxp=np_(wxp), y=np_(y), gy=np_(gy), gx=np_(grads[0]),
+               Cin=Cin, Cout=Cout, n_des=ndes, n_bins=2, B=B, R=R)
+    for name, t in blk.state_dict().items():
+        rec['p_' + name] = np_(t)
+    for (name, _), gval in zip(params.items(), grads[1:]):
+        rec['g_' + name] = np_(gval)
+    out['echo_block'] = rec
+
+    # LiftBlock / TransField (receives the strided stencil slice, segmentation.ipynb:204)
+    for ftype in (0, 1):
+        Cin, Cout = 3, 6
+        xs = torch.randn(N, Cin, generator=g).requires_grad_(True)
+        lift = refnn.LiftBlock(Cin, Cout, n_rings=R, ftype=ftype)
+        lsten = sten[..., B:B + 2]
+        y = lift(xs, edges, lsten)
+        gy = rand_c(g, N, Cout)
+        params = dict(lift.named_parameters())
+        grads = torch.autograd.grad(y, [xs] + list(params.values()), grad_outputs=gy)
+        rec = dict(x=np_(xs), edges=np_(edges), lift_sten=np_(lsten), y=np_(y), gy=np_(gy), gx=np_(grads[0]),
+                   Cin=Cin, Cout=Cout, R=R, ftype=ftype)
+        for name, t in lift.state_dict().items():
+            rec['p_' + name] = np_(t)
+        for (name, _), gval in zip(params.items(), grads[1:]):
+            rec['g_' + name] = np_(gval)
+        out[f'lift_block_t{ftype}'] = rec
+
+
+def main():
+    groups = {
+        'fieldconv.npz': fieldconv_cases,
+        'precomp.npz': precomp_cases,
+        'blocks.npz': block_cases,
+        'pointwise.npz': pointwise_cases,
+        'echo_lift.npz': echo_lift_cases,
+    }
+    for fname, fn in groups.items():
+        cases = {}
+        fn(cases)
+        flat = {}
+        for tag, rec in cases.items():
+            for key, val in rec.items():
+                flat[f'{tag}/{key}'] = np.asarray(val)
+        path = os.path.join(HERE, fname)
+        np.savez_compressed(path, **flat)
+        print(f'{fname}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+if __name__ == '__main__':
+    main()
