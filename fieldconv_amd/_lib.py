@@ -1,0 +1,75 @@
+"""ctypes binding of libfieldconv_hip.so (the C ABI in include/fieldconv_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, the product path
+raises.  Nothing under oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c_int32 = ctypes.c_int32
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+class FcDims(ctypes.Structure):
+    _fields_ = [('N', _c_int32), ('E', _c_int32), ('I', _c_int32), ('O', _c_int32), ('R', _c_int32), ('B', _c_int32)]
+
+
+class FcCsr(ctypes.Structure):
+    _fields_ = [('rowptr', _vp), ('nbr', _vp), ('eid', _vp)]
+
+
+_DP = ctypes.POINTER(FcDims)
+_CP = ctypes.POINTER(FcCsr)
+
+# name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
+SIGNATURES = {
+    'fc_abi_version': (ctypes.c_int, []),
+    'fc_status_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'fc_supported': (ctypes.c_int, [_DP]),
+    'fc_packed_filter_floats_fwd': (_sz, [_DP]),
+    'fc_packed_filter_floats_bwd': (_sz, [_DP]),
+    'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _vp]),
+    'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
+    'fc_backward_workspace_bytes': (_sz, [_DP]),
+    'fc_backward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _vp, _sz, _DP, _vp]),
+    'fc_tangent_lin_forward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_tangent_lin_backward_workspace_bytes': (_sz, [_c_int32, _c_int32, _c_int32]),
+    'fc_tangent_lin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_tangent_nonlin_forward': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),
+    'fc_tangent_nonlin_backward_workspace_bytes': (_sz, [_c_int32, _c_int32]),
+    'fc_tangent_nonlin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
+}
+
+_LIB = None
+
+
+class FieldConvNativeError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the library and bind every entry point; raises if it is not built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or os.environ.get('FIELDCONV_HIP_LIB', LIB_PATH)
+    if not os.path.exists(path):
+        raise FieldConvNativeError(
+            f'{path} not found: build it with `python -m fieldconv_amd.build` '
+            '(fieldconv_amd has no CPU or eager fallback for the field-convolution path)')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().fc_status_string(int(status)).decode()
+        raise FieldConvNativeError(f'{what} failed: {msg} (status {status})')

@@ -1,0 +1,58 @@
+"""Build libfieldconv_hip.so (gfx950 only) in-tree with hipcc.
+
+`python -m fieldconv_amd.build` or `fieldconv_amd.build.build_native()`.  The shared object
+lands in fieldconv_amd/_native/ (git-ignored, but it travels to the GPU box with the repo
+snapshot) and exposes only the C ABI declared in include/fieldconv_hip.h.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+OUT_DIR = os.path.join(PKG, '_native')
+LIB_PATH = os.path.join(OUT_DIR, 'libfieldconv_hip.so')
+SOURCES = ['fc_api.hip', 'fc_pack.hip', 'fc_forward.hip', 'fc_backward.hip', 'fc_pointwise.hip']
+HEADERS = ['fc_common.hpp', 'fc_kernels.hpp', os.path.join('..', '..', 'include', 'fieldconv_hip.h')]
+# -fno-slp-vectorize: keep the stencil FMAs as v_fma_f32 with a direct SGPR operand; packed
+# v_pk_fma_f32 needs SGPR pairs built with s_mov and saturates the CU's single scalar ALU.
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fno-slp-vectorize',
+         '-fno-gpu-rdc', '-Wno-unused-result']
+
+
+def _hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: libfieldconv_hip.so cannot be built')
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared library; returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(OUT_DIR, exist_ok=True)
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    cmd = [_hipcc()] + FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError('hipcc failed:\n' + res.stdout)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_native(force='--force' in sys.argv, verbose=True))

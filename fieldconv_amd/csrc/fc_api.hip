@@ -1,0 +1,82 @@
+// extern "C" surface of libfieldconv_hip.so; see include/fieldconv_hip.h for the contract.
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+
+namespace fc {
+
+bool shape_compiled(int R, int B) {
+#define FC_CASE(RR, BB) if (R == RR && B == BB) return true;
+    FC_FOR_EACH_SHAPE(FC_CASE)
+#undef FC_CASE
+    return false;
+}
+
+static bool dims_valid(const fc_dims* d) {
+    return d && d->N > 0 && d->E >= 0 && d->I > 0 && d->O > 0 && d->R > 0 && d->B >= 0;
+}
+
+static bool dims_supported(const fc_dims* d) {
+    if (!dims_valid(d)) return false;
+    if (!shape_compiled(d->R, d->B)) return false;
+    if (d->I > kMaxChannels || d->O > kMaxChannels) return false;
+    return true;
+}
+
+}  // namespace fc
+
+extern "C" {
+
+int fc_abi_version(void) { return 1; }
+
+const char* fc_status_string(int s) {
+    switch (s) {
+        case FC_OK: return "ok";
+        case FC_ERR_BAD_ARGUMENT: return "bad argument (null pointer or inconsistent dims)";
+        case FC_ERR_UNSUPPORTED: return "unsupported (n_rings, band_limit, channels) for the compiled kernels";
+        case FC_ERR_LAUNCH: return "HIP kernel launch failed";
+        case FC_ERR_WORKSPACE: return "workspace missing or too small";
+        default: return "unknown status";
+    }
+}
+
+int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0; }
+
+size_t fc_packed_filter_floats_fwd(const fc_dims* d) {
+    if (!fc::dims_valid(d)) return 0;
+    return (size_t)(2 * d->B + 1) * 2 * fc::round_up(d->O, 16) * fc::round_up(d->R * d->I, 16);
+}
+
+size_t fc_packed_filter_floats_bwd(const fc_dims* d) {
+    if (!fc::dims_valid(d)) return 0;
+    return (size_t)(2 * d->B + 1) * 2 * fc::round_up(d->I, 16) * fc::round_up(d->R * d->O, 16);
+}
+
+int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream) {
+    if (!w_eff || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, static_cast<hipStream_t>(stream));
+}
+
+int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const float* wpk_fwd, float* y,
+               const fc_dims* dims, void* stream) {
+    if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (dims->E > 0 && (!sten || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    return fc::forward_impl(x, sten, by_target, wpk_fwd, y, dims, static_cast<hipStream_t>(stream));
+}
+
+size_t fc_backward_workspace_bytes(const fc_dims* dims) {
+    if (!fc::dims_supported(dims)) return 0;
+    return fc::backward_workspace_bytes(dims);
+}
+
+int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
+                float* gx, float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!x || !gy || !gx || !gw_eff || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims))
+        return FC_ERR_BAD_ARGUMENT;
+    if (dims->E > 0 && (!sten || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, gx, gw_eff, workspace, workspace_bytes, dims,
+                             static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

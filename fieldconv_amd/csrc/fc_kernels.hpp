@@ -1,0 +1,28 @@
+// Internal declarations shared by the .hip translation units of libfieldconv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/fieldconv_hip.h"
+
+// (n_rings, band_limit) pairs with register-resident kernels.  The reference's notebooks use
+// (6,1), (6,2), (6,3); the small ones serve the golden fixtures.  Anything else returns
+// FC_ERR_UNSUPPORTED (fc_supported() == 0).
+#define FC_FOR_EACH_SHAPE(X) \
+    X(3, 1) X(4, 1) X(6, 1) X(8, 1) \
+    X(3, 2) X(4, 2) X(6, 2) X(8, 2) \
+    X(5, 3) X(6, 3)
+
+namespace fc {
+
+constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kMaxChannels = 64;     // one channel per lane in the gather phases
+
+int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
+                 const fc_dims* d, hipStream_t stream);
+size_t backward_workspace_bytes(const fc_dims* d);
+int backward_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk,
+                  float* gx, float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
+int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream);
+
+bool shape_compiled(int R, int B);
+
+}  // namespace fc

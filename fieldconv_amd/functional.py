@@ -1,0 +1,182 @@
+"""autograd.Function wrappers that launch the HIP kernels through the C ABI.
+
+The tensors are plain torch device buffers; only raw pointers, sizes and the current HIP stream
+cross into libfieldconv_hip.so (include/fieldconv_hip.h).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FcCsr, FcDims, check
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: fieldconv_amd runs on a ROCm device only (got a {t.device} tensor); '
+                           'there is no CPU fallback')
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _csr(rowptr, nbr):
+    return FcCsr(rowptr.data_ptr(), nbr.data_ptr() if nbr.numel() else None, None)
+
+
+def make_dims(graph, I, O, B):
+    return FcDims(graph.N, graph.E, int(I), int(O), graph.R, int(B))
+
+
+def supported(graph, I, O, B):
+    return bool(_lib.load().fc_supported(ctypes.byref(make_dims(graph, I, O, B))))
+
+
+class _FieldConvFn(torch.autograd.Function):
+    """y = FieldConv(x; W_eff) on a preprocessed support graph (reference nn/field_conv.py:128-137)."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, graph):
+        lib = _lib.load()
+        x = x.contiguous()
+        w_eff = w_eff.contiguous()
+        O, I, R, F = w_eff.shape
+        B = (F - 1) // 2
+        dims = make_dims(graph, I, O, B)
+        if not lib.fc_supported(ctypes.byref(dims)):
+            raise _lib.FieldConvNativeError(
+                f'FieldConv(in={I}, out={O}, n_rings={R}, band_limit={B}) is outside the compiled HIP kernels '
+                '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
+        with torch.cuda.device(x.device):
+            st = _stream()
+            wpk_f = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            wpk_b = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), st), 'fc_pack_filter')
+            y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
+            csr = _csr(graph.rowptr_t, graph.nbr_t)
+            check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                  'fc_forward')
+        ctx.save_for_backward(x, wpk_b)
+        ctx.graph = graph
+        ctx.wshape = (O, I, R, F)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, wpk_b = ctx.saved_tensors
+        graph = ctx.graph
+        O, I, R, F = ctx.wshape
+        dims = make_dims(graph, I, O, (F - 1) // 2)
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            st = _stream()
+            gx = torch.empty_like(x)
+            gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
+            nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            csr = _csr(graph.rowptr_s, graph.nbr_s)
+            check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(gw), _p(ws),
+                                  nbytes, ctypes.byref(dims), st), 'fc_backward')
+        return gx, gw, None
+
+
+def field_conv(x, w_eff, graph):
+    """x (N,I) complex64, w_eff (O,I,R,F) complex64, graph: fieldconv_amd.graph.SupportGraph -> (N,O) complex64."""
+    _require_device(x, 'field_conv')
+    if x.dtype != torch.complex64 or w_eff.dtype != torch.complex64:
+        raise ValueError('field_conv expects complex64 features and filters')
+    if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != w_eff.shape[1]:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {w_eff.shape[1]})')
+    if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
+        raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
+    return _FieldConvFn.apply(x, w_eff, graph)
+
+
+class _TangentLinFn(torch.autograd.Function):
+    """reference nn/tangent_lin.py:27-29"""
+
+    @staticmethod
+    def forward(ctx, x, re_w, im_w):
+        lib = _lib.load()
+        x = x.contiguous()
+        re_w = re_w.contiguous()
+        im_w = im_w.contiguous()
+        O, I = re_w.shape
+        N = x.shape[0]
+        with torch.cuda.device(x.device):
+            y = torch.empty((N, O), dtype=torch.complex64, device=x.device)
+            check(lib.fc_tangent_lin_forward(_p(x), _p(re_w), _p(im_w), _p(y), N, I, O, _stream()), 'fc_tangent_lin_forward')
+        ctx.save_for_backward(x, re_w, im_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, re_w, im_w = ctx.saved_tensors
+        O, I = re_w.shape
+        N = x.shape[0]
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            gx = torch.empty_like(x)
+            g_re = torch.empty_like(re_w)
+            g_im = torch.empty_like(im_w)
+            nbytes = lib.fc_tangent_lin_backward_workspace_bytes(N, I, O)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            check(lib.fc_tangent_lin_backward(_p(x), _p(gy), _p(re_w), _p(im_w), _p(gx), _p(g_re), _p(g_im), _p(ws), nbytes,
+                                              N, I, O, _stream()), 'fc_tangent_lin_backward')
+        return gx, g_re, g_im
+
+
+def tangent_lin(x, re_w, im_w):
+    _require_device(x, 'tangent_lin')
+    if x.dtype != torch.complex64:
+        raise ValueError('tangent_lin expects complex64 features')
+    if x.dim() != 2 or x.shape[1] != re_w.shape[1]:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected (N, {re_w.shape[1]})')
+    return _TangentLinFn.apply(x, re_w, im_w)
+
+
+class _TangentNonLinFn(torch.autograd.Function):
+    """reference nn/tangent_nonlin.py:24-35"""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        lib = _lib.load()
+        x = x.contiguous()
+        b = bias.contiguous()
+        N, C = x.shape
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            check(lib.fc_tangent_nonlin_forward(_p(x), _p(b), _p(y), N, C, _stream()), 'fc_tangent_nonlin_forward')
+        ctx.save_for_backward(x, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, b = ctx.saved_tensors
+        N, C = x.shape
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            gx = torch.empty_like(x)
+            gb = torch.empty_like(b)
+            nbytes = lib.fc_tangent_nonlin_backward_workspace_bytes(N, C)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            check(lib.fc_tangent_nonlin_backward(_p(x), _p(b), _p(gy), _p(gx), _p(gb), _p(ws), nbytes, N, C, _stream()),
+                  'fc_tangent_nonlin_backward')
+        return gx, gb
+
+
+def tangent_nonlin(x, bias):
+    _require_device(x, 'tangent_nonlin')
+    if x.dtype != torch.complex64:
+        raise ValueError('tangent_nonlin expects complex64 features')
+    if x.dim() != 2 or bias.numel() != x.shape[1]:
+        raise ValueError(f'x has shape {tuple(x.shape)} but bias has {bias.numel()} channels')
+    return _TangentNonLinFn.apply(x, bias)

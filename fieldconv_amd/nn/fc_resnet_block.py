@@ -1,0 +1,24 @@
+import torch.nn as nn
+
+from .field_conv import FieldConv
+from .tangent_lin import TangentLin
+from .tangent_nonlin import TangentNonLin
+
+
+class FCResNetBlock(nn.Module):
+    """nonlin2(res(x) + conv2(nonlin1(conv1(x)))) -- the FCResNet block of section 5 / figure 2
+    (reference nn/fc_resnet_block.py:7-88).  `frontload` picks which convolution changes width."""
+
+    def __init__(self, in_channels, out_channels, band_limit=1, n_rings=6, ftype=1, frontload=False):
+        super().__init__()
+        mid = in_channels if frontload else out_channels
+        self.conv1 = FieldConv(in_channels, mid, band_limit=band_limit, n_rings=n_rings, ftype=ftype)
+        self.conv2 = FieldConv(mid, out_channels, band_limit=band_limit, n_rings=n_rings, ftype=ftype)
+        self.nonlin1 = TangentNonLin(mid)
+        self.nonlin2 = TangentNonLin(out_channels)
+        self.res = TangentLin(in_channels, out_channels)
+
+    def forward(self, x, supp_edges, supp_sten):
+        h = self.nonlin1(self.conv1(x, supp_edges, supp_sten))
+        h = self.conv2(h, supp_edges, supp_sten)
+        return self.nonlin2(self.res(x) + h)

@@ -1,0 +1,53 @@
+"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97)."""
+import torch
+
+
+def radialInterpolant(r, n_rings):
+    """(E,R) linear-interpolation weights on the equal-area knots sqrt(q/(R-1)); exactly two
+    non-zeros per row (reference transforms/fc_precomp.py:10-27).  The upper knot is the first
+    knot >= r, never knot 0."""
+    knots = torch.sqrt(torch.arange(n_rings, device=r.device) / (n_rings - 1))
+    gap = knots[None, :] - r[:, None]
+    gap = torch.where(gap < 0, torch.full_like(gap, 1e8), gap)
+    hi = torch.argmin(gap, dim=1).clamp_min(1)
+    lo = hi - 1
+    w_hi = (r - knots[lo]) / (knots[hi] - knots[lo])
+    w = torch.zeros(r.shape[0], n_rings, device=r.device, dtype=torch.float32)
+    w.scatter_(1, hi[:, None], w_hi[:, None].float())
+    w.scatter_(1, lo[:, None], (1 - w_hi)[:, None].float())
+    return w
+
+
+class FCPrecomp(object):
+    """Organises per-edge log-map / transport data into the convolution stencil
+    (equations (6)-(7) of the paper).
+
+    data needs: logMag (E), logAng (E), w (N,1), supp_edges (E,2), xp (E complex).
+    Returns (supp_edges, supp_sten (E',R,2B+1), ln (E'), wxp (E')) restricted to r <= epsilon.
+    """
+
+    def __init__(self, band_limit, n_rings, epsilon):
+        self.B = band_limit
+        self.R = n_rings
+        self.max_r = epsilon
+
+    def __call__(self, data):
+        r, theta, w, supp_edges, xp = data.logMag, data.logAng, data.w, data.supp_edges, data.xp
+        B, R = self.B, self.R
+        r = r / self.max_r
+        keep = torch.nonzero(r <= 1.0).squeeze(-1)
+        r, theta, supp_edges, xp = r[keep], theta[keep], supp_edges[keep, :], xp[keep]
+        ln = torch.polar(r, theta)
+        ring = radialInterpolant(r, R)
+        m = torch.arange(-B, B + 1, device=theta.device)
+        ang = m[None, :] * theta[:, None]
+        freq = torch.polar(torch.ones_like(ang), ang)
+        src, dst = supp_edges[:, 0], supp_edges[:, 1]
+        ws = w[src, 0]
+        total = torch.zeros(w.shape[0], dtype=ws.dtype, device=ws.device).index_add(0, dst, ws)
+        wxp = (ws / (1e-12 + total[dst])) * xp
+        supp_sten = ring[:, :, None] * freq[:, None, :] * wxp[:, None, None]
+        return supp_edges, supp_sten, ln, wxp
+
+    def __repr__(self):
+        return '{}(n_rings={}, epsilon={})'.format(self.__class__.__name__, self.R, self.max_r)

@@ -1,0 +1,108 @@
+/* fieldconv_hip.h -- C ABI of libfieldconv_hip.so (gfx950 / MI355X).
+ *
+ * The reference (twmitchel/FieldConv) has no native interface for this path: its hot loop is a
+ * composite of stock torch ops plus torch_scatter.scatter_add inside Python modules.  Each entry
+ * point below replaces the body of one reference Python method; a maintainer binds it with
+ * ctypes / a torch custom op exactly as fieldconv_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); nothing is allocated,
+ *     freed or retained by the library; workspaces are caller-provided
+ *   - complex tensors are interleaved (re, im) fp32 pairs == torch.complex64 storage
+ *   - indices are int32; `stream` is a hipStream_t passed as void*
+ *   - return value: 0 on success, a negative fc_status otherwise; no exceptions, no globals,
+ *     re-entrant; work is enqueued on `stream` and NOT synchronised
+ */
+#ifndef FIELDCONV_HIP_H
+#define FIELDCONV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fc_status {
+    FC_OK = 0,
+    FC_ERR_BAD_ARGUMENT = -1,   /* null pointer, non-positive size, inconsistent dims */
+    FC_ERR_UNSUPPORTED = -2,    /* (n_rings, band_limit, channels) outside the compiled set */
+    FC_ERR_LAUNCH = -3,         /* hipLaunchKernel reported an error */
+    FC_ERR_WORKSPACE = -4       /* workspace pointer missing or too small */
+} fc_status;
+
+/* Problem dimensions of one FieldConv call (reference nn/field_conv.py:104-123). */
+typedef struct fc_dims {
+    int32_t N;   /* vertices                                   */
+    int32_t E;   /* support edges                              */
+    int32_t I;   /* in_channels                                */
+    int32_t O;   /* out_channels                               */
+    int32_t R;   /* n_rings                                    */
+    int32_t B;   /* band_limit; F = 2B+1 angular frequencies   */
+} fc_dims;
+
+/* Edge list grouped by one endpoint (CSR).  Slot s in [rowptr[v], rowptr[v+1]) is one edge
+ * incident to vertex v; nbr[s] is the OTHER endpoint.  `eid[s]` is the row of the stencil that
+ * belongs to the slot, or eid == NULL when the stencil passed alongside is already stored in
+ * slot order.  Grouped by target (col 1 of supp_edges) for the forward pass, by source (col 0)
+ * for the backward pass. */
+typedef struct fc_csr {
+    const int32_t* rowptr;   /* N+1 */
+    const int32_t* nbr;      /* E   */
+    const int32_t* eid;      /* E or NULL */
+} fc_csr;
+
+int fc_abi_version(void);
+const char* fc_status_string(int status);
+
+/* 1 if the compiled kernels cover these dims, 0 otherwise (then every call returns
+ * FC_ERR_UNSUPPORTED for them). */
+int fc_supported(const fc_dims* dims);
+
+/* ---- filter packing -------------------------------------------------------------------- *
+ * W_eff (O,I,R,F) complex64 is what reference nn/field_conv.py:10-33 (weightContrib*) builds
+ * from (zonal, spherical, phase); the 1/(2B+1) of :14,:25,:33 is folded in here.
+ * wpk_fwd: F x {re,im} x OP x KPf floats,  k = r*I + i,  OP = ceil16(O), KPf = ceil16(R*I)
+ * wpk_bwd: F x {re,im} x IP x KPb floats,  k = r*O + o,  conjugated,  IP = ceil16(I), KPb = ceil16(R*O) */
+size_t fc_packed_filter_floats_fwd(const fc_dims* dims);
+size_t fc_packed_filter_floats_bwd(const fc_dims* dims);
+int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
+
+/* ---- FieldConv.forward, reference nn/field_conv.py:128-137 ------------------------------- *
+ * y[n,o] = 1/F sum_{e: dst_e=n} sum_{i,r,f} x[src_e,i] e^{-i(f-B)phi[src_e,i]} S[e,r,f] W_eff[o,i,r,f]
+ * x (N,I) c64, sten (E,R,F) c64, by_target: CSR grouped by target, y (N,O) c64 (overwritten). */
+int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const float* wpk_fwd,
+               float* y, const fc_dims* dims, void* stream);
+
+/* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
+ * gx (N,I) c64 and gw_eff (O,I,R,F) c64 are overwritten.  by_source: CSR grouped by source.
+ * workspace: fc_backward_workspace_bytes(dims) bytes, 256-byte aligned. */
+size_t fc_backward_workspace_bytes(const fc_dims* dims);
+int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source,
+                const float* wpk_bwd, float* gx, float* gw_eff, void* workspace, size_t workspace_bytes,
+                const fc_dims* dims, void* stream);
+
+/* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
+ * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */
+int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w, float* y,
+                           int32_t N, int32_t I, int32_t O, void* stream);
+/* gx (N,I) c64, g_re / g_im (O,I) fp32 (all overwritten); I, O <= 64.
+ * workspace: fc_tangent_lin_backward_workspace_bytes() bytes of per-wavefront partial sums. */
+size_t fc_tangent_lin_backward_workspace_bytes(int32_t N, int32_t I, int32_t O);
+int fc_tangent_lin_backward(const float* x, const float* gy, const float* re_w, const float* im_w,
+                            float* gx, float* g_re, float* g_im, void* workspace, size_t workspace_bytes,
+                            int32_t N, int32_t I, int32_t O, void* stream);
+
+/* ---- TangentNonLin.forward (modReLU), reference nn/tangent_nonlin.py:24-35 --------------- *
+ * y = relu(|x| + b_c) x/|x| outside the origin box, x inside it.  bias: C floats. */
+int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32_t N, int32_t C, void* stream);
+/* gx (N,C) c64 overwritten; gbias (C floats) overwritten.
+ * workspace: fc_tangent_nonlin_backward_workspace_bytes() bytes of per-block bias partials. */
+size_t fc_tangent_nonlin_backward_workspace_bytes(int32_t N, int32_t C);
+int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
+                               void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIELDCONV_HIP_H */

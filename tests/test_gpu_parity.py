@@ -1,0 +1,248 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors captured from the
+reference modules, the CPU oracle on seeded inputs, and size-independent properties at the
+benchmark size.  Tolerance: max|delta| <= 1e-5 * max|ref| in fp32 (the
+reference's own fp32-vs-fp64 error is ~2e-7)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import fieldconv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def D(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+def load_params(module, c, prefix='p_'):
+    sd = {k[len(prefix):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in c.items() if k.startswith(prefix)}
+    module.load_state_dict(sd)
+    return module
+
+
+FC = {k: v for k, v in load_golden('fieldconv.npz').items() if k.endswith('f32')}
+
+
+@pytest.mark.parametrize('tag', sorted(FC))
+def test_fieldconv_golden(tag, dev):
+    from fieldconv_amd.nn import FieldConv
+    c = FC[tag]
+    ftype, B, R = int(c['ftype']), int(c['B']), int(c['R'])
+    conv = FieldConv(c['x'].shape[1], c['y'].shape[1], band_limit=B, n_rings=R, ftype=ftype)
+    conv.load_state_dict({'zonal': torch.from_numpy(c['zonal']), 'spherical': torch.from_numpy(c['spherical']),
+                          'phase': torch.from_numpy(c['phase'])})
+    conv = conv.to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = conv(x, D(c['edges'], dev), D(c['sten'], dev))
+    assert rel_err(H(y), c['y']) < TOL
+    params = dict(conv.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(grads[0]), c['gx']) < TOL
+    for (name, _), g in zip(params.items(), grads[1:]):
+        assert rel_err(H(g), c['g_' + name]) < TOL, name
+
+
+def test_pointwise_golden(dev):
+    from fieldconv_amd.nn import TangentLin, TangentNonLin
+    c = load_golden('pointwise.npz')['tangent_lin']
+    lin = TangentLin(c['Re'].shape[1], c['Re'].shape[0])
+    lin.load_state_dict({'Re': torch.from_numpy(c['Re']), 'Im': torch.from_numpy(c['Im'])})
+    lin = lin.to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = lin(x)
+    assert rel_err(H(y), c['y']) < TOL
+    gx, gRe, gIm = torch.autograd.grad(y, [x, lin.Re, lin.Im], grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(gx), c['gx']) < TOL
+    assert rel_err(H(gRe), c['gRe']) < TOL
+    assert rel_err(H(gIm), c['gIm']) < TOL
+
+    c = load_golden('pointwise.npz')['tangent_nonlin']
+    nl = TangentNonLin(c['bias'].shape[1])
+    nl.load_state_dict({'bias': torch.from_numpy(c['bias'])})
+    nl = nl.to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = nl(x)
+    assert rel_err(H(y), c['y']) < TOL
+    gx, gb = torch.autograd.grad(y, [x, nl.bias], grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(gx), c['gx']) < TOL
+    assert rel_err(H(gb), c['gbias']) < TOL
+    # origin-box entries pass through bit-exactly (reference tangent_nonlin.py:26)
+    org = orc.is_origin(c['x'])
+    assert np.array_equal(H(y)[org], c['x'][org])
+
+
+@pytest.mark.parametrize('tag', sorted(load_golden('blocks.npz')))
+def test_fc_resnet_block_golden(tag, dev):
+    from fieldconv_amd.nn import FCResNetBlock
+    c = load_golden('blocks.npz')[tag]
+    blk = FCResNetBlock(int(c['Cin']), int(c['Cout']), band_limit=int(c['B']), n_rings=int(c['R']), ftype=int(c['ftype']),
+                        frontload=bool(c['frontload']))
+    blk = load_params(blk, c).to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = blk(x, D(c['edges'], dev), D(c['sten'], dev))
+    assert rel_err(H(y), c['y']) < TOL
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(grads[0]), c['gx']) < 2 * TOL
+    for (name, _), g in zip(params.items(), grads[1:]):
+        assert rel_err(H(g), c['g_' + name]) < 2 * TOL, name
+
+
+def test_echo_block_and_lift_block_golden(dev):
+    from fieldconv_amd.nn import ECHOBlock, LiftBlock
+    c = load_golden('echo_lift.npz')['echo_block']
+    m = ECHOBlock(int(c['Cin']), int(c['Cout']), n_des=int(c['n_des']), n_bins=int(c['n_bins']), band_limit=int(c['B']),
+                  n_rings=int(c['R']), ftype=1)
+    m = load_params(m, c).to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = m(x, D(c['edges'], dev), D(c['sten'], dev), D(c['ln'], dev), D(c['wxp'], dev))
+    assert rel_err(H(y), c['y']) < 5 * TOL
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev), allow_unused=True)
+    assert rel_err(H(grads[0]), c['gx']) < 2e-4          # histogram votes: piecewise-linear, fp32 floor/ceil sensitive
+    for ft in (0, 1):
+        c = load_golden('echo_lift.npz')[f'lift_block_t{ft}']
+        m = load_params(LiftBlock(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ft), c).to(dev)
+        xs = D(c['x'], dev).requires_grad_(True)
+        y = m(xs, D(c['edges'], dev), D(c['lift_sten'], dev))
+        assert rel_err(H(y), c['y']) < 5 * TOL
+        gx, = torch.autograd.grad(y, [xs], grad_outputs=D(c['gy'], dev))
+        assert rel_err(H(gx), c['gx']) < 1e-4
+
+
+# ---------------------------------------------------------------- seeded inputs vs the oracle
+def make_case(seed, N, k, I, O, B, R, sort_by_source=True, zero_frac=0.01):
+    g = torch.Generator().manual_seed(seed)
+    dst = torch.arange(N).repeat_interleave(k)
+    src = torch.randint(0, N, (N * k,), generator=g)
+    keep = torch.rand(N * k, generator=g) > 0.1
+    keep &= (dst % 37) != 5                        # some vertices without in-edges
+    src, dst = src[keep], dst[keep]
+    perm = torch.randperm(src.numel(), generator=g)
+    src, dst = src[perm], dst[perm]
+    if sort_by_source:
+        o = torch.argsort(src, stable=True)
+        src, dst = src[o], dst[o]
+    E = src.numel()
+    edges = torch.stack((src, dst), 1)
+    F = 2 * B + 1
+    sten = torch.complex(torch.randn(E, R, F, generator=g), torch.randn(E, R, F, generator=g)) * (0.5 / k ** 0.5)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    x[torch.rand(N, I, generator=g) < zero_frac] = 0
+    x[0, 0] = complex(5e-8, -2e-8)
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, F, generator=g), torch.randn(O, I, R, F, generator=g)) * (1.0 / (I * R) ** 0.5)
+    return edges, sten, x, gy, W
+
+
+CASES = [
+    # seed, N,   k,  I,  O,  B, R, sorted
+    (1, 1000, 20, 48, 48, 2, 6, True),      # the benchmark shape, small mesh
+    (2, 777, 12, 48, 48, 2, 6, False),     # unsorted edges, ragged tail tile (777 = 48*16 + 9)
+    (3, 500, 16, 64, 64, 3, 6, True),      # FAUST config: C=64, B=3
+    (4, 300, 9, 16, 16, 2, 6, True),       # SHREC config: C=16
+    (5, 260, 9, 48, 8, 2, 6, True),        # ECHOBlock-like width change
+    (6, 333, 7, 3, 48, 1, 6, False),
+    (7, 150, 40, 32, 33, 2, 8, True),
+    (8, 100, 5, 17, 5, 1, 3, True),
+    (9, 15, 4, 8, 8, 2, 4, True),          # fewer vertices than one tile
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'N%d_k%d_I%d_O%d_B%d_R%d' % c[1:7])
+def test_fieldconv_vs_oracle(case, dev):
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    seed, N, k, I, O, B, R, srt = case
+    edges, sten, x, gy, W = make_case(seed, N, k, I, O, B, R, srt)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(y), y_ref) < TOL
+    assert rel_err(H(gx), gx_ref) < TOL
+    assert rel_err(H(gW), gW_ref) < TOL
+
+
+def test_empty_graph_and_isolated_vertices(dev):
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    N, I, O, B, R = 40, 8, 8, 1, 3
+    g = torch.Generator().manual_seed(0)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g)).to(dev).requires_grad_(True)
+    W = torch.complex(torch.randn(O, I, R, 3, generator=g), torch.randn(O, I, R, 3, generator=g)).to(dev)
+    graph = SupportGraph(torch.zeros(0, 2, dtype=torch.long, device=dev), torch.zeros(0, R, 3, dtype=torch.cfloat, device=dev), N)
+    y = field_conv(x, W, graph)
+    assert torch.count_nonzero(y) == 0
+    gx, = torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y))
+    assert torch.count_nonzero(gx) == 0
+
+
+def test_unsupported_shapes_fail_loudly(dev):
+    from fieldconv_amd._lib import FieldConvNativeError
+    from fieldconv_amd.nn import FieldConv
+    conv = FieldConv(4, 4, band_limit=1, n_rings=7).to(dev)       # n_rings=7 is not compiled
+    x = torch.zeros(5, 4, dtype=torch.cfloat, device=dev)
+    with pytest.raises(FieldConvNativeError):
+        conv(x, torch.zeros(3, 2, dtype=torch.long, device=dev), torch.zeros(3, 7, 3, dtype=torch.cfloat, device=dev))
+
+
+# ---------------------------------------------------------------- full benchmark size: properties
+def test_full_size_properties(dev):
+    """Config 2 of BASELINE.json (20k vertices, k=32, C=48, B=2, R=6): the oracle needs ~32 GB at
+    this size, so check (a) a random subset of output rows / input-gradient rows against the oracle
+    on the sub-edge-lists that determine them, (b) linearity in the filter, (c) the adjoint identity
+    Re<gy, conv(x;V)> = Re<gW, V>, (d) bitwise run-to-run reproducibility."""
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    N, k, I, O, B, R = 20000, 32, 48, 48, 2, 6
+    edges, sten, x, gy, W = make_case(11, N, k, I, O, B, R, True)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+
+    g = torch.Generator().manual_seed(5)
+    sub = torch.randperm(N, generator=g)[:150]
+    # (a1) output rows depend only on the in-edges of those rows
+    mask = torch.isin(edges[:, 1], sub)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges[mask].numpy(), sten[mask].numpy(), W.numpy())
+    assert rel_err(H(y)[sub.numpy()], y_ref[sub.numpy()]) < TOL
+    # (a2) input-gradient rows depend only on the out-edges of those rows
+    mask = torch.isin(edges[:, 0], sub)
+    gx_ref, _ = orc.fieldconv_backward(x.numpy(), edges[mask].numpy(), sten[mask].numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(gx)[sub.numpy()], gx_ref[sub.numpy()]) < TOL
+
+    # (b) linearity in the filter
+    V = torch.complex(torch.randn(W.shape, generator=g), torch.randn(W.shape, generator=g)).to(dev) * 0.1
+    with torch.no_grad():
+        yv = field_conv(xd, V, graph)
+        ysum = field_conv(xd, Wd + V, graph)
+    assert rel_err(H(ysum), H(y + yv)) < TOL
+    # (c) adjoint identity for the filter gradient
+    lhs = torch.sum(torch.conj(gy.to(dev)) * yv).real.item()
+    rhs = torch.sum(torch.conj(gW) * V).real.item()
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0)
+    # (d) deterministic: no atomics anywhere on the path
+    y2 = field_conv(xd, Wd, graph)
+    gx2, gW2 = torch.autograd.grad(y2, [xd, Wd], grad_outputs=gy.to(dev))
+    assert torch.equal(torch.view_as_real(y2), torch.view_as_real(y))
+    assert torch.equal(torch.view_as_real(gx2), torch.view_as_real(gx))
+    assert torch.equal(torch.view_as_real(gW2), torch.view_as_real(gW))

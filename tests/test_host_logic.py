@@ -1,0 +1,224 @@
+"""CPU tests of the host-side logic of fieldconv_amd: module/state_dict layout, filter assembly,
+stencil assembly, graph preprocessing, torch-composite blocks, and the C-ABI surface (symbols only:
+no kernel launches without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, rel_err
+from oracle import fieldconv_oracle as orc
+
+import fieldconv_amd
+from fieldconv_amd import _lib
+from fieldconv_amd.graph import SupportGraph, get_graph
+from fieldconv_amd.nn import ECHO, ECHOBlock, FCResNetBlock, FieldConv, LiftBlock, TangentLin, TangentNonLin, TransField
+from fieldconv_amd.nn.field_conv import effective_filter
+from fieldconv_amd.transforms import FCPrecomp
+from fieldconv_amd.utils import isOrigin, softAbs, softAngle
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_builds_and_exports_every_declared_symbol():
+    from fieldconv_amd.build import build_native
+    path = build_native()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, 'include', 'fieldconv_hip.h')).read()
+    declared = set(re.findall(r'\b(fc_[a-z_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
+    assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
+    assert _lib.load(path).fc_abi_version() == 1
+
+
+def test_supported_query_and_sizes_need_no_gpu():
+    lib = _lib.load()
+    d = _lib.FcDims(20000, 640000, 48, 48, 6, 2)
+    assert lib.fc_supported(ctypes.byref(d)) == 1
+    assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d)) == 5 * 2 * 48 * 288
+    assert lib.fc_backward_workspace_bytes(ctypes.byref(d)) > 0
+    bad = _lib.FcDims(100, 10, 48, 48, 7, 2)
+    assert lib.fc_supported(ctypes.byref(bad)) == 0
+    wide = _lib.FcDims(100, 10, 128, 48, 6, 2)
+    assert lib.fc_supported(ctypes.byref(wide)) == 0
+    assert b'unsupported' in lib.fc_status_string(-2)
+
+
+def test_product_path_refuses_cpu_tensors():
+    conv = FieldConv(4, 4, band_limit=1, n_rings=3)
+    x = torch.zeros(5, 4, dtype=torch.cfloat)
+    edges = torch.zeros(3, 2, dtype=torch.long)
+    sten = torch.zeros(3, 3, 3, dtype=torch.cfloat)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        conv(x, edges, sten)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        TangentLin(4, 4)(x)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        TangentNonLin(4)(x)
+
+
+def test_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'fieldconv_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                imports = re.findall(r'^\s*(?:from|import)\s+([\w\.]+)', src, flags=re.M)
+                assert not any(m.split('.')[0] == 'oracle' for m in imports), f'{f} imports the oracle'
+
+
+# ------------------------------------------------------------------ modules / state_dict
+def test_state_dict_layout_matches_reference_fixture():
+    blocks = load_golden('blocks.npz')
+    for tag, c in blocks.items():
+        blk = FCResNetBlock(int(c['Cin']), int(c['Cout']), band_limit=int(c['B']), n_rings=int(c['R']),
+                            ftype=int(c['ftype']), frontload=bool(c['frontload']))
+        sd = blk.state_dict()
+        ref = {k[2:]: v for k, v in c.items() if k.startswith('p_')}
+        assert list(sd) == list(ref), tag            # same names, same order
+        for k in sd:
+            assert tuple(sd[k].shape) == ref[k].shape, (tag, k)
+        blk.load_state_dict({k: T(v) for k, v in ref.items()})     # a reference checkpoint loads
+    eb = load_golden('echo_lift.npz')['echo_block']
+    m = ECHOBlock(int(eb['Cin']), int(eb['Cout']), n_des=int(eb['n_des']), n_bins=int(eb['n_bins']),
+                  band_limit=int(eb['B']), n_rings=int(eb['R']), ftype=1)
+    ref = {k[2:]: v for k, v in eb.items() if k.startswith('p_')}
+    assert list(m.state_dict()) == list(ref)
+    m.load_state_dict({k: T(v) for k, v in ref.items()})
+    for ft in (0, 1):
+        lb = load_golden('echo_lift.npz')[f'lift_block_t{ft}']
+        m = LiftBlock(int(lb['Cin']), int(lb['Cout']), n_rings=int(lb['R']), ftype=ft)
+        ref = {k[2:]: v for k, v in lb.items() if k.startswith('p_')}
+        assert list(m.state_dict()) == list(ref)
+        m.load_state_dict({k: T(v) for k, v in ref.items()})
+
+
+@pytest.mark.parametrize('ftype', [0, 1, 2])
+def test_parameter_kinds_and_attributes(ftype):
+    conv = FieldConv(5, 7, band_limit=2, n_rings=6, ftype=ftype)
+    names = dict(conv.named_parameters())
+    assert ('phase' in names) == (ftype == 1)                 # buffer for ftype 0/2 (field_conv.py:75,93)
+    assert 'phase' in conv.state_dict()
+    assert (conv.in_channels, conv.out_channels, conv.R, conv.B, conv.ftype) == (5, 7, 6, 2, ftype)
+    assert callable(conv.WR)
+    assert torch.count_nonzero(conv.zonal) > 0
+
+
+@pytest.mark.parametrize('tag', sorted(k for k in load_golden('fieldconv.npz') if k.endswith('f32')))
+def test_effective_filter_and_its_autograd(tag):
+    c = load_golden('fieldconv.npz')[tag]
+    ftype, B = int(c['ftype']), int(c['B'])
+    z, s, p = (T(c['zonal']).requires_grad_(True), T(c['spherical']).requires_grad_(True),
+               T(c['phase']).requires_grad_(ftype == 1))
+    W = effective_filter(z, s, p, ftype, B)
+    W_ref = orc.effective_filter(c['zonal'], c['spherical'], c['phase'], ftype, B)
+    assert rel_err(W.detach().numpy(), W_ref) < 1e-6
+    # y through the (oracle-checked) closed form, from our W
+    y = orc.fieldconv_forward(c['x'], c['edges'], c['sten'], W.detach().numpy())
+    assert rel_err(y, c['y']) < 2e-6
+    # parameter gradients: oracle dL/dW_eff pulled back through torch autograd of effective_filter
+    _, gW = orc.fieldconv_backward(c['x'], c['edges'], c['sten'], W_ref, c['gy'])
+    ins = [z, s] + ([p] if ftype == 1 else [])
+    grads = torch.autograd.grad(W, ins, grad_outputs=T(gW.astype(np.complex64)))
+    assert rel_err(grads[0].numpy(), c['g_zonal']) < 1e-5
+    assert rel_err(grads[1].numpy(), c['g_spherical']) < 1e-5
+    if ftype == 1:
+        assert rel_err(grads[2].numpy(), c['g_phase']) < 1e-5
+    # WR keeps the reference call signature
+    conv = FieldConv(c['x'].shape[1], c['y'].shape[1], band_limit=B, n_rings=int(c['R']), ftype=ftype)
+    contrib = orc.fieldconv_contrib(c['x'], c['edges'], c['sten'], B)
+    y2 = conv.WR(T(contrib), z.detach(), s.detach(), p.detach(), B)
+    assert rel_err(y2.numpy(), c['y']) < 2e-6
+
+
+# ------------------------------------------------------------------ zero-safe helpers
+def test_soft_helpers_match_oracle_and_have_finite_grads():
+    z = torch.tensor([0j, 3e-8 - 5e-8j, 9.9e-8 + 2e-7j, -1e-7 + 0j, 2.5j, -1.5 + 0j, 1 + 1j], dtype=torch.cfloat,
+                     requires_grad=True)
+    assert np.array_equal(isOrigin(z).numpy(), orc.is_origin(z.detach().numpy()))
+    assert np.allclose(softAngle(z).detach().numpy(), orc.soft_angle(z.detach().numpy()), atol=1e-7)
+    assert np.allclose(softAbs(z).detach().numpy(), orc.soft_abs(z.detach().numpy()), atol=1e-7)
+    g, = torch.autograd.grad((softAngle(z) + softAbs(z)).sum(), z)
+    assert torch.isfinite(torch.view_as_real(g)).all()
+    assert g[0] == 0 and g[1] == 0                      # no gradient inside the origin box
+
+
+# ------------------------------------------------------------------ stencil assembly
+class _D:
+    pass
+
+
+@pytest.mark.parametrize('tag', sorted(load_golden('precomp.npz')))
+def test_fc_precomp_matches_reference(tag):
+    c = load_golden('precomp.npz')[tag]
+    d = _D()
+    d.logMag, d.logAng, d.w, d.supp_edges, d.xp = T(c['logMag']), T(c['logAng']), T(c['w']), T(c['edges']), T(c['xp'])
+    e, sten, ln, wxp = FCPrecomp(int(c['B']), int(c['R']), float(c['eps']))(d)
+    assert torch.equal(e, T(c['out_edges']))
+    assert rel_err(sten.numpy(), c['out_sten']) < 5e-6
+    assert rel_err(ln.numpy(), c['out_ln']) < 5e-6
+    assert rel_err(wxp.numpy(), c['out_wxp']) < 5e-6
+    assert sten.dtype == torch.cfloat
+
+
+# ------------------------------------------------------------------ graph preprocessing
+def test_support_graph_groups_edges_both_ways():
+    g = torch.Generator().manual_seed(3)
+    N, E = 23, 150
+    edges = torch.randint(0, N, (E, 2), generator=g)
+    edges[edges[:, 1] == 5, 1] = 6                     # vertex 5 has no in-edges
+    sten = torch.complex(torch.randn(E, 3, 3, generator=g), torch.randn(E, 3, 3, generator=g))
+    gr = SupportGraph(edges, sten, N)
+    for rowptr, nbr, st, key, other in ((gr.rowptr_t, gr.nbr_t, gr.sten_t, 1, 0), (gr.rowptr_s, gr.nbr_s, gr.sten_s, 0, 1)):
+        assert rowptr[0] == 0 and rowptr[-1] == E and rowptr.dtype == torch.int32 and nbr.dtype == torch.int32
+        for v in range(N):
+            ids = torch.nonzero(edges[:, key] == v).squeeze(-1)          # stable: original order within a group
+            lo, hi = int(rowptr[v]), int(rowptr[v + 1])
+            assert hi - lo == ids.numel()
+            assert torch.equal(nbr[lo:hi].long(), edges[ids, other])
+            assert torch.equal(st[lo:hi], sten[ids])
+    assert gr.rowptr_t[6] == gr.rowptr_t[5]
+    # source-sorted input (the reference's order): no second stencil copy
+    order = torch.argsort(edges[:, 0], stable=True)
+    gr2 = SupportGraph(edges[order], sten[order], N)
+    assert gr2.sten_s.data_ptr() == sten[order].contiguous().data_ptr() or torch.equal(gr2.sten_s, sten[order])
+    # cache: same tensors -> same object; in-place edit -> rebuilt
+    a = get_graph(edges, sten, N)
+    assert get_graph(edges, sten, N) is a
+    sten.mul_(2)
+    assert get_graph(edges, sten, N) is not a
+    with pytest.raises(ValueError):
+        SupportGraph(edges, sten.to(torch.cdouble), N)
+    empty = SupportGraph(torch.zeros(0, 2, dtype=torch.long), torch.zeros(0, 3, 3, dtype=torch.cfloat), 4)
+    assert empty.rowptr_t.tolist() == [0] * 5
+
+
+# ------------------------------------------------------------------ torch-composite "next" rows
+def test_echo_descriptor_matches_reference():
+    c = load_golden('echo_lift.npz')['echo']
+    m = ECHO(c['x'].shape[1], int(c['n_bins']))
+    assert torch.equal(m.dMap, T(c['dMap']))
+    x = T(c['x']).requires_grad_(True)
+    y = m(x, T(c['edges']), T(c['ln']), T(c['wxp']))
+    assert rel_err(y.detach().numpy(), c['y']) < 5e-6
+    gx, = torch.autograd.grad(y, x, grad_outputs=T(c['gy']))
+    assert rel_err(gx.numpy(), c['gx']) < 5e-5
+
+
+@pytest.mark.parametrize('ftype', [0, 1])
+def test_trans_field_matches_reference(ftype):
+    c = load_golden('echo_lift.npz')[f'lift_block_t{ftype}']
+    m = TransField(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ftype)
+    m.load_state_dict({k[len('p_field.'):]: T(v) for k, v in c.items() if k.startswith('p_field.')})
+    y = m(T(c['x']), T(c['edges']), T(c['lift_sten']))
+    # LiftBlock output = modReLU(TransField); check through the oracle's modReLU
+    out = orc.tangent_nonlin_forward(y.detach().numpy(), c['p_nonlin.bias'])
+    assert rel_err(out, c['y']) < 5e-6
