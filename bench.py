@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the FieldConv hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one FieldConv layer forward + backward (input gradient, filter-parameter gradients, the
+filter assembly and its autograd chain included) on a synthetic sphere mesh of 20 000 vertices per
+GPU, k = 32 in-neighbours, C = 48 -> 48 channels, band_limit 2, n_rings 6, ftype 1, fp32 -- the
+shape BASELINE.json's metric is quoted on.  With N > 1 (launched by torch.distributed.run, one rank
+per GPU) the mesh has N x 20 000 vertices, is partitioned into N latitude bands, and every step
+also runs the one-hop halo exchange (forward and transposed) and the all-reduce of the parameter
+gradients over RCCL: weak scaling.  Inputs are resident in HBM before the timed region; support
+graph preprocessing (CSR by target / by source, stencil permutation) is done once outside it and
+reported separately, as it is shared by every convolution of a network.
+
+Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 MFMA == fp32 vector peak on gfx950
+
+
+def algorithmic_bytes(N, E, I, O, R, F):
+    """Compulsory traffic of the operator contract with int32 indices, everything touched once
+    (SURVEY.md 8(d) / BASELINE.md section 4)."""
+    fwd = E * (8 * R * F + 4) + 4 * N + 8 * N * (I + O) + 8 * O * I * R * F
+    bwd = E * (8 * R * F + 8) + 8 * N + 8 * N * (2 * I + O) + 16 * O * I * R * F
+    return fwd, bwd
+
+
+def algorithmic_flops(N, E, I, O, R, F):
+    gather = 8 * E * I * R * F
+    gemm = 8 * N * O * I * R * F
+    return gather + gemm, gather + 2 * gemm       # fwd, bwd (H gather + two contractions)
+
+
+def cpu_baseline(B, R, C, k, threads):
+    """Reference algorithm (oracle/reference_port_torch.py) on the host cores, bounded sample."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.transforms import FCPrecomp
+    from fieldconv_amd.nn import FieldConv
+    from oracle import reference_port_torch as port
+    n_s = 2500
+    torch.set_num_threads(threads)
+    data = sphere_support(n_s, k=k, seed=1)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(1)
+    x = torch.complex(torch.randn(n_s, C, generator=g), torch.randn(n_s, C, generator=g)).requires_grad_(True)
+    gy = torch.complex(torch.randn(n_s, C, generator=g), torch.randn(n_s, C, generator=g))
+    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1)       # parameter container only (CPU)
+    params = [conv.zonal, conv.spherical, conv.phase]
+
+    def step():
+        y = port.field_conv(x, edges, sten, conv.zonal, conv.spherical, conv.phase, 1, B)
+        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+    step()
+    best = float('inf')
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step()
+        best = min(best, time.perf_counter() - t0)
+    E = edges.shape[0]
+    return {'value': E / best / 1e6, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
+            'sample': f'reference-structured torch CPU port (oracle/reference_port_torch.py), one FieldConv fwd+bwd on a '
+                      f'{n_s}-vertex sphere mesh, k={k}, C={C}, B={B}, R={R} (E={E}); best of 2 after 1 warm-up, '
+                      f'{best:.2f} s per step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--verts', type=int, default=20000, help='vertices per GPU')
+    ap.add_argument('--k', type=int, default=32)
+    ap.add_argument('--channels', type=int, default=48)
+    ap.add_argument('--band-limit', type=int, default=2)
+    ap.add_argument('--n-rings', type=int, default=6)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from fieldconv_amd.data import sphere_partition
+    from fieldconv_amd.dist import HaloPlan, halo_exchange
+    from fieldconv_amd.functional import kernel_timer
+    from fieldconv_amd.graph import get_graph
+    from fieldconv_amd.nn import FieldConv
+    from fieldconv_amd.transforms import FCPrecomp
+
+    B, R, C, k = args.band_limit, args.n_rings, args.channels, args.k
+    F = 2 * B + 1
+    n_total = args.verts * world
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0)
+    data = data.to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    n_local = data.num_nodes
+    E = int(edges.shape[0])
+    plan = HaloPlan(n_owned, halo_global, bounds, device=dev) if world > 1 else None
+
+    torch.manual_seed(1234)                                  # identical parameters on every rank
+    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
+    params = list(conv.parameters())
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g))
+    x[torch.rand(n_owned, C, generator=g) < 0.01] = 0        # 1 % exact zeros (origin-box path)
+    x = x.to(dev).requires_grad_(True)
+    gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    get_graph(edges, sten, n_local)
+    torch.cuda.synchronize()
+    prep_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        xl = halo_exchange(x, plan) if plan is not None else x
+        y = conv(xl, edges, sten)
+        if plan is not None:
+            y = y[:n_owned]
+        grads = torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+        if world > 1:
+            flat = torch.cat([t.reshape(-1) for t in grads[1:]])
+            dist.all_reduce(flat)
+        return grads
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    kernel_timer.reset()
+    kernel_timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ecount = torch.tensor([E], device=dev, dtype=torch.int64)
+        dist.all_reduce(ecount)
+        E_total = int(ecount.item())
+    else:
+        E_total = E
+    ms_per_step = elapsed / args.steps * 1e3
+    value = E_total / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        kt = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
+        fwd_b, bwd_b = algorithmic_bytes(n_local, E, C, C, R, F)
+        fwd_f, bwd_f = algorithmic_flops(n_local, E, C, C, R, F)
+        per_kernel = {}
+        for name, nbytes, nflops in (('fc_forward', fwd_b, fwd_f), ('fc_backward', bwd_b, bwd_f)):
+            if name in kt:
+                sec = kt[name] * 1e-3
+                per_kernel[name] = {'avg_ms': kt[name], 'algorithmic_bytes': nbytes, 'GBps': nbytes / sec / 1e9,
+                                    'hbm_frac': nbytes / sec / 1e9 / HBM_PEAK_GBS, 'algorithmic_flops': nflops,
+                                    'TFLOPs': nflops / sec / 1e12, 'mfma_f32_frac': nflops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if dom and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom + '_kernel', {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roofline = None
+        if dom:
+            roofline = {'bound': 'hbm', 'kernel': dom + '_kernel', 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': per_kernel[dom]['hbm_frac'], 'traffic': traffic,
+                        'avg_launch_ms': per_kernel[dom]['avg_ms'], 'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes'],
+                        'mfma_f32_frac': per_kernel[dom]['mfma_f32_frac']}
+        out = {
+            'metric': 'FieldConv fwd+bwd Medges/s (20k verts, k=32, C=48, M=2)',
+            'value': value, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1] shape: one FieldConv layer fwd+bwd on a synthetic sphere mesh, '
+                                   f'{args.verts} verts/GPU, k={k}, C={C}->{C}, band_limit={B}, n_rings={R}, ftype=1',
+                       'verts_per_gpu': args.verts, 'edges_total': E_total, 'k': k, 'channels': C, 'band_limit': B, 'n_rings': R,
+                       'parallelism': 'single GPU' if world == 1 else f'vertex partition x{world}, one-hop halo over RCCL',
+                       'halo_rows_rank0': 0 if plan is None else plan.n_halo},
+            'roofline': roofline,
+            'kernels': per_kernel,
+            'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'graph_preprocessing_ms': prep_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncpu = os.cpu_count() or 2
+            threads = max(1, ncpu // 2)                 # physical cores (SMT siblings excluded)
+            try:
+                out['cpu_baseline'] = cpu_baseline(B, R, C, k, threads)
+            except Exception as exc:                   # the GPU numbers stand on their own
+                out['cpu_baseline'] = {'value': None, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
+                                       'sample': f'failed: {type(exc).__name__}: {exc}'}
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -70,13 +70,19 @@ size_t fc_backward_workspace_bytes(const fc_dims* dims) {
 }
 
 int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
-                float* gx, float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
-    if (!x || !gy || !gx || !gw_eff || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims))
-        return FC_ERR_BAD_ARGUMENT;
+                void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!x || !gy || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!sten || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, gx, gw_eff, workspace, workspace_bytes, dims,
+    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, workspace, workspace_bytes, dims,
                              static_cast<hipStream_t>(stream));
+}
+
+int fc_backward_finish(float* gx, float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims,
+                       void* stream) {
+    if (!gx || !gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_finish_impl(gx, gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

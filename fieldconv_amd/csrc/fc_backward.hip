@@ -325,7 +325,7 @@ static int launch_backward(const BwdPtrs& q, const BwdArgs& a, const BwdPlan& p,
 }
 
 int backward_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk,
-                  float* gx, float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
+                  void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
     const BwdPlan p = plan_backward(d);
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.gxp_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
@@ -347,12 +347,22 @@ int backward_impl(const float* x, const float* gy, const float* sten, const fc_c
 #define FC_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_backward<RR, BB>(q, a, p, stream);
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
-    if (rc != FC_OK) return rc;
+    return rc;
+}
+
+// Second stage of the backward pass: fixed-order sums of the per-frequency gx terms and the
+// per-workgroup gW partials left in the workspace by backward_impl.
+int backward_finish_impl(float* gx, float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
+    const BwdPlan p = plan_backward(d);
+    if (!p.ok) return FC_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < p.gxp_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
+    const float2* gxp = reinterpret_cast<const float2*>(ws);
+    const float2* gwp = reinterpret_cast<const float2*>(static_cast<char*>(ws) + p.gxp_bytes);
     const size_t NI = (size_t)d->N * d->I;
-    hipLaunchKernelGGL(fc_reduce_gx_kernel, dim3((unsigned)((NI + 255) / 256)), dim3(256), 0, stream, q.gxp,
+    hipLaunchKernelGGL(fc_reduce_gx_kernel, dim3((unsigned)((NI + 255) / 256)), dim3(256), 0, stream, gxp,
                        reinterpret_cast<float2*>(gx), NI, p.F);
     const int total = p.F * d->R * d->O * d->I;
-    hipLaunchKernelGGL(fc_reduce_gw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, q.gwp,
+    hipLaunchKernelGGL(fc_reduce_gw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, gwp,
                        reinterpret_cast<float2*>(gw_eff), p.P, p.F, d->R, d->O, d->I, p.KP, p.IP);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }

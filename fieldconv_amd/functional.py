@@ -11,6 +11,43 @@ from . import _lib
 from ._lib import FcCsr, FcDims, check
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around the single-kernel launches `fc_forward` / `fc_backward`
+    (each of those entry points enqueues exactly one kernel on the current stream).  bench.py turns
+    it on for the timed region to obtain per-kernel durations for the roofline figure."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def reset(self):
+        self.events = {}
+
+    def elapsed_ms(self):
+        """{name: [ms, ...]}; call after torch.cuda.synchronize()."""
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+
+
+kernel_timer = KernelTimer()
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if kernel_timer.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if kernel_timer.enabled:
+            self.b.record()
+            kernel_timer.events.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _require_device(t, what):
     if not t.is_cuda:
         raise RuntimeError(f'{what}: fieldconv_amd runs on a ROCm device only (got a {t.device} tensor); '
@@ -59,8 +96,9 @@ class _FieldConvFn(torch.autograd.Function):
             check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), st), 'fc_pack_filter')
             y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
             csr = _csr(graph.rowptr_t, graph.nbr_t)
-            check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                  'fc_forward')
+            with _timed('fc_forward'):
+                check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                      'fc_forward')
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
         ctx.wshape = (O, I, R, F)
@@ -81,8 +119,10 @@ class _FieldConvFn(torch.autograd.Function):
             nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             csr = _csr(graph.rowptr_s, graph.nbr_s)
-            check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(gw), _p(ws),
-                                  nbytes, ctypes.byref(dims), st), 'fc_backward')
+            with _timed('fc_backward'):
+                check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(ws), nbytes,
+                                      ctypes.byref(dims), st), 'fc_backward')
+            check(lib.fc_backward_finish(_p(gx), _p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
         return gx, gw, None
 
 

@@ -75,12 +75,17 @@ int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const
                float* y, const fc_dims* dims, void* stream);
 
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
- * gx (N,I) c64 and gw_eff (O,I,R,F) c64 are overwritten.  by_source: CSR grouped by source.
- * workspace: fc_backward_workspace_bytes(dims) bytes, 256-byte aligned. */
+ * Two stages on the same stream.  fc_backward launches the one heavy kernel (source-centric
+ * gather + both MFMA contractions); it leaves per-frequency gx terms and per-workgroup filter
+ * gradient partials in `workspace`.  fc_backward_finish reduces them, in a fixed order, into
+ * gx (N,I) c64 and gw_eff (O,I,R,F) c64 (both overwritten).  by_source: CSR grouped by source.
+ * workspace: fc_backward_workspace_bytes(dims) bytes, 256-byte aligned, untouched in between. */
 size_t fc_backward_workspace_bytes(const fc_dims* dims);
 int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source,
-                const float* wpk_bwd, float* gx, float* gw_eff, void* workspace, size_t workspace_bytes,
+                const float* wpk_bwd, void* workspace, size_t workspace_bytes,
                 const fc_dims* dims, void* stream);
+int fc_backward_finish(float* gx, float* gw_eff, void* workspace, size_t workspace_bytes,
+                       const fc_dims* dims, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */

@@ -1,0 +1,81 @@
+"""Worker for tests/test_distributed_cpu.py: world_size-2 gloo run of the vertex-partition + halo
+exchange path.  The local convolution is the CPU oracle (this is a test of the partition / exchange
+logic, which is backend-agnostic torch.distributed code; the HIP kernels are covered by -m gpu)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fieldconv_amd.data import sphere_partition                     # noqa: E402
+from fieldconv_amd.dist import HaloPlan, halo_exchange              # noqa: E402
+from fieldconv_amd.transforms import FCPrecomp                      # noqa: E402
+from oracle import fieldconv_oracle as orc                          # noqa: E402
+
+
+class OracleConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, edges, sten):
+        ctx.save_for_backward(x, W, edges, sten)
+        return torch.from_numpy(orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy()).astype(np.complex64))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, edges, sten = ctx.saved_tensors
+        gx, gW = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+        return torch.from_numpy(gx.astype(np.complex64)), torch.from_numpy(gW.astype(np.complex64)), None, None
+
+
+def features(n_total, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.complex(torch.randn(n_total, C, generator=g), torch.randn(n_total, C, generator=g))
+
+
+def main():
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_total, k, C, O, B, R = 400, 8, 5, 4, 1, 3
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    assert edges.shape[0] == n_owned * k
+    plan = HaloPlan(n_owned, halo_global, bounds, device='cpu')
+    lo = int(bounds[rank])
+    x_all = features(n_total, C, 1)
+    gy_all = features(n_total, O, 2)
+    g = torch.Generator().manual_seed(9)
+    W = torch.complex(torch.randn(O, C, R, 2 * B + 1, generator=g), torch.randn(O, C, R, 2 * B + 1, generator=g)).requires_grad_(True)
+    x_owned = x_all[lo:lo + n_owned].clone().requires_grad_(True)
+
+    x_local = halo_exchange(x_owned, plan)
+    # the halo rows must be exactly the owners' rows
+    assert torch.equal(x_local[n_owned:].detach(), x_all[halo_global])
+    y_local = OracleConv.apply(x_local, W, edges, sten)
+    y_owned = y_local[:n_owned]
+    gx, gW = torch.autograd.grad(y_owned, [x_owned, W], grad_outputs=gy_all[lo:lo + n_owned])
+    gWr = torch.view_as_real(gW.contiguous()).clone()
+    dist.all_reduce(gWr)
+
+    # single-process answer on the unpartitioned mesh
+    full, _, _, _ = sphere_partition(n_total, 1, 0, k=k, seed=3)
+    fe, fs, _, _ = FCPrecomp(B, R, full.epsilon)(full)
+    y_ref = orc.fieldconv_forward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy(), gy_all.numpy())
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    e_y = rel(y_owned.detach().numpy(), y_ref[lo:lo + n_owned])
+    e_gx = rel(gx.numpy(), gx_ref[lo:lo + n_owned])
+    e_gw = rel(torch.view_as_complex(gWr).numpy(), gW_ref)
+    print(f'rank {rank}: n_owned={n_owned} halo={plan.n_halo} send={plan.send_counts} recv={plan.recv_counts} '
+          f'err y={e_y:.2e} gx={e_gx:.2e} gW={e_gw:.2e}', flush=True)
+    assert plan.n_halo > 0
+    assert e_y < 1e-5 and e_gx < 1e-5 and e_gw < 1e-5
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

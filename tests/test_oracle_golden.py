@@ -78,3 +78,21 @@ def test_fc_resnet_block_forward(tag):
     p = {k[2:]: v for k, v in c.items() if k.startswith('p_')}
     y = orc.fc_resnet_block_forward(c['x'], c['edges'], c['sten'], p, int(c['ftype']), int(c['B']))
     assert rel_err(y, c['y']) < 5e-6
+
+
+@pytest.mark.parametrize('tag', sorted(k for k in FC if k.endswith('f32')))
+def test_reference_port_torch(tag):
+    """The torch CPU port timed as `cpu_baseline` in bench.py reproduces the reference outputs/grads."""
+    import torch
+    from oracle import reference_port_torch as port
+    c = FC[tag]
+    ftype, B = int(c['ftype']), int(c['B'])
+    x = torch.from_numpy(c['x']).requires_grad_(True)
+    z = torch.from_numpy(c['zonal']).requires_grad_(True)
+    s = torch.from_numpy(c['spherical']).requires_grad_(True)
+    p = torch.from_numpy(c['phase']).requires_grad_(ftype == 1)
+    y = port.field_conv(x, torch.from_numpy(c['edges']), torch.from_numpy(c['sten']), z, s, p, ftype, B)
+    assert rel_err(y.detach().numpy(), c['y']) < TOL32
+    gx, gz = torch.autograd.grad(y, [x, z], grad_outputs=torch.from_numpy(c['gy']))
+    assert rel_err(gx.numpy(), c['gx']) < TOL32 * 5
+    assert rel_err(gz.numpy(), c['g_zonal']) < TOL32 * 5
