@@ -18,7 +18,7 @@ class FcDims(ctypes.Structure):
 
 
 class FcCsr(ctypes.Structure):
-    _fields_ = [('rowptr', _vp), ('nbr', _vp), ('eid', _vp)]
+    _fields_ = [('rowptr', _vp), ('nbr', _vp)]
 
 
 _DP = ctypes.POINTER(FcDims)
@@ -33,6 +33,8 @@ SIGNATURES = {
     'fc_packed_filter_floats_bwd': (_sz, [_DP]),
     'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _vp]),
     'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
+    'fc_factored_record_floats': (ctypes.c_int, [_c_int32]),
+    'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
     'fc_backward_workspace_bytes': (_sz, [_DP]),
     'fc_backward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _vp, _sz, _DP, _vp]),

@@ -33,7 +33,7 @@ struct BwdArgs {
 template <int R, int B, int T>
 __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
     const float2* __restrict__ gx_, const float2* __restrict__ ggy, const float* __restrict__ gsten,
-    const int32_t* __restrict__ growptr, const int32_t* __restrict__ gnbr, const int32_t* __restrict__ geid,
+    const int32_t* __restrict__ growptr, const int32_t* __restrict__ gnbr,
     const float* __restrict__ gwpk, float2* __restrict__ ggxp /* [F][N][I] */,
     float2* __restrict__ ggwp /* [P][F][KP][IP] */, const BwdArgs a) {
     constexpr int F = 2 * B + 1;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
         float2 g_next = make_float2(0.f, 0.f);
         if (beg < end) {
             d_next = gnbr[beg];
-            row_next = geid ? geid[beg] : beg;
+            row_next = beg;
             g_next = ggy[(size_t)d_next * O + ol];
         }
         for (int e = beg; e < end; ++e) {
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
             float2 g = g_next;
             if (e + 1 < end) {
                 d_next = gnbr[e + 1];
-                row_next = geid ? geid[e + 1] : e + 1;
+                row_next = e + 1;
                 g_next = ggy[(size_t)d_next * O + ol];
             }
             if (!has_o) g = make_float2(0.f, 0.f);
@@ -311,7 +311,7 @@ static int launch_backward_t(const BwdPtrs& q, const BwdArgs& a, const BwdPlan& 
             return FC_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds, stream, q.x, q.gy, q.sten, q.g->rowptr, q.g->nbr,
-                       q.g->eid, q.wpk, q.gxp, q.gwp, a);
+                       q.wpk, q.gxp, q.gwp, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fc {
 
@@ -27,6 +28,29 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Compile-time loop: fn(std::integral_constant<int, i>) for i in [BEGIN, END).
+template <int BEGIN, int END, class Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+    if constexpr (BEGIN < END) {
+        fn(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(fn);
+    }
+}
+
+// Floats per edge record of the factored stencil (see fc_forward.hip): header of 4 + F complex phases,
+// rounded up to a multiple of 4 floats so records stay 16-byte aligned.
+__host__ __device__ constexpr int factored_record_floats(int B) { return round_up(4 + 2 * (2 * B + 1), 4); }
+
+// Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
+__host__ __device__ constexpr int factored_log_chunk_records(int B) {
+    const int per_kib = 256 / factored_record_floats(B);
+    return per_kib >= 32 ? 5 : per_kib >= 16 ? 4 : per_kib >= 8 ? 3 : per_kib >= 4 ? 2 : 1;
+}
+constexpr int kRingChunks = 4;     // 1 KiB chunks per wavefront in the record ring (power of two, >= 3)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source
+typedef __attribute__((address_space(3))) void* lptr_t;         // global_load_lds destination (wave-uniform base)
 
 // LDS row stride (floats) for a slab with KP (multiple of 16) k-entries per vertex:
 // KP + 8 keeps the 16x4 float4 fragment reads bank-conflict free (stride = 8 mod 16).
@@ -54,15 +78,118 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {   // a * conj(
 }
 
 // All 2B+1 rotated copies xt[f] = z * u^(f-B) (reference nn/field_conv.py:128-130).
+// Slot B+1 (m = +1) is z*u = |z|, real up to rounding: it is stored as (|z|, *) and consumed by
+// cmac_sx_real (inside the origin box u = 1 and the copy is z itself, whose imaginary part, below
+// 1e-7 in magnitude, is dropped there).
 template <int B>
 __device__ __forceinline__ void rotate_all(float2 z, float2 (&xt)[2 * B + 1]) {
-    const float2 u = unit_conj(z);
+    const bool org = is_origin(z);
+    const float n2 = z.x * z.x + z.y * z.y;
+    const float inv = org ? 0.f : __frsqrt_rn(n2);
+    const float2 u = org ? make_float2(1.f, 0.f) : make_float2(z.x * inv, -z.y * inv);
     xt[B] = z;
+    if (B >= 1) {
+        xt[B + 1] = org ? z : make_float2(n2 * inv, 0.f);
+        xt[B - 1] = cmul_conj(z, u);
+    }
 #pragma unroll
-    for (int m = 1; m <= B; ++m) {
+    for (int m = 2; m <= B; ++m) {
         xt[B + m] = cmul(xt[B + m - 1], u);
         xt[B - m] = cmul_conj(xt[B - m + 1], u);
     }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Complex multiply-accumulate on packed fp32: acc (re,im) += s * x with s a WAVE-UNIFORM complex
+// number in an SGPR pair and x a per-lane complex number.  Plain wave64 FMAs issue every 4 cycles on
+// gfx950 (measured 76 TFLOP/s with an SGPR operand); v_pk_fma_f32 does two per lane in the same
+// slot (146 TFLOP/s, tools/ubench/pk_fma.hip).  Written with the generic vector fma so the
+// register allocator sees ordinary values (inline-asm FMAs with tied operands made hipcc copy
+// every accumulator once per edge); hipcc folds the broadcasts into op_sel / one s_mov:
+//   acc += (s.re, s.re) * (x.re, x.im);   acc += (s.im, s.im) * (-x.im, x.re)
+// `xs` = (-x.im, x.re) is formed once per rotated feature, not per ring.
+__device__ __forceinline__ void cmac_sx(f32x2& acc, f32x2 s, f32x2 x, f32x2 xs) {
+    acc = __builtin_elementwise_fma(f32x2{s.x, s.x}, x, acc);
+    acc = __builtin_elementwise_fma(f32x2{s.y, s.y}, xs, acc);
+}
+// acc += s * a for a REAL per-lane a (the m = +1 slot, x*u = |x|): one instruction.
+__device__ __forceinline__ void cmac_sx_real(f32x2& acc, f32x2 s, float a) {
+    acc = __builtin_elementwise_fma(s, f32x2{a, a}, acc);
+}
+// acc += g * conj(s) = (s.re, s.re)*(g.re, g.im) + (s.im, s.im)*(g.im, -g.re); gs = (g.im, -g.re)
+__device__ __forceinline__ void cmac_gconjs(f32x2& acc, f32x2 s, f32x2 g, f32x2 gs) {
+    acc = __builtin_elementwise_fma(f32x2{s.x, s.x}, g, acc);
+    acc = __builtin_elementwise_fma(f32x2{s.y, s.y}, gs, acc);
+}
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A run of NF (even) floats of a wave-uniform stream, held in SGPRs and loaded with hand-issued
+// scalar loads so that the load/wait placement is ours, not the compiler's (hipcc neither counts
+// nor waits for loads inside asm): issue() starts the s_load_dwordx{16,8,4,2} pieces, retire()
+// is the matching s_waitcnt lgkmcnt(0) and routes every piece through an asm so no use can be
+// scheduled above it.  Scalar loads return out of order, hence lgkmcnt(0) and one chunk in flight.
+template <int NF>
+struct SgprChunk {
+    static_assert(NF % 2 == 0 && NF >= 2 && NF <= 62, "chunk of 2..62 floats");
+    static constexpr int N16 = NF / 16, R16 = NF % 16;
+    static constexpr int N8 = R16 / 8, R8 = R16 % 8;
+    static constexpr int N4 = R8 / 4, R4 = R8 % 4;
+    static constexpr int N2 = R4 / 2;
+    f32x16 a[N16 ? N16 : 1];
+    f32x8 b;
+    f32x4 c;
+    f32x2 d;
+
+    __device__ __forceinline__ void issue(const float* __restrict__ p) {
+        // one base pointer (SGPR pair), byte offsets as instruction immediates
+        if (N16 > 0) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[0]) : "s"(p), "i"(0));
+        if (N16 > 1) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[N16 > 1 ? 1 : 0]) : "s"(p), "i"(64));
+        if (N16 > 2) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[N16 > 2 ? 2 : 0]) : "s"(p), "i"(128));
+        if (N8) asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(b) : "s"(p), "i"(64 * N16));
+        if (N4) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c) : "s"(p), "i"(64 * N16 + 32 * N8));
+        if (N2) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(d) : "s"(p), "i"(64 * N16 + 32 * N8 + 16 * N4));
+    }
+    __device__ __forceinline__ void retire() {
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        // (volatile asms keep their order; each piece is routed through one so that its uses follow the wait)
+#pragma unroll
+        for (int i = 0; i < N16; ++i) asm volatile("" : "+s"(a[i]));
+        if (N8) asm volatile("" : "+s"(b));
+        if (N4) asm volatile("" : "+s"(c));
+        if (N2) asm volatile("" : "+s"(d));
+    }
+    // complex entry k (floats 2k, 2k+1) as an SGPR pair; k must fold to a constant after unrolling,
+    // the pair is then an aligned sub-register of its piece (no copy)
+    __device__ __forceinline__ float elem(const int i) const {
+        if (i < 16 * N16) return a[i / 16][i % 16];
+        if (i < 16 * N16 + 8 * N8) return b[(i - 16 * N16) % 8];
+        if (i < 16 * N16 + 8 * N8 + 4 * N4) return c[(i - 16 * N16 - 8 * N8) % 4];
+        return d[(i - 16 * N16 - 8 * N8 - 4 * N4) % 2];
+    }
+    __device__ __forceinline__ f32x2 pair(const int k) const { return f32x2{elem(2 * k), elem(2 * k + 1)}; }
+};
+
+// Make the compiler retire its own pending scalar load of `v` here (empty asm consuming the SGPR).
+__device__ __forceinline__ void fc_keep_sgpr(int v) { asm volatile("" ::"s"(v)); }
+
+// Pull [base, base+bytes) towards L2 ahead of the scalar loads that will consume it: every lane
+// reads one float per 64-byte granule, up to 8 wave-instructions (32 KiB) in flight, values summed
+// into dead registers.  Plain loads on purpose: an asm load taking the pointer stops the compiler
+// from proving the stream read-only and it falls back to per-lane vector loads for the stencil.
+__device__ __forceinline__ void prefetch_range(const void* __restrict__ base, long bytes, int lane) {
+    const char* p = reinterpret_cast<const char*>(base);
+    float sink[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long off0 = 0; off0 < bytes; off0 += 8 * kWave * 64) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long off = off0 + (long)(j * kWave + lane) * 64;
+            if (off < bytes) sink[j] += *reinterpret_cast<const float*>(p + off);
+        }
+    }
+    asm volatile("" ::"v"(sink[0]), "v"(sink[1]), "v"(sink[2]), "v"(sink[3]), "v"(sink[4]), "v"(sink[5]), "v"(sink[6]), "v"(sink[7]));
 }
 
 // One rotated copy for a run-time frequency m (|m| <= B): returns u^m, the caller multiplies.

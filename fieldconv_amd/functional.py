@@ -63,7 +63,7 @@ def _p(t):
 
 
 def _csr(rowptr, nbr):
-    return FcCsr(rowptr.data_ptr(), nbr.data_ptr() if nbr.numel() else None, None)
+    return FcCsr(rowptr.data_ptr(), nbr.data_ptr() if nbr.numel() else None)
 
 
 def make_dims(graph, I, O, B):
@@ -97,8 +97,12 @@ class _FieldConvFn(torch.autograd.Function):
             y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
             csr = _csr(graph.rowptr_t, graph.nbr_t)
             with _timed('fc_forward'):
-                check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                      'fc_forward')
+                if graph.factored:
+                    check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y),
+                                                  ctypes.byref(dims), st), 'fc_forward_factored')
+                else:
+                    check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                          'fc_forward')
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
         ctx.wshape = (O, I, R, F)

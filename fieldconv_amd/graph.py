@@ -16,6 +16,7 @@ Everything runs on the device with torch ops (sort / bincount / cumsum / gather)
 host synchronisation.
 """
 import collections
+import os
 
 import torch
 
@@ -23,10 +24,52 @@ _CACHE_SIZE = 4
 _cache = collections.OrderedDict()
 
 
-class SupportGraph:
-    __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', '_keep')
+def factor_stencil(sten, tol=2e-6):
+    """Rank-1, ring-2-sparse factorisation of a dense stencil, or None if it does not have that
+    structure.  sten (E,R,F) complex64 -> records (E, RECF) float32 as documented in
+    include/fieldconv_hip.h (fc_forward_factored): [q bits, w_q, w_{q+1}, 0, Re/Im ph_f ...].
 
-    def __init__(self, supp_edges, supp_sten, N):
+    FCPrecomp builds supp_sten[e,r,f] = rSten[e,r] * fSten[e,f] * wxp[e] with exactly two adjacent
+    non-zero interpolation weights (reference transforms/fc_precomp.py:24-25,95); the check below
+    accepts any stencil of that shape (every row is reconstructed and compared), so hand-made dense
+    stencils simply stay on the dense kernels.  One host synchronisation (the verdict)."""
+    E, R, F = sten.shape
+    B = (F - 1) // 2
+    mag = sten.abs().amax(dim=2)                                   # (E,R)
+    nz = mag > 0
+    first = torch.argmax(nz.to(torch.int8), dim=1)                 # first non-zero ring, 0 if the row is empty
+    q = torch.clamp(first, max=R - 2)
+    ring = torch.arange(R, device=sten.device)[None, :]
+    outside = nz & ((ring < q[:, None]) | (ring > q[:, None] + 1))
+    rows = torch.arange(E, device=sten.device)
+    s0 = sten[rows, q]                                             # (E,F)
+    s1 = sten[rows, q + 1]
+    ph = s0 + s1                                                   # = ph * (w_q + w_{q+1}); weights are rescaled below
+    den = (ph.real ** 2 + ph.imag ** 2).sum(1)
+    safe = torch.where(den > 0, den, torch.ones_like(den))
+    w0 = (s0 * ph.conj()).sum(1).real / safe
+    w1 = (s1 * ph.conj()).sum(1).real / safe
+    w0 = torch.where(den > 0, w0, torch.zeros_like(w0))
+    w1 = torch.where(den > 0, w1, torch.zeros_like(w1))
+    err = torch.maximum((s0 - w0[:, None] * ph).abs().amax(1), (s1 - w1[:, None] * ph).abs().amax(1))
+    scale = mag.amax(1)
+    bad = outside.any() | (err > tol * scale).any()
+    if bool(bad):
+        return None
+    recf = (4 + 2 * F + 3) // 4 * 4
+    rec = torch.zeros((E, recf), dtype=torch.float32, device=sten.device)
+    rec[:, 0] = q.to(torch.int32).view(torch.float32)
+    rec[:, 1] = w0
+    rec[:, 2] = w1
+    rec[:, 4:4 + 2 * F] = torch.view_as_real(ph.contiguous()).reshape(E, 2 * F)
+    return rec
+
+
+class SupportGraph:
+    __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
+                 'rec_s', '_keep')
+
+    def __init__(self, supp_edges, supp_sten, N, allow_factored=True):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
             raise ValueError('supp_edges must have shape (E, 2)')
         if supp_sten.dim() != 3 or supp_sten.shape[0] != supp_edges.shape[0]:
@@ -42,29 +85,56 @@ class SupportGraph:
         src = supp_edges[:, 0].to(torch.int64)
         dst = supp_edges[:, 1].to(torch.int64)
 
-        def group(key, other):
+        def group(key, other, minor=None):
+            """CSR of `key` (stable; ties ordered by `minor` if given): rowptr, other[perm] as int32, perm."""
             if E == 0:
                 z = torch.zeros(self.N + 1, dtype=torch.int32, device=dev)
                 e = torch.zeros(0, dtype=torch.int32, device=dev)
                 return z, e, None
-            sorted_key, perm = torch.sort(key, stable=True)
+            if minor is None:
+                sorted_key, perm = torch.sort(key, stable=True)
+            else:
+                _, perm = torch.sort(key * self.R + minor, stable=True)
+                sorted_key = key[perm]
             counts = torch.bincount(sorted_key, minlength=self.N)[: self.N]
             rowptr = torch.zeros(self.N + 1, dtype=torch.int32, device=dev)
             rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
             return rowptr, other[perm].to(torch.int32).contiguous(), perm
 
         sten = supp_sten.contiguous()
-        self.rowptr_t, self.nbr_t, perm_t = group(dst, src)
-        self.rowptr_s, self.nbr_s, perm_s = group(src, dst)
-        if E == 0:
-            self.sten_t = self.sten_s = sten
-        else:
-            self.sten_t = sten.index_select(0, perm_t)
-            # input already grouped by source (the reference's own order): a stable sort is then the
-            # identity permutation and the stencil needs no second copy (one host sync per build)
-            by_source = bool((src[1:] >= src[:-1]).all()) if E > 1 else True
-            self.sten_s = sten if by_source else sten.index_select(0, perm_s)
         self._keep = (supp_edges, supp_sten)      # pins the storages the cache key refers to
+        self.factored = False
+        self.rec_t = self.rec_s = self.sten_t = self.sten_s = None
+        # factored fast path: FCPrecomp's stencil is w[e,r] * ph[e,f] with two adjacent non-zero rings
+        rec = None
+        if allow_factored and E > 0 and self.R >= 2 and os.environ.get('FIELDCONV_DENSE', '0') != '1':
+            rec = factor_stencil(sten)
+        if rec is not None:
+            # records grouped by vertex and, inside a vertex, sorted by ring index q: the kernels walk
+            # R-1 runs with statically indexed accumulators; the other endpoint rides in the record
+            q = rec[:, 0].view(torch.int32).to(torch.int64)
+            pad = torch.zeros((1024 // (rec.shape[1] * 4) + 16, rec.shape[1]), dtype=rec.dtype, device=dev)
+            self.rowptr_t, self.nbr_t, perm_t = group(dst, src, q)
+            self.rowptr_s, self.nbr_s, perm_s = group(src, dst, q)
+            rt = rec.index_select(0, perm_t)
+            rt[:, 3] = self.nbr_t.view(torch.float32)
+            rs = rec.index_select(0, perm_s)
+            rs[:, 3] = self.nbr_s.view(torch.float32)
+            self.rec_t = torch.cat((rt, pad), 0)
+            self.rec_s = torch.cat((rs, pad), 0)
+            self.sten_s = sten.index_select(0, perm_s)      # dense rows in the same slot order (dense backward)
+            self.factored = True
+        else:
+            self.rowptr_t, self.nbr_t, perm_t = group(dst, src)
+            self.rowptr_s, self.nbr_s, perm_s = group(src, dst)
+            if E == 0:
+                self.sten_t = self.sten_s = sten
+            else:
+                self.sten_t = sten.index_select(0, perm_t)
+                # input already grouped by source (the reference's own order): a stable sort is then the
+                # identity permutation and the stencil needs no second copy (one host sync per build)
+                by_source = bool((src[1:] >= src[:-1]).all()) if E > 1 else True
+                self.sten_s = sten if by_source else sten.index_select(0, perm_s)
 
     def check_indices(self):
         """Debug helper: host-synchronising range check of the edge list."""

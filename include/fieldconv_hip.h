@@ -42,14 +42,12 @@ typedef struct fc_dims {
 } fc_dims;
 
 /* Edge list grouped by one endpoint (CSR).  Slot s in [rowptr[v], rowptr[v+1]) is one edge
- * incident to vertex v; nbr[s] is the OTHER endpoint.  `eid[s]` is the row of the stencil that
- * belongs to the slot, or eid == NULL when the stencil passed alongside is already stored in
- * slot order.  Grouped by target (col 1 of supp_edges) for the forward pass, by source (col 0)
- * for the backward pass. */
+ * incident to vertex v; nbr[s] is the OTHER endpoint.  Grouped by target (col 1 of supp_edges)
+ * for the forward pass, by source (col 0) for the backward pass.  The stencil passed alongside a
+ * CSR is stored in that CSR's SLOT order (the kernels stream it): see fc_forward / fc_backward. */
 typedef struct fc_csr {
     const int32_t* rowptr;   /* N+1 */
     const int32_t* nbr;      /* E   */
-    const int32_t* eid;      /* E or NULL */
 } fc_csr;
 
 int fc_abi_version(void);
@@ -70,9 +68,21 @@ int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_
 
 /* ---- FieldConv.forward, reference nn/field_conv.py:128-137 ------------------------------- *
  * y[n,o] = 1/F sum_{e: dst_e=n} sum_{i,r,f} x[src_e,i] e^{-i(f-B)phi[src_e,i]} S[e,r,f] W_eff[o,i,r,f]
- * x (N,I) c64, sten (E,R,F) c64, by_target: CSR grouped by target, y (N,O) c64 (overwritten). */
-int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const float* wpk_fwd,
+ * x (N,I) c64; by_target: CSR grouped by target; sten_t (E,R,F) c64 = supp_sten rows permuted into
+ * by_target slot order; y (N,O) c64 (overwritten). */
+int fc_forward(const float* x, const float* sten_t, const fc_csr* by_target, const float* wpk_fwd,
                float* y, const fc_dims* dims, void* stream);
+
+/* ---- factored stencil fast path ---------------------------------------------------------- *
+ * FCPrecomp's stencil (reference transforms/fc_precomp.py:24-25,95) is rank-1 and 2-sparse in the
+ * ring index: supp_sten[e,r,f] = w[e,r] * ph[e,f] with w[e,q], w[e,q+1] the only non-zeros.  When
+ * the caller has verified that structure it may pass, instead of the dense rows, one record of
+ * fc_factored_record_floats(B) floats per edge (in by_target slot order, followed by at least
+ * 1 KiB of readable padding):  [0] q as int32 bits, [1] w[q], [2] w[q+1],
+ * [3] the slot's other endpoint (= by_target->nbr[slot]) as int32 bits, [4+2f], [5+2f] = Re, Im ph[f].  Same result as fc_forward up to fp32 rounding. */
+int fc_factored_record_floats(int32_t band_limit);
+int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd,
+                        float* y, const fc_dims* dims, void* stream);
 
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
  * Two stages on the same stream.  fc_backward launches the one heavy kernel (source-centric

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Time fc_forward / fc_backward alone on the config-2 shape (HIP events, median of reps)."""
+import os
+import sys
+import ctypes
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fieldconv_amd import _lib
+from fieldconv_amd.data import random_support, sphere_support
+from fieldconv_amd.functional import _csr, _p, _stream, make_dims
+from fieldconv_amd.graph import SupportGraph
+from fieldconv_amd.transforms import FCPrecomp
+
+kind = sys.argv[1] if len(sys.argv) > 1 else 'geo'
+N, k, C, B, R = 20000, 32, int(os.environ.get('C', 48)), 2, 6
+dev = torch.device('cuda:0')
+data = (sphere_support(N, k) if kind == 'geo' else random_support(N, k)).to(dev)
+edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+graph = SupportGraph(edges, sten, N)
+lib = _lib.load()
+g = torch.Generator().manual_seed(0)
+x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
+gy = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
+W = (torch.complex(torch.randn(C, C, R, 2 * B + 1, generator=g), torch.randn(C, C, R, 2 * B + 1, generator=g)) * 0.05).to(dev)
+dims = make_dims(graph, C, C, B)
+wf = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), device=dev)
+wb = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), device=dev)
+lib.fc_pack_filter(_p(W), _p(wf), _p(wb), ctypes.byref(dims), _stream())
+y = torch.empty(N, C, dtype=torch.cfloat, device=dev)
+gx = torch.empty_like(x)
+gw = torch.empty_like(W)
+nb = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
+ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+ct, cs = _csr(graph.rowptr_t, graph.nbr_t), _csr(graph.rowptr_s, graph.nbr_s)
+sten_s = getattr(graph, 'sten_s')
+
+
+FACT = os.environ.get('FACT', '1') == '1' and graph.factored
+
+
+def fwd():
+    if FACT:
+        lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(ct), _p(wf), _p(y), ctypes.byref(dims), _stream())
+    else:
+        lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(ct), _p(wf), _p(y), ctypes.byref(dims), _stream())
+
+
+def bwd():
+    lib.fc_backward(_p(x), _p(gy), _p(sten_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+which = os.environ.get('WHICH', 'fb')
+tag = os.environ.get('FC_DEBUG', '0') + (' factored' if FACT else ' dense')
+if 'f' in which:
+    print(f'FC_DEBUG={tag} {kind} fwd median/min us: %.1f %.1f' % timeit(fwd))
+if 'b' in which:
+    print(f'FC_DEBUG={tag} {kind} bwd median/min us: %.1f %.1f' % timeit(bwd))
