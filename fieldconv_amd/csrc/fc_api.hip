@@ -84,7 +84,16 @@ int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr
     if (!x || !gy || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!sten || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, workspace, workspace_bytes, dims,
+    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, workspace, workspace_bytes, dims, false,
+                             static_cast<hipStream_t>(stream));
+}
+
+int fc_backward_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
+                         const float* wpk_bwd, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!x || !gy || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (dims->E > 0 && !rec_s) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_impl(x, gy, rec_s, by_source, wpk_bwd, workspace, workspace_bytes, dims, true,
                              static_cast<hipStream_t>(stream));
 }
 

@@ -13,8 +13,13 @@
 // (KP x IP complex, spread over the 16 wavefronts' MFMA accumulators) in registers while it
 // walks its source tiles persistently; gW partials (one per workgroup) and the per-frequency gx
 // terms are summed by two small reduction kernels in a fixed order (bitwise reproducible).
+//
+// As in the forward pass the gather has a dense variant (stencil rows through the scalar cache)
+// and a factored one (per-edge records through a per-wavefront LDS ring, see fc_forward.hip).
+#include <stdlib.h>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
+#include "fc_tile.hpp"
 
 namespace fc {
 
@@ -23,22 +28,28 @@ constexpr int kMaxGwTiles = 8;   // 16x16 complex gW tiles a wavefront can own
 // (pointers are separate __restrict__ kernel parameters, see fc_forward.hip)
 struct BwdArgs {
     int N, I, O;
-    int IP, KP, KS;      // IP = ceil16(I), KP = ceil16(R*O)
-    int NIT, NKP, KST;   // input-channel tiles, k partitions, 16-wide k blocks
+    MmaGeom g;           // M = I (rows of gxt), K = R*O
     int ntiles;
-    int ngw;             // KST * NIT gW tiles per frequency
+    int ngw;             // KST * NMT 16x16 gW tiles per frequency
+    int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
 };
 
 // T = 16x16 complex gW tiles owned by each wavefront (ceil(ngw / 16)); 8*T accumulator VGPRs.
-template <int R, int B, int T>
+template <int R, int B, int T, bool FACTORED>
 __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
     const float2* __restrict__ gx_, const float2* __restrict__ ggy, const float* __restrict__ gsten,
     const int32_t* __restrict__ growptr, const int32_t* __restrict__ gnbr,
     const float* __restrict__ gwpk, float2* __restrict__ ggxp /* [F][N][I] */,
-    float2* __restrict__ ggwp /* [P][F][KP][IP] */, const BwdArgs a) {
+    float2* __restrict__ ggwp /* [P][F][KP][MP] */, const BwdArgs a) {
     constexpr int F = 2 * B + 1;
+    constexpr int ROWF = 2 * R * F;
+    constexpr int RECF = factored_record_floats(B);
+    constexpr int LOG_CR = factored_log_chunk_records(B);
+    constexpr int CR = 1 << LOG_CR;
+    constexpr int NR = kRingChunks;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int KS = a.KS, KP = a.KP, IP = a.IP, I = a.I, O = a.O;
+    const MmaGeom& mg = a.g;
+    const int KS = mg.KS, KP = mg.KP, IP = mg.MP, I = a.I, O = a.O;
     float* const hre = reinterpret_cast<float*>(smem);     // [16][KS]
     float* const him = hre + kTile * KS;                    // [16][KS]
     float* const xtr = him + kTile * KS;                    // [IP][16]
@@ -48,26 +59,27 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const ring = part + mg.NKP * kTile * IP * 2 + wave * NR * 256;   // factored: [NR][256] floats per wavefront
     const int f = blockIdx.y;
     const int m = f - B;
 
     for (int idx = tid; idx < 2 * kTile * KS + 2 * IP * kTile; idx += kThreads) hre[idx] = 0.f;
     __syncthreads();
 
-    const int it = wave % a.NIT;
-    const int kp = wave / a.NIT;
-    const bool mma_active = kp < a.NKP;
+    const int it = wave % mg.NMT;
+    const int kp = wave / mg.NMT;
+    const bool mma_active = kp < mg.NKP;
     const int fr = lane & 15;
     const int fq = lane >> 4;
     const bool has_o = lane < O;
-    const int ol = has_o ? lane : 0;
+    const int ol = has_o ? lane : 0;       // lanes >= O gather channel 0 and are never stored
 
     // my gW tiles: u = wave + 16 n  ->  (row tile rt over k = (r,o), column tile ct over i)
     int gw_h[T], gw_x[T];       // wave-uniform LDS offsets, -1 when the slot is unused
 #pragma unroll
     for (int n = 0; n < T; ++n) {
         const int u = wave + kWaves * n;
-        const int rt = u / a.NIT, ct = u - rt * a.NIT;
+        const int rt = u / mg.NMT, ct = u - rt * mg.NMT;
         gw_h[n] = (u < a.ngw) ? rt * 16 : -1;
         gw_x[n] = ct * 16 * kTile;
     }
@@ -78,41 +90,112 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
 #pragma unroll
     for (int n = 0; n < T; ++n) { gre[n] = f32x4{0.f, 0.f, 0.f, 0.f}; gim[n] = gre[n]; }
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        // ------------------------------------------------------------ gather H for my source
-        float hr[R], hi[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { hr[r] = 0.f; hi[r] = 0.f; }
-        const int j = tile * kTile + wave;
-        int beg = 0, end = 0;
-        if (j < a.N) { beg = growptr[j]; end = growptr[j + 1]; }
+    auto dma_chunk = [&](const int first, const int ch) {
+        const float* src = gsten + ((size_t)first + ((size_t)ch << LOG_CR)) * RECF + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
+    };
 
-        int d_next = 0, row_next = 0;
-        float2 g_next = make_float2(0.f, 0.f);
-        if (beg < end) {
-            d_next = gnbr[beg];
-            row_next = beg;
-            g_next = ggy[(size_t)d_next * O + ol];
+    int beg = 0, end = 0;
+    {
+        const int j0 = blockIdx.x * kTile + wave;
+        if (blockIdx.x < a.ntiles && j0 < a.N) { beg = growptr[j0]; end = growptr[j0 + 1]; }
+        if (FACTORED) {
+            const int nch = (end - beg + CR - 1) >> LOG_CR;
+            for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
         }
-        for (int e = beg; e < end; ++e) {
-            const int row = __builtin_amdgcn_readfirstlane(row_next);
-            float2 g = g_next;
-            if (e + 1 < end) {
-                d_next = gnbr[e + 1];
-                row_next = e + 1;
-                g_next = ggy[(size_t)d_next * O + ol];
-            }
-            if (!has_o) g = make_float2(0.f, 0.f);
-            const float* __restrict__ S = gsten + (size_t)row * (2 * R * F) + 2 * f;   // wave-uniform
+    }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int j = tile * kTile + wave;
+        int nbeg = 0, nend = 0;      // my source in the next tile
+        {
+            const int jn = (tile + gridDim.x) * kTile + wave;
+            if (tile + gridDim.x < a.ntiles && jn < a.N) { nbeg = growptr[jn]; nend = growptr[jn + 1]; }
+        }
+        // ------------------------------------------------------------ gather H[:, f] for my source
+        f32x2 h[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float sr = S[2 * r * F];
-                const float si = S[2 * r * F + 1];
-                hr[r] = fmaf(g.x, sr, hr[r]);
-                hr[r] = fmaf(g.y, si, hr[r]);
-                hi[r] = fmaf(g.y, sr, hi[r]);
-                hi[r] = fmaf(-g.x, si, hi[r]);
+        for (int r = 0; r < R; ++r) h[r] = f32x2{0.f, 0.f};
+        const int nslots = end - beg;
+
+        if constexpr (FACTORED) {
+            const int nch = (nslots + CR - 1) >> LOG_CR;
+            auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
+            auto ring_of = [&](const int s) { return __builtin_amdgcn_readfirstlane(__float_as_int(rec_ptr(s)[0])); };
+            float2 ga = make_float2(0.f, 0.f), gb = ga;
+            if (nslots > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+                const int d0 = __float_as_int(rec_ptr(0)[3]);
+                const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
+                ga = ggy[(size_t)d0 * O + ol];
+                gb = ggy[(size_t)d1 * O + ol];
             }
+            // one slot with compile-time lower ring Q: z = g conj(ph_f); h[Q] += w0 z; h[Q+1] += w1 z
+            auto slot = [&](auto qc, const int s, float2& gcur) {
+                constexpr int Q = decltype(qc)::value;
+                if ((s & (CR - 1)) == 0 && s > 0) {
+                    const int ch = s >> LOG_CR;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                }
+                const float* rp = rec_ptr(s);
+                const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+                const f32x2 ph = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
+                const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
+                const f32x2 g = f32x2{gcur.x, gcur.y};
+                gcur = ggy[(size_t)d2 * O + ol];
+                f32x2 z = f32x2{ph.x, ph.x} * g;
+                z = __builtin_elementwise_fma(f32x2{ph.y, ph.y}, f32x2{g.y, -g.x}, z);
+                h[Q] = __builtin_elementwise_fma(f32x2{head.y, head.y}, z, h[Q]);
+                h[Q + 1] = __builtin_elementwise_fma(f32x2{head.z, head.z}, z, h[Q + 1]);
+            };
+            if (!(a.dbg & 1)) {
+                int s = 0;
+                static_for<0, R - 1>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    while (s < nslots && ring_of(s) == Q) {
+                        const bool two = (s + 1 < nslots) && ring_of(s + 1) == Q;
+                        slot(qc, s, ga);
+                        if (two) {
+                            slot(qc, s + 1, gb);
+                            s += 2;
+                        } else {
+                            const float2 t = ga; ga = gb; gb = t;
+                            s += 1;
+                        }
+                    }
+                });
+            }
+            // my source is done: stream the first record chunks of my next tile's source; they land
+            // while the MFMAs below run
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
+            for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
+        } else {
+            const int last = end - 1;
+            int nx = 0;
+            float2 ga = make_float2(0.f, 0.f), gb = ga;
+            if (beg < end) {
+                const int d0 = gnbr[beg];
+                const int d1 = gnbr[min(beg + 1, last)];
+                nx = gnbr[min(beg + 2, last)];
+                ga = ggy[(size_t)d0 * O + ol];
+                gb = ggy[(size_t)d1 * O + ol];
+            }
+            auto slot = [&](const int e, float2& gcur) {
+                const f32x2* __restrict__ Se = reinterpret_cast<const f32x2*>(gsten + (size_t)e * ROWF) + f;   // wave-uniform
+                const int n3 = gnbr[min(e + 3, last)];
+                const f32x2 g = f32x2{gcur.x, gcur.y}, gs = f32x2{gcur.y, -gcur.x};
+                gcur = ggy[(size_t)nx * O + ol];
+#pragma unroll
+                for (int r = 0; r < R; ++r) cmac_gconjs(h[r], Se[r * F], g, gs);
+                nx = n3;
+            };
+            if (!(a.dbg & 1))
+                for (int e = beg; e < end; e += 2) {
+                    slot(e, ga);
+                    if (e + 1 < end) slot(e + 1, gb);
+                }
         }
 
         // rotated feature xt_f of my source row (B operand of the gW product)
@@ -128,8 +211,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
         if (has_o) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                hre[wave * KS + r * O + lane] = hr[r];
-                him[wave * KS + r * O + lane] = hi[r];
+                hre[wave * KS + r * O + lane] = h[r].x;
+                him[wave * KS + r * O + lane] = h[r].y;
             }
         }
         __syncthreads();
@@ -137,55 +220,36 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
         // ------------------------------------------------------------ (a) gxt = H . conj(W)/F
         if (mma_active) {
             f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
-            const float* wre = gwpk + ((size_t)(f * 2 + 0) * IP + it * 16 + fr) * KP + 4 * fq;
-            const float* wim = gwpk + ((size_t)(f * 2 + 1) * IP + it * 16 + fr) * KP + 4 * fq;
-            const float* bre = hre + fr * KS + 4 * fq;
-            const float* bim = him + fr * KS + 4 * fq;
-            for (int kb = kp; kb < a.KST; kb += a.NKP) {
-                const float4 wr = *reinterpret_cast<const float4*>(wre + 16 * kb);
-                const float4 wi = *reinterpret_cast<const float4*>(wim + 16 * kb);
-                const float4 br = *reinterpret_cast<const float4*>(bre + 16 * kb);
-                const float4 bi = *reinterpret_cast<const float4*>(bim + 16 * kb);
-                acc_re = mfma16(wr.x, br.x, acc_re); acc_im = mfma16(wi.x, br.x, acc_im);
-                acc_re = mfma16(-wi.x, bi.x, acc_re); acc_im = mfma16(wr.x, bi.x, acc_im);
-                acc_re = mfma16(wr.y, br.y, acc_re); acc_im = mfma16(wi.y, br.y, acc_im);
-                acc_re = mfma16(-wi.y, bi.y, acc_re); acc_im = mfma16(wr.y, bi.y, acc_im);
-                acc_re = mfma16(wr.z, br.z, acc_re); acc_im = mfma16(wi.z, br.z, acc_im);
-                acc_re = mfma16(-wi.z, bi.z, acc_re); acc_im = mfma16(wr.z, bi.z, acc_im);
-                acc_re = mfma16(wr.w, br.w, acc_re); acc_im = mfma16(wi.w, br.w, acc_im);
-                acc_re = mfma16(-wi.w, bi.w, acc_re); acc_im = mfma16(wr.w, bi.w, acc_im);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int i = it * 16 + 4 * fq + jj;
-                float* p = part + ((size_t)(kp * kTile + fr) * IP + i) * 2;
-                p[0] = acc_re[jj];
-                p[1] = acc_im[jj];
-            }
+            if (!(a.dbg & 2))
+                mma_slab(gwpk + (size_t)(f * 2 + 0) * IP * KP, gwpk + (size_t)(f * 2 + 1) * IP * KP, hre, him, mg, it, kp, lane,
+                         acc_re, acc_im);
+            store_partial(part, mg, it, kp, lane, acc_re, acc_im);
         }
         __builtin_amdgcn_sched_barrier(0);
 
         // ------------------------------------------------------------ (b) gW += H^T . conj(xt)
         // re += Hre*Xre + Him*Xim ; im += Him*Xre - Hre*Xim
+        if (!(a.dbg & 4)) {
 #pragma unroll
-        for (int n = 0; n < T; ++n) {
-            if (gw_h[n] >= 0) {
-                const float4 xr4 = *reinterpret_cast<const float4*>(xtr + gw_x[n] + x_lane);
-                const float4 xi4 = *reinterpret_cast<const float4*>(xti + gw_x[n] + x_lane);
-                const float* ha = hre + gw_h[n] + h_lane;
-                const float* hb = him + gw_h[n] + h_lane;
-                const float a0 = ha[0], a1 = ha[KS], a2 = ha[2 * KS], a3 = ha[3 * KS];
-                const float b0 = hb[0], b1 = hb[KS], b2 = hb[2 * KS], b3 = hb[3 * KS];
-                gre[n] = mfma16(a0, xr4.x, gre[n]); gim[n] = mfma16(b0, xr4.x, gim[n]);
-                gre[n] = mfma16(b0, xi4.x, gre[n]); gim[n] = mfma16(-a0, xi4.x, gim[n]);
-                gre[n] = mfma16(a1, xr4.y, gre[n]); gim[n] = mfma16(b1, xr4.y, gim[n]);
-                gre[n] = mfma16(b1, xi4.y, gre[n]); gim[n] = mfma16(-a1, xi4.y, gim[n]);
-                gre[n] = mfma16(a2, xr4.z, gre[n]); gim[n] = mfma16(b2, xr4.z, gim[n]);
-                gre[n] = mfma16(b2, xi4.z, gre[n]); gim[n] = mfma16(-a2, xi4.z, gim[n]);
-                gre[n] = mfma16(a3, xr4.w, gre[n]); gim[n] = mfma16(b3, xr4.w, gim[n]);
-                gre[n] = mfma16(b3, xi4.w, gre[n]); gim[n] = mfma16(-a3, xi4.w, gim[n]);
+            for (int n = 0; n < T; ++n) {
+                if (gw_h[n] >= 0) {
+                    const float4 xr4 = *reinterpret_cast<const float4*>(xtr + gw_x[n] + x_lane);
+                    const float4 xi4 = *reinterpret_cast<const float4*>(xti + gw_x[n] + x_lane);
+                    const float* ha = hre + gw_h[n] + h_lane;
+                    const float* hb = him + gw_h[n] + h_lane;
+                    const float a0 = ha[0], a1 = ha[KS], a2 = ha[2 * KS], a3 = ha[3 * KS];
+                    const float b0 = hb[0], b1 = hb[KS], b2 = hb[2 * KS], b3 = hb[3 * KS];
+                    gre[n] = mfma16(a0, xr4.x, gre[n]); gim[n] = mfma16(b0, xr4.x, gim[n]);
+                    gre[n] = mfma16(b0, xi4.x, gre[n]); gim[n] = mfma16(-a0, xi4.x, gim[n]);
+                    gre[n] = mfma16(a1, xr4.y, gre[n]); gim[n] = mfma16(b1, xr4.y, gim[n]);
+                    gre[n] = mfma16(b1, xi4.y, gre[n]); gim[n] = mfma16(-a1, xi4.y, gim[n]);
+                    gre[n] = mfma16(a2, xr4.z, gre[n]); gim[n] = mfma16(b2, xr4.z, gim[n]);
+                    gre[n] = mfma16(b2, xi4.z, gre[n]); gim[n] = mfma16(-a2, xi4.z, gim[n]);
+                    gre[n] = mfma16(a3, xr4.w, gre[n]); gim[n] = mfma16(b3, xr4.w, gim[n]);
+                    gre[n] = mfma16(b3, xi4.w, gre[n]); gim[n] = mfma16(-a3, xi4.w, gim[n]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
 
@@ -194,13 +258,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
             const int v = idx / I, i = idx - v * I;
             const int jn = tile * kTile + v;
             if (jn >= a.N) continue;
-            float zr = 0.f, zi = 0.f;
-            for (int q = 0; q < a.NKP; ++q) {
-                const float* p = part + ((size_t)(q * kTile + v) * IP + i) * 2;
-                zr += p[0];
-                zi += p[1];
-            }
-            const float2 z = make_float2(zr, zi);
+            const float2 z = sum_partials(part, mg, v, i);
             const float2 xs = gx_[(size_t)jn * I + i];
             const float2 c = unit_power(unit_conj(xs), m);
             const float2 xtv = cmul(xs, c);
@@ -214,6 +272,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_kernel(
             ggxp[((size_t)f * a.N + jn) * I + i] = out;
         }
         __syncthreads();
+        beg = nbeg;
+        end = nend;
     }
 
     // ---------------------------------------------------------------- flush my gW partial
@@ -265,31 +325,30 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
 }
 
 struct BwdPlan {
-    int IP, KP, KS, NIT, NKP, KST, ntiles, ngw, P, F;
-    size_t lds, gxp_bytes, gwp_bytes;
-    bool ok;
+    MmaGeom g;
+    int IP, KP, ntiles, ngw, P, F;
+    size_t lds, lds_factored, gxp_bytes, gwp_bytes;
+    bool ok, ok_factored;
 };
 
 static BwdPlan plan_backward(const fc_dims* d) {
     BwdPlan p;
     p.F = 2 * d->B + 1;
-    p.IP = round_up(d->I, 16);
-    p.KP = round_up(d->R * d->O, 16);
-    p.KS = slab_stride(p.KP);
-    p.NIT = p.IP / 16;
-    p.KST = p.KP / 16;
-    p.NKP = kWaves / p.NIT;
-    if (p.NKP > p.KST) p.NKP = p.KST;
+    p.g = make_mma_geom(d->I, d->R * d->O);
+    p.IP = p.g.MP;
+    p.KP = p.g.KP;
     p.ntiles = (d->N + kTile - 1) / kTile;
-    p.ngw = p.KST * p.NIT;
-    int P = 256 / p.F;                       // one workgroup per CU across the F frequency slices
+    p.ngw = p.g.KST * p.g.NMT;
+    int P = kNumCUs / p.F;                   // one workgroup per CU across the F frequency slices
     if (P < 1) P = 1;
     if (P > p.ntiles) P = p.ntiles;
     p.P = P;
-    p.lds = (size_t)(2 * kTile * p.KS + 2 * p.IP * kTile + p.NKP * kTile * p.IP * 2) * sizeof(float);
+    p.lds = (size_t)(2 * kTile * p.g.KS + 2 * p.IP * kTile + p.g.NKP * kTile * p.IP * 2) * sizeof(float);
+    p.lds_factored = p.lds + (size_t)kWaves * kRingChunks * 1024;
     p.gxp_bytes = (((size_t)p.F * d->N * d->I * sizeof(float2) + 255) / 256) * 256;
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
-    p.ok = p.lds <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.NIT <= kWaves;
+    p.ok = p.lds <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves;
+    p.ok_factored = p.ok && p.lds_factored <= kMaxLds;
     return p;
 }
 
@@ -302,32 +361,33 @@ struct BwdPtrs {
     const float2* x; const float2* gy; const float* sten; const fc_csr* g; const float* wpk; float2* gxp; float2* gwp;
 };
 
-template <int R, int B, int T>
+template <int R, int B, int T, bool FACTORED>
 static int launch_backward_t(const BwdPtrs& q, const BwdArgs& a, const BwdPlan& p, hipStream_t stream) {
-    auto kern = fc_backward_kernel<R, B, T>;
-    if (p.lds > 64 * 1024) {
+    auto kern = fc_backward_kernel<R, B, T, FACTORED>;
+    const size_t lds = FACTORED ? p.lds_factored : p.lds;
+    if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)p.lds) != hipSuccess)
+                                (int)lds) != hipSuccess)
             return FC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds, stream, q.x, q.gy, q.sten, q.g->rowptr, q.g->nbr,
+    hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), lds, stream, q.x, q.gy, q.sten, q.g->rowptr, q.g->nbr,
                        q.wpk, q.gxp, q.gwp, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-template <int R, int B>
+template <int R, int B, bool FACTORED>
 static int launch_backward(const BwdPtrs& q, const BwdArgs& a, const BwdPlan& p, hipStream_t stream) {
     const int need = (p.ngw + kWaves - 1) / kWaves;
-    if (need <= 2) return launch_backward_t<R, B, 2>(q, a, p, stream);
-    if (need <= 4) return launch_backward_t<R, B, 4>(q, a, p, stream);
-    if (need <= kMaxGwTiles) return launch_backward_t<R, B, kMaxGwTiles>(q, a, p, stream);
+    if (need <= 2) return launch_backward_t<R, B, 2, FACTORED>(q, a, p, stream);
+    if (need <= 4) return launch_backward_t<R, B, 4, FACTORED>(q, a, p, stream);
+    if (need <= kMaxGwTiles) return launch_backward_t<R, B, kMaxGwTiles, FACTORED>(q, a, p, stream);
     return FC_ERR_UNSUPPORTED;
 }
 
 int backward_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk,
-                  void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
+                  void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
     const BwdPlan p = plan_backward(d);
-    if (!p.ok) return FC_ERR_UNSUPPORTED;
+    if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.gxp_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     BwdArgs a;
     BwdPtrs q;
@@ -339,12 +399,14 @@ int backward_impl(const float* x, const float* gy, const float* sten, const fc_c
     q.gxp = reinterpret_cast<float2*>(ws);
     q.gwp = reinterpret_cast<float2*>(static_cast<char*>(ws) + p.gxp_bytes);
     a.N = d->N; a.I = d->I; a.O = d->O;
-    a.IP = p.IP; a.KP = p.KP; a.KS = p.KS;
-    a.NIT = p.NIT; a.NKP = p.NKP; a.KST = p.KST;
+    a.g = p.g;
     a.ntiles = p.ntiles;
     a.ngw = p.ngw;
+    { const char* e = getenv("FC_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
     int rc = FC_ERR_UNSUPPORTED;
-#define FC_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_backward<RR, BB>(q, a, p, stream);
+#define FC_CASE(RR, BB)                                                              \
+    if (d->R == RR && d->B == BB)                                                    \
+        rc = factored ? launch_backward<RR, BB, true>(q, a, p, stream) : launch_backward<RR, BB, false>(q, a, p, stream);
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
     return rc;

@@ -124,8 +124,12 @@ class _FieldConvFn(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             csr = _csr(graph.rowptr_s, graph.nbr_s)
             with _timed('fc_backward'):
-                check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(ws), nbytes,
-                                      ctypes.byref(dims), st), 'fc_backward')
+                if graph.factored:
+                    check(lib.fc_backward_factored(_p(x), _p(gy), _p(graph.rec_s), ctypes.byref(csr), _p(wpk_b), _p(ws),
+                                                   nbytes, ctypes.byref(dims), st), 'fc_backward_factored')
+                else:
+                    check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(ws), nbytes,
+                                          ctypes.byref(dims), st), 'fc_backward')
             check(lib.fc_backward_finish(_p(gx), _p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
         return gx, gw, None
 

@@ -122,7 +122,6 @@ class SupportGraph:
             rs[:, 3] = self.nbr_s.view(torch.float32)
             self.rec_t = torch.cat((rt, pad), 0)
             self.rec_s = torch.cat((rs, pad), 0)
-            self.sten_s = sten.index_select(0, perm_s)      # dense rows in the same slot order (dense backward)
             self.factored = True
         else:
             self.rowptr_t, self.nbr_t, perm_t = group(dst, src)

@@ -77,8 +77,8 @@ int fc_forward(const float* x, const float* sten_t, const fc_csr* by_target, con
  * FCPrecomp's stencil (reference transforms/fc_precomp.py:24-25,95) is rank-1 and 2-sparse in the
  * ring index: supp_sten[e,r,f] = w[e,r] * ph[e,f] with w[e,q], w[e,q+1] the only non-zeros.  When
  * the caller has verified that structure it may pass, instead of the dense rows, one record of
- * fc_factored_record_floats(B) floats per edge (in by_target slot order, followed by at least
- * 1 KiB of readable padding):  [0] q as int32 bits, [1] w[q], [2] w[q+1],
+ * fc_factored_record_floats(B) floats per edge (in by_target slot order and, inside every target's
+ * slot range, sorted by q; followed by at least 1 KiB of readable padding):  [0] q as int32 bits, [1] w[q], [2] w[q+1],
  * [3] the slot's other endpoint (= by_target->nbr[slot]) as int32 bits, [4+2f], [5+2f] = Re, Im ph[f].  Same result as fc_forward up to fp32 rounding. */
 int fc_factored_record_floats(int32_t band_limit);
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd,
@@ -96,6 +96,12 @@ int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr
                 const fc_dims* dims, void* stream);
 int fc_backward_finish(float* gx, float* gw_eff, void* workspace, size_t workspace_bytes,
                        const fc_dims* dims, void* stream);
+/* Same, with the factored stencil records (see fc_forward_factored) in by_source slot order,
+ * sorted by ring index inside every source's slot range; record [3] = the slot's target vertex.
+ * Followed by fc_backward_finish as above. */
+int fc_backward_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
+                         const float* wpk_bwd, void* workspace, size_t workspace_bytes,
+                         const fc_dims* dims, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */

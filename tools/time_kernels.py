@@ -47,7 +47,10 @@ def fwd():
 
 
 def bwd():
-    lib.fc_backward(_p(x), _p(gy), _p(sten_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
+    if FACT:
+        lib.fc_backward_factored(_p(x), _p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
+    else:
+        lib.fc_backward(_p(x), _p(gy), _p(sten_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
 
 
 def timeit(fn, reps=20):
@@ -63,7 +66,7 @@ def timeit(fn, reps=20):
 
 
 which = os.environ.get('WHICH', 'fb')
-tag = os.environ.get('FC_DEBUG', '0') + (' factored' if FACT else ' dense')
+tag = os.environ.get('FC_DEBUG', '0') + '/' + os.environ.get('FC_DEBUG_BWD', '0') + (' factored' if FACT else ' dense')
 if 'f' in which:
     print(f'FC_DEBUG={tag} {kind} fwd median/min us: %.1f %.1f' % timeit(fwd))
 if 'b' in which:
