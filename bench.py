@@ -183,7 +183,8 @@ def main():
         fwd_b, bwd_b = algorithmic_bytes(n_local, E, C, C, R, F)
         fwd_f, bwd_f = algorithmic_flops(n_local, E, C, C, R, F)
         per_kernel = {}
-        for name, nbytes, nflops in (('fc_forward', fwd_b, fwd_f), ('fc_backward', bwd_b, bwd_f)):
+        for name, nbytes, nflops in (('fc_forward', fwd_b, fwd_f), ('fc_backward_data', bwd_b, bwd_f - 8 * n_local * C * C * R * F),
+                                     ('fc_backward_filter', bwd_b, 8 * n_local * C * C * R * F)):
             if name in kt:
                 sec = kt[name] * 1e-3
                 per_kernel[name] = {'avg_ms': kt[name], 'algorithmic_bytes': nbytes, 'GBps': nbytes / sec / 1e9,

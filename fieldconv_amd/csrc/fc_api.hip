@@ -79,29 +79,42 @@ size_t fc_backward_workspace_bytes(const fc_dims* dims) {
     return fc::backward_workspace_bytes(dims);
 }
 
-int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
-                void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
-    if (!x || !gy || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
-    if (dims->E > 0 && (!sten || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
+static int check_bwd(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
+                     float* gx, const fc_dims* dims) {
+    if (!x || !gy || !gx || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (dims->E > 0 && !sten) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_impl(x, gy, sten, by_source, wpk_bwd, workspace, workspace_bytes, dims, false,
-                             static_cast<hipStream_t>(stream));
+    return FC_OK;
 }
 
-int fc_backward_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
-                         const float* wpk_bwd, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
-    if (!x || !gy || !wpk_bwd || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
-    if (dims->E > 0 && !rec_s) return FC_ERR_BAD_ARGUMENT;
-    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_impl(x, gy, rec_s, by_source, wpk_bwd, workspace, workspace_bytes, dims, true,
-                             static_cast<hipStream_t>(stream));
+int fc_backward_data(const float* x, const float* gy, const float* sten_s, const fc_csr* by_source, const float* wpk_bwd,
+                     float* gx, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    const int rc = check_bwd(x, gy, sten_s, by_source, wpk_bwd, gx, dims);
+    if (rc != FC_OK) return rc;
+    if (dims->E > 0 && !by_source->nbr) return FC_ERR_BAD_ARGUMENT;
+    return fc::backward_data_impl(x, gy, sten_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, false,
+                                  static_cast<hipStream_t>(stream));
 }
 
-int fc_backward_finish(float* gx, float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims,
-                       void* stream) {
-    if (!gx || !gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+int fc_backward_data_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
+                              const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
+                              const fc_dims* dims, void* stream) {
+    const int rc = check_bwd(x, gy, rec_s, by_source, wpk_bwd, gx, dims);
+    if (rc != FC_OK) return rc;
+    return fc::backward_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, true,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!x || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_finish_impl(gx, gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+    return fc::backward_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+}
+
+int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

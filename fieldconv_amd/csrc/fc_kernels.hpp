@@ -20,9 +20,10 @@ constexpr int kMaxChannels = 64;     // one channel per lane in the gather phase
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
                  const fc_dims* d, bool factored, hipStream_t stream);
 size_t backward_workspace_bytes(const fc_dims* d);
-int backward_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk,
-                  void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);
-int backward_finish_impl(float* gx, float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
+int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
+                       void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);
+int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
+int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream);
 
 bool shape_compiled(int R, int B);

@@ -123,14 +123,14 @@ class _FieldConvFn(torch.autograd.Function):
             nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             csr = _csr(graph.rowptr_s, graph.nbr_s)
-            with _timed('fc_backward'):
-                if graph.factored:
-                    check(lib.fc_backward_factored(_p(x), _p(gy), _p(graph.rec_s), ctypes.byref(csr), _p(wpk_b), _p(ws),
-                                                   nbytes, ctypes.byref(dims), st), 'fc_backward_factored')
-                else:
-                    check(lib.fc_backward(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(csr), _p(wpk_b), _p(ws), nbytes,
-                                          ctypes.byref(dims), st), 'fc_backward')
-            check(lib.fc_backward_finish(_p(gx), _p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
+            sten = graph.rec_s if graph.factored else graph.sten_s
+            fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
+            with _timed('fc_backward_data'):
+                check(fn(_p(x), _p(gy), _p(sten), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(ws), nbytes, ctypes.byref(dims), st),
+                      'fc_backward_data')
+            with _timed('fc_backward_filter'):
+                check(lib.fc_backward_filter(_p(x), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_filter')
+            check(lib.fc_backward_finish(_p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
         return gx, gw, None
 
 

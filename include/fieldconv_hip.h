@@ -85,23 +85,24 @@ int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_tar
                         float* y, const fc_dims* dims, void* stream);
 
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
- * Two stages on the same stream.  fc_backward launches the one heavy kernel (source-centric
- * gather + both MFMA contractions); it leaves per-frequency gx terms and per-workgroup filter
- * gradient partials in `workspace`.  fc_backward_finish reduces them, in a fixed order, into
- * gx (N,I) c64 and gw_eff (O,I,R,F) c64 (both overwritten).  by_source: CSR grouped by source.
- * workspace: fc_backward_workspace_bytes(dims) bytes, 256-byte aligned, untouched in between. */
+ * Three calls on the same stream, sharing `workspace` (fc_backward_workspace_bytes(dims) bytes,
+ * 256-byte aligned, untouched in between):
+ *   fc_backward_data[_factored]  one kernel: source-centric gather of H = sum gy conj(S) over the
+ *                                out-edges (by_source: CSR grouped by source; sten_s / rec_s in its
+ *                                slot order, records sorted by ring inside a source and carrying the
+ *                                target in [3]), MFMA contraction with the conjugated filter, writes
+ *                                gx (N,I) c64 and leaves H in the workspace
+ *   fc_backward_filter           one kernel: filter-gradient partials from the stored H and x
+ *   fc_backward_finish           fixed-order sum of the partials into gw_eff (O,I,R,F) c64 */
 size_t fc_backward_workspace_bytes(const fc_dims* dims);
-int fc_backward(const float* x, const float* gy, const float* sten, const fc_csr* by_source,
-                const float* wpk_bwd, void* workspace, size_t workspace_bytes,
-                const fc_dims* dims, void* stream);
-int fc_backward_finish(float* gx, float* gw_eff, void* workspace, size_t workspace_bytes,
-                       const fc_dims* dims, void* stream);
-/* Same, with the factored stencil records (see fc_forward_factored) in by_source slot order,
- * sorted by ring index inside every source's slot range; record [3] = the slot's target vertex.
- * Followed by fc_backward_finish as above. */
-int fc_backward_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
-                         const float* wpk_bwd, void* workspace, size_t workspace_bytes,
-                         const fc_dims* dims, void* stream);
+int fc_backward_data(const float* x, const float* gy, const float* sten_s, const fc_csr* by_source,
+                     const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
+                     const fc_dims* dims, void* stream);
+int fc_backward_data_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
+                              const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
+                              const fc_dims* dims, void* stream);
+int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
+int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */

@@ -17,7 +17,7 @@ N, k, C, B, R = 20000, 32, int(os.environ.get('C', 48)), 2, 6
 dev = torch.device('cuda:0')
 data = (sphere_support(N, k) if kind == 'geo' else random_support(N, k)).to(dev)
 edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
-graph = SupportGraph(edges, sten, N)
+graph = SupportGraph(edges, sten, N, allow_factored=os.environ.get('FACT', '1') == '1')
 lib = _lib.load()
 g = torch.Generator().manual_seed(0)
 x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
@@ -33,7 +33,6 @@ gw = torch.empty_like(W)
 nb = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 ct, cs = _csr(graph.rowptr_t, graph.nbr_t), _csr(graph.rowptr_s, graph.nbr_s)
-sten_s = getattr(graph, 'sten_s')
 
 
 FACT = os.environ.get('FACT', '1') == '1' and graph.factored
@@ -46,11 +45,13 @@ def fwd():
         lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(ct), _p(wf), _p(y), ctypes.byref(dims), _stream())
 
 
-def bwd():
-    if FACT:
-        lib.fc_backward_factored(_p(x), _p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
-    else:
-        lib.fc_backward(_p(x), _p(gy), _p(sten_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
+def bwd_data():
+    fn = lib.fc_backward_data_factored if FACT else lib.fc_backward_data
+    fn(_p(x), _p(gy), _p(graph.rec_s if FACT else graph.sten_s), ctypes.byref(cs), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), _stream())
+
+
+def bwd_filter():
+    lib.fc_backward_filter(_p(x), _p(ws), nb, ctypes.byref(dims), _stream())
 
 
 def timeit(fn, reps=20):
@@ -70,4 +71,5 @@ tag = os.environ.get('FC_DEBUG', '0') + '/' + os.environ.get('FC_DEBUG_BWD', '0'
 if 'f' in which:
     print(f'FC_DEBUG={tag} {kind} fwd median/min us: %.1f %.1f' % timeit(fwd))
 if 'b' in which:
-    print(f'FC_DEBUG={tag} {kind} bwd median/min us: %.1f %.1f' % timeit(bwd))
+    print(f'FC_DEBUG={tag} {kind} bwd_data median/min us: %.1f %.1f' % timeit(bwd_data))
+    print(f'FC_DEBUG={tag} {kind} bwd_filter median/min us: %.1f %.1f' % timeit(bwd_filter))
