@@ -32,6 +32,8 @@ SIGNATURES = {
     'fc_packed_filter_floats_fwd': (_sz, [_DP]),
     'fc_packed_filter_floats_bwd': (_sz, [_DP]),
     'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _vp]),
+    'fc_pack_filter_params': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _vp, _vp, _DP, _vp]),
+    'fc_filter_param_grads': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _vp, _vp, _vp, _DP, _vp]),
     'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
     'fc_factored_record_floats': (ctypes.c_int, [_c_int32]),
     'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),

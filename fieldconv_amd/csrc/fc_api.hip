@@ -56,6 +56,21 @@ int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_
     return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, static_cast<hipStream_t>(stream));
 }
 
+int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype, float* wpk_fwd,
+                          float* wpk_bwd, const fc_dims* dims, void* stream) {
+    if (!zonal || !spherical || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (ftype < 0 || ftype > 2 || (ftype == 1 && !phase)) return FC_ERR_BAD_ARGUMENT;
+    return fc::pack_filter_params_impl(zonal, spherical, phase, ftype, wpk_fwd, wpk_bwd, dims, static_cast<hipStream_t>(stream));
+}
+
+int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* spherical, const float* phase, int32_t ftype,
+                          float* g_zonal, float* g_spherical, float* g_phase, const fc_dims* dims, void* stream) {
+    if (!gw_eff || !zonal || !spherical || !g_zonal || !g_spherical || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (ftype < 0 || ftype > 2 || (ftype == 1 && (!phase || !g_phase))) return FC_ERR_BAD_ARGUMENT;
+    return fc::filter_param_grads_impl(gw_eff, zonal, spherical, phase, ftype, g_zonal, g_spherical, g_phase, dims,
+                                       static_cast<hipStream_t>(stream));
+}
+
 int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const float* wpk_fwd, float* y,
                const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;

@@ -25,6 +25,10 @@ int backward_data_impl(const float* x, const float* gy, const float* sten, const
 int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream);
+int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
+                            float* wpk_bwd, const fc_dims* d, hipStream_t stream);
+int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,
+                            float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
 

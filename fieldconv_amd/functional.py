@@ -94,15 +94,7 @@ class _FieldConvFn(torch.autograd.Function):
             wpk_f = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
             wpk_b = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
             check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), st), 'fc_pack_filter')
-            y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
-            csr = _csr(graph.rowptr_t, graph.nbr_t)
-            with _timed('fc_forward'):
-                if graph.factored:
-                    check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y),
-                                                  ctypes.byref(dims), st), 'fc_forward_factored')
-                else:
-                    check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                          'fc_forward')
+            y = _launch_forward(lib, x, graph, wpk_f, dims, O, st)
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
         ctx.wshape = (O, I, R, F)
@@ -112,26 +104,101 @@ class _FieldConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         lib = _lib.load()
         x, wpk_b = ctx.saved_tensors
-        graph = ctx.graph
         O, I, R, F = ctx.wshape
-        dims = make_dims(graph, I, O, (F - 1) // 2)
+        dims = make_dims(ctx.graph, I, O, (F - 1) // 2)
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, dims, ctx.wshape, _stream())
+        return gx, gw, None
+
+
+def _launch_forward(lib, x, graph, wpk_f, dims, O, st):
+    y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
+    csr = _csr(graph.rowptr_t, graph.nbr_t)
+    with _timed('fc_forward'):
+        if graph.factored:
+            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                  'fc_forward_factored')
+        else:
+            check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                  'fc_forward')
+    return y
+
+
+def _launch_backward(lib, x, gy, graph, wpk_b, dims, wshape, st):
+    O, I, R, F = wshape
+    gx = torch.empty_like(x)
+    gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
+    nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    csr = _csr(graph.rowptr_s, graph.nbr_s)
+    sten = graph.rec_s if graph.factored else graph.sten_s
+    fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
+    with _timed('fc_backward_data'):
+        check(fn(_p(x), _p(gy), _p(sten), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(ws), nbytes, ctypes.byref(dims), st),
+              'fc_backward_data')
+    with _timed('fc_backward_filter'):
+        check(lib.fc_backward_filter(_p(x), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_filter')
+    check(lib.fc_backward_finish(_p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
+    return gx, gw
+
+
+class _FieldConvParamFn(torch.autograd.Function):
+    """FieldConv straight from the module parameters: the filter assembly of reference
+    nn/field_conv.py:10-33 and its autograd twin run as one small HIP kernel each
+    (fc_pack_filter_params / fc_filter_param_grads) instead of a dozen torch ops."""
+
+    @staticmethod
+    def forward(ctx, x, zonal, spherical, phase, ftype, B, graph):
+        lib = _lib.load()
+        x = x.contiguous()
+        zonal, spherical, phase = zonal.contiguous(), spherical.contiguous(), phase.contiguous()
+        O, I, R = zonal.shape[0], zonal.shape[1], zonal.shape[2]
+        F = 2 * B + 1
+        dims = make_dims(graph, I, O, B)
+        if not lib.fc_supported(ctypes.byref(dims)):
+            raise _lib.FieldConvNativeError(
+                f'FieldConv(in={I}, out={O}, n_rings={R}, band_limit={B}) is outside the compiled HIP kernels '
+                '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
+        with torch.cuda.device(x.device):
+            st = _stream()
+            wpk_f = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            wpk_b = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), ctypes.byref(dims),
+                                            st), 'fc_pack_filter_params')
+            y = _launch_forward(lib, x, graph, wpk_f, dims, O, st)
+        ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
+        ctx.graph, ctx.ftype, ctx.wshape = graph, ftype, (O, I, R, F)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, wpk_b, zonal, spherical, phase = ctx.saved_tensors
+        O, I, R, F = ctx.wshape
+        dims = make_dims(ctx.graph, I, O, (F - 1) // 2)
         gy = gy.contiguous()
         with torch.cuda.device(x.device):
             st = _stream()
-            gx = torch.empty_like(x)
-            gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
-            nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            csr = _csr(graph.rowptr_s, graph.nbr_s)
-            sten = graph.rec_s if graph.factored else graph.sten_s
-            fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
-            with _timed('fc_backward_data'):
-                check(fn(_p(x), _p(gy), _p(sten), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(ws), nbytes, ctypes.byref(dims), st),
-                      'fc_backward_data')
-            with _timed('fc_backward_filter'):
-                check(lib.fc_backward_filter(_p(x), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_filter')
-            check(lib.fc_backward_finish(_p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
-        return gx, gw, None
+            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, dims, ctx.wshape, st)
+            g_z = torch.empty_like(zonal)
+            g_s = torch.empty_like(spherical)
+            g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
+            check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ctx.ftype, _p(g_z), _p(g_s),
+                                            _p(g_p) if g_p is not None else None, ctypes.byref(dims), st), 'fc_filter_param_grads')
+        return gx, g_z, g_s, g_p, None, None, None
+
+
+def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
+    """FieldConv from the raw module parameters (see FieldConv.forward)."""
+    _require_device(x, 'field_conv')
+    if x.dtype != torch.complex64:
+        raise ValueError('field_conv expects complex64 features')
+    if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != zonal.shape[1]:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {zonal.shape[1]})')
+    if zonal.shape[2] != graph.R or 2 * band_limit + 1 != graph.F:
+        raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={zonal.shape[2]}, band_limit={band_limit}')
+    return _FieldConvParamFn.apply(x, zonal, spherical, phase, int(ftype), int(band_limit), graph)
 
 
 def field_conv(x, w_eff, graph):

@@ -65,6 +65,16 @@ int fc_supported(const fc_dims* dims);
 size_t fc_packed_filter_floats_fwd(const fc_dims* dims);
 size_t fc_packed_filter_floats_bwd(const fc_dims* dims);
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
+/* Same, assembling W_eff on the fly from the module parameters exactly as reference
+ * nn/field_conv.py:10-33 does (zonal (O,I,R[,2]), spherical (O,I,R,B|2B,2), phase (O,I,B+1), all fp32
+ * contiguous; ftype 0/1/2 as in :53-59; phase is read for ftype 1 only). */
+int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype,
+                          float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
+/* Autograd twin of the assembly: dL/dW_eff (O,I,R,F) c64 -> gradients shaped like the parameters
+ * (overwritten; g_phase written for ftype 1 only). */
+int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* spherical, const float* phase,
+                          int32_t ftype, float* g_zonal, float* g_spherical, float* g_phase,
+                          const fc_dims* dims, void* stream);
 
 /* ---- FieldConv.forward, reference nn/field_conv.py:128-137 ------------------------------- *
  * y[n,o] = 1/F sum_{e: dst_e=n} sum_{i,r,f} x[src_e,i] e^{-i(f-B)phi[src_e,i]} S[e,r,f] W_eff[o,i,r,f]
