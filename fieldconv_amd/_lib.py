@@ -18,7 +18,7 @@ class FcDims(ctypes.Structure):
 
 
 class FcCsr(ctypes.Structure):
-    _fields_ = [('rowptr', _vp), ('nbr', _vp)]
+    _fields_ = [('rowptr', _vp), ('nbr', _vp), ('runs', _vp)]
 
 
 _DP = ctypes.POINTER(FcDims)

@@ -84,8 +84,8 @@ int fc_factored_record_floats(int32_t band_limit) { return band_limit >= 0 ? fc:
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd, float* y,
                         const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
-    if (dims->E > 0 && (!rec_t || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
-    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    if (dims->E > 0 && (!rec_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims) || dims->R > 8) return FC_ERR_UNSUPPORTED;
     return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, true, static_cast<hipStream_t>(stream));
 }
 
@@ -116,6 +116,8 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
                               const fc_dims* dims, void* stream) {
     const int rc = check_bwd(x, gy, rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;
+    if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
+    if (dims->R > 8) return FC_ERR_UNSUPPORTED;
     return fc::backward_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, true,
                                   static_cast<hipStream_t>(stream));
 }

@@ -89,10 +89,19 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
     };
 
-    int beg = 0, end = 0;
+    int beg = 0, end = 0, ro[R];      // ro: ring-run offsets of my source (factored), see fc_forward.hip
+#pragma unroll
+    for (int q = 0; q < R; ++q) ro[q] = 0;
     {
         const int j0 = blockIdx.x * kTile + wave;
-        if (blockIdx.x < a.ntiles && j0 < a.N) { beg = growptr[j0]; end = growptr[j0 + 1]; }
+        if (blockIdx.x < a.ntiles && j0 < a.N) {
+            beg = growptr[j0];
+            end = growptr[j0 + 1];
+            if (FACTORED) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) ro[q] = gnbr[(size_t)j0 * kRunStride + q];
+            }
+        }
         if (FACTORED) {
             const int nch = (end - beg + CR - 1) >> LOG_CR;
             for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
@@ -100,10 +109,19 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     }
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int nbeg = 0, nend = 0;      // my source in the next tile
+        int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
+#pragma unroll
+        for (int q = 0; q < R; ++q) nro[q] = 0;
         {
             const int jn = (tile + gridDim.x) * kTile + wave;
-            if (tile + gridDim.x < a.ntiles && jn < a.N) { nbeg = growptr[jn]; nend = growptr[jn + 1]; }
+            if (tile + gridDim.x < a.ntiles && jn < a.N) {
+                nbeg = growptr[jn];
+                nend = growptr[jn + 1];
+                if (FACTORED) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) nro[q] = gnbr[(size_t)jn * kRunStride + q];
+                }
+            }
         }
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
@@ -127,7 +145,6 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             if constexpr (FACTORED) {
                 if (g > 0) for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);   // walk the slots again
                 auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
-                auto ring_of = [&](const int s) { return __builtin_amdgcn_readfirstlane(__float_as_int(rec_ptr(s)[0])); };
                 float2 ga = make_float2(0.f, 0.f), gb = ga;
                 if (nslots > 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
@@ -163,19 +180,17 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     }
                 };
                 if (!(a.dbg & 1)) {
-                    int s = 0;
                     static_for<0, R - 1>([&](auto qc) {
                         constexpr int Q = decltype(qc)::value;
-                        while (s < nslots && ring_of(s) == Q) {
-                            const bool two = (s + 1 < nslots) && ring_of(s + 1) == Q;
+                        int s = ro[Q];
+                        const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                        for (; s + 1 < run_end; s += 2) {
                             slot(qc, s, ga);
-                            if (two) {
-                                slot(qc, s + 1, gb);
-                                s += 2;
-                            } else {
-                                const float2 t = ga; ga = gb; gb = t;
-                                s += 1;
-                            }
+                            slot(qc, s + 1, gb);
+                        }
+                        if (s < run_end) {
+                            slot(qc, s, ga);
+                            const float2 t = ga; ga = gb; gb = t;
                         }
                     });
                 }
@@ -263,6 +278,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         if (e_active && ejn < a.N) ggx[(size_t)ejn * I + ei] = gxacc;
         beg = nbeg;
         end = nend;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ro[q] = nro[q];
     }
 }
 
@@ -459,7 +476,8 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
             return FC_ERR_LAUNCH;
     }
     const int grid = FACTORED ? (p.ntiles < kNumCUs ? p.ntiles : kNumCUs) : p.ntiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, g->nbr, wpk, gx, hdump, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, gx,
+                       hdump, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -47,6 +47,7 @@ __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);
     return per_kib >= 32 ? 5 : per_kib >= 16 ? 4 : per_kib >= 8 ? 3 : per_kib >= 4 ? 2 : 1;
 }
+constexpr int kRunStride = 8;      // ints per vertex in fc_csr::runs (ring-run offsets, n_rings <= 8)
 constexpr int kRingChunks = 4;     // 1 KiB chunks per wavefront in the record ring (power of two, >= 3)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source

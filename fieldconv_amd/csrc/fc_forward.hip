@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
 template <int R, int B>
 __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ grec, const int32_t* __restrict__ growptr,
-    const int32_t* __restrict__ gnbr, const float* __restrict__ gwpk,
+    const int32_t* __restrict__ gruns, const float* __restrict__ gwpk,
     float2* __restrict__ gy_, const FwdArgs a) {
     constexpr int F = 2 * B + 1;
     constexpr int NG = FwdShape<R, B>::NG;
@@ -210,10 +210,18 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
     };
 
-    int beg = 0, end = 0;
+    // ro[q] = first slot (relative to beg) whose ring index is >= q: the slots of ring q are [ro[q], ro[q+1])
+    int beg = 0, end = 0, ro[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) ro[q] = 0;
     {
         const int t0 = blockIdx.x * kTile + wave;
-        if (blockIdx.x < a.ntiles && t0 < a.N) { beg = growptr[t0]; end = growptr[t0 + 1]; }
+        if (blockIdx.x < a.ntiles && t0 < a.N) {
+            beg = growptr[t0];
+            end = growptr[t0 + 1];
+#pragma unroll
+            for (int q = 0; q < R; ++q) ro[q] = gruns[(size_t)t0 * kRunStride + q];
+        }
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
     }
@@ -223,10 +231,17 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
 
         // next tile's slot range for this wavefront (its first chunks are DMA'd during phase B)
-        int nbeg = 0, nend = 0;
+        int nbeg = 0, nend = 0, nro[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) nro[q] = 0;
         {
             const int tn = (tile + gridDim.x) * kTile + wave;
-            if (tile + gridDim.x < a.ntiles && tn < a.N) { nbeg = growptr[tn]; nend = growptr[tn + 1]; }
+            if (tile + gridDim.x < a.ntiles && tn < a.N) {
+                nbeg = growptr[tn];
+                nend = growptr[tn + 1];
+#pragma unroll
+                for (int q = 0; q < R; ++q) nro[q] = gruns[(size_t)tn * kRunStride + q];
+            }
         }
 
 #pragma unroll
@@ -245,7 +260,6 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             const int nslots = end - beg;
             // record s of this target (s relative to beg) lives at ring[((s >> LOG_CR) & (NR-1)) * 256 + (s & (CR-1)) * RECF]
             auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
-            auto ring_of = [&](const int s) { return __builtin_amdgcn_readfirstlane(__float_as_int(rec_ptr(s)[0])); };
             float2 xa = make_float2(0.f, 0.f), xb = xa;
             if (nslots > 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
@@ -295,19 +309,17 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             // The records of a target are sorted by ring index, so the walk is R-1 consecutive runs, each
             // with statically indexed accumulators (no data-dependent register indexing, no switch).
             if (!(a.dbg & 1)) {
-                int s = 0;
                 static_for<0, R - 1>([&](auto qc) {
                     constexpr int Q = decltype(qc)::value;
-                    while (s < nslots && ring_of(s) == Q) {
-                        const bool two = (s + 1 < nslots) && ring_of(s + 1) == Q;
+                    int s = ro[Q];
+                    const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                    for (; s + 1 < run_end; s += 2) {
                         slot(qc, s, xa);
-                        if (two) {
-                            slot(qc, s + 1, xb);
-                            s += 2;
-                        } else {        // odd tail of the run: rotate the two prefetch registers
-                            const float2 t = xa; xa = xb; xb = t;
-                            s += 1;
-                        }
+                        slot(qc, s + 1, xb);
+                    }
+                    if (s < run_end) {      // odd tail of the run: rotate the two prefetch registers
+                        slot(qc, s, xa);
+                        const float2 t = xa; xa = xb; xb = t;
                     }
                 });
             }
@@ -323,6 +335,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
         forward_epilogue(part, a, tile, wave, lane, acc_re, acc_im, gy_);
         beg = nbeg;
         end = nend;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ro[q] = nro[q];
     }
 }
 
@@ -335,7 +349,7 @@ static int launch_forward(const float2* x, const float* sten, const fc_csr* g, c
                                 (int)lds_bytes) != hipSuccess)
             return FC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, g->nbr, wpk, y, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, y, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -62,8 +62,8 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _csr(rowptr, nbr):
-    return FcCsr(rowptr.data_ptr(), nbr.data_ptr() if nbr.numel() else None)
+def _csr(rowptr, nbr, runs=None):
+    return FcCsr(rowptr.data_ptr(), nbr.data_ptr() if nbr.numel() else None, runs.data_ptr() if runs is not None else None)
 
 
 def make_dims(graph, I, O, B):
@@ -114,7 +114,7 @@ class _FieldConvFn(torch.autograd.Function):
 
 def _launch_forward(lib, x, graph, wpk_f, dims, O, st):
     y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
-    csr = _csr(graph.rowptr_t, graph.nbr_t)
+    csr = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
     with _timed('fc_forward'):
         if graph.factored:
             check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
@@ -131,7 +131,7 @@ def _launch_backward(lib, x, gy, graph, wpk_b, dims, wshape, st):
     gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
     nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    csr = _csr(graph.rowptr_s, graph.nbr_s)
+    csr = _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
     sten = graph.rec_s if graph.factored else graph.sten_s
     fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
     with _timed('fc_backward_data'):

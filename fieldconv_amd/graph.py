@@ -67,7 +67,7 @@ def factor_stencil(sten, tol=2e-6):
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', '_keep')
+                 'rec_s', 'runs_t', 'runs_s', '_keep')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -104,7 +104,7 @@ class SupportGraph:
         sten = supp_sten.contiguous()
         self._keep = (supp_edges, supp_sten)      # pins the storages the cache key refers to
         self.factored = False
-        self.rec_t = self.rec_s = self.sten_t = self.sten_s = None
+        self.rec_t = self.rec_s = self.sten_t = self.sten_s = self.runs_t = self.runs_s = None
         # factored fast path: FCPrecomp's stencil is w[e,r] * ph[e,f] with two adjacent non-zero rings
         rec = None
         if allow_factored and E > 0 and self.R >= 2 and os.environ.get('FIELDCONV_DENSE', '0') != '1':
@@ -122,6 +122,14 @@ class SupportGraph:
             rs[:, 3] = self.nbr_s.view(torch.float32)
             self.rec_t = torch.cat((rt, pad), 0)
             self.rec_s = torch.cat((rs, pad), 0)
+
+            def run_offsets(key):
+                # runs[v, q] = number of v's slots with ring index < q  (N x 8 int32, see fc_csr::runs)
+                hist = torch.bincount(key * 8 + q, minlength=self.N * 8)[: self.N * 8].reshape(self.N, 8)
+                excl = torch.cumsum(hist, 1) - hist
+                return excl.to(torch.int32).contiguous()
+            self.runs_t = run_offsets(dst)
+            self.runs_s = run_offsets(src)
             self.factored = True
         else:
             self.rowptr_t, self.nbr_t, perm_t = group(dst, src)

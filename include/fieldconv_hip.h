@@ -47,7 +47,10 @@ typedef struct fc_dims {
  * CSR is stored in that CSR's SLOT order (the kernels stream it): see fc_forward / fc_backward. */
 typedef struct fc_csr {
     const int32_t* rowptr;   /* N+1 */
-    const int32_t* nbr;      /* E   */
+    const int32_t* nbr;      /* E   (dense entry points; may be NULL for the factored ones) */
+    const int32_t* runs;     /* factored entry points only, else NULL: N x 8 ints; runs[8v + q] = first slot of
+                              * vertex v, relative to rowptr[v], whose ring index is >= q (so the slots of ring q
+                              * are [runs[8v+q], runs[8v+q+1]) and runs[8v] = 0) */
 } fc_csr;
 
 int fc_abi_version(void);

@@ -32,7 +32,7 @@ gx = torch.empty_like(x)
 gw = torch.empty_like(W)
 nb = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-ct, cs = _csr(graph.rowptr_t, graph.nbr_t), _csr(graph.rowptr_s, graph.nbr_s)
+ct, cs = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t), _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
 
 
 FACT = os.environ.get('FACT', '1') == '1' and graph.factored
