@@ -35,7 +35,9 @@ struct BwdArgs {
     MmaGeom g;           // M = I (rows of gxt), K = R*O
     int ntiles;
     int ngw;             // KST * NMT 16x16 gW tiles per frequency
-    int slab_floats;     // 2 * 16 * KS
+    int KD;              // row stride (floats) of the H slabs kept for the filter kernel: KP + 4, so that the
+                         // filter kernel's 4-byte A-fragment reads (rows 4 apart per lane group) hit distinct banks
+    int slab_floats;     // 2 * 16 * KD
     int slab_stride;     // floats between consecutive (tile, f) slabs in hdump (multiple of 256)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
 };
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const ring = part + mg.NKP * kTile * IP * 2 + wave * NR * 256;   // factored: [NR][256] floats per wavefront
+    float* const ring = part + partial_floats(mg.NKP, IP) + wave * NR * 256;   // factored: [NR][256] floats per wavefront
 
     for (int idx = tid; idx < 2 * kTile * KS; idx += kThreads) hre[idx] = 0.f;
     __syncthreads();
@@ -243,10 +245,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         }
                     }
                     __syncthreads();
-                    {   // keep this slab for the filter-gradient kernel (coalesced 16 B per thread)
-                        const float4* s4 = reinterpret_cast<const float4*>(hre);
-                        float4* d4 = reinterpret_cast<float4*>(hdump + ((size_t)tile * F + f) * a.slab_stride);
-                        for (int idx = tid; idx < a.slab_floats / 4; idx += kThreads) d4[idx] = s4[idx];
+                    {   // keep this slab for the filter-gradient kernel (16 B per thread, rows re-strided to KD)
+                        float* dst = hdump + ((size_t)tile * F + f) * a.slab_stride;
+                        const int k4n = KP / 4;
+                        for (int idx = tid; idx < 2 * kTile * k4n; idx += kThreads) {
+                            const int row = idx / k4n, k4 = idx - row * k4n;          // row = plane * 16 + vertex
+                            *reinterpret_cast<float4*>(dst + row * a.KD + 4 * k4) = *reinterpret_cast<const float4*>(hre + row * KS + 4 * k4);
+                        }
                     }
                     if (mma_active) {
                         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const BwdArgs a, const int F, const int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MmaGeom& mg = a.g;
-    const int KS = mg.KS, KP = mg.KP, IP = mg.MP, I = a.I;
+    const int KD = a.KD, KP = mg.KP, IP = mg.MP, I = a.I;
     float* const slab0 = reinterpret_cast<float*>(smem);               // [2][slab_stride]: (hre | him) of a tile
     float* const xtr = slab0 + 2 * a.slab_stride;                      // [IP][16]
     float* const xti = xtr + IP * kTile;                               // [IP][16]
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         gw_h[n] = (u < a.ngw) ? rt * 16 : -1;
         gw_x[n] = ct * 16 * kTile;
     }
-    const int h_lane = (4 * fq) * KS + fr;        // A fragment: H[vertex 4fq+s][k = rt*16 + fr]
+    const int h_lane = (4 * fq) * KD + fr;        // A fragment: H[vertex 4fq+s][k = rt*16 + fr]
     const int x_lane = fr * kTile + 4 * fq;       // B fragment: xt[i = ct*16 + fr][vertex 4fq..4fq+3]
 
     f32x4 gre[T], gim[T];
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         __builtin_amdgcn_s_barrier();
 
         const float* hre = slab0 + buf * a.slab_stride;
-        const float* him = hre + kTile * KS;
+        const float* him = hre + kTile * KD;
         // gW += H^T . conj(xt):  re += Hre*Xre + Him*Xim ; im += Him*Xre - Hre*Xim
         if (!(a.dbg & 4)) {
 #pragma unroll
@@ -365,8 +370,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
                     const float4 xi4 = *reinterpret_cast<const float4*>(xti + gw_x[n] + x_lane);
                     const float* ha = hre + gw_h[n] + h_lane;
                     const float* hb = him + gw_h[n] + h_lane;
-                    const float a0 = ha[0], a1 = ha[KS], a2 = ha[2 * KS], a3 = ha[3 * KS];
-                    const float b0 = hb[0], b1 = hb[KS], b2 = hb[2 * KS], b3 = hb[3 * KS];
+                    const float a0 = ha[0], a1 = ha[KD], a2 = ha[2 * KD], a3 = ha[3 * KD];
+                    const float b0 = hb[0], b1 = hb[KD], b2 = hb[2 * KD], b3 = hb[3 * KD];
                     gre[n] = mfma16(a0, xr4.x, gre[n]); gim[n] = mfma16(b0, xr4.x, gim[n]);
                     gre[n] = mfma16(b0, xi4.x, gre[n]); gim[n] = mfma16(-a0, xi4.x, gim[n]);
                     gre[n] = mfma16(a1, xr4.y, gre[n]); gim[n] = mfma16(b1, xr4.y, gim[n]);
@@ -418,7 +423,7 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
 
 struct BwdPlan {
     MmaGeom g;
-    int IP, KP, ntiles, ngw, P, F, slab_floats, slab_stride;
+    int IP, KP, KD, ntiles, ngw, P, F, slab_floats, slab_stride;
     size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes;
     bool ok, ok_factored;
 };
@@ -435,9 +440,10 @@ static BwdPlan plan_backward(const fc_dims* d) {
     if (P < 1) P = 1;
     if (P > p.ntiles) P = p.ntiles;
     p.P = P;
-    p.slab_floats = 2 * kTile * p.g.KS;
+    p.KD = p.g.KP + 4;
+    p.slab_floats = 2 * kTile * p.KD;
     p.slab_stride = round_up(p.slab_floats, 256);
-    p.lds_data = (size_t)(2 * kTile * p.g.KS + p.g.NKP * kTile * p.IP * 2) * sizeof(float);
+    p.lds_data = (size_t)(2 * kTile * p.g.KS + partial_floats(p.g.NKP, p.IP)) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
     p.lds_filter = (size_t)(2 * p.slab_stride + 2 * p.IP * kTile) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
@@ -459,6 +465,7 @@ static BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.g = p.g;
     a.ntiles = p.ntiles;
     a.ngw = p.ngw;
+    a.KD = p.KD;
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
     { const char* e = getenv("FC_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }

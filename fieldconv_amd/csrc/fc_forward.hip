@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const ring = part + a.g.NKP * kTile * a.g.MP * 2 + wave * NR * 256;   // [NR][256] floats, this wavefront's
+    float* const ring = part + partial_floats(a.g.NKP, a.g.MP) + wave * NR * 256;   // [NR][256] floats, this wavefront's
     const int I = a.I;
 
     for (int idx = tid; idx < 2 * kTile * a.g.KS; idx += kThreads) cre[idx] = 0.f;
@@ -360,7 +360,7 @@ int forward_impl(const float* x, const float* sten, const fc_csr* g, const float
     a.g = make_mma_geom(d->O, d->R * d->I);
     a.ntiles = (d->N + kTile - 1) / kTile;
     { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
-    size_t lds = (size_t)(2 * kTile * a.g.KS + a.g.NKP * kTile * a.g.MP * 2) * sizeof(float);
+    size_t lds = (size_t)(2 * kTile * a.g.KS + partial_floats(a.g.NKP, a.g.MP)) * sizeof(float);
     a.ring_chunks = 0;
     if (factored) {
         a.ring_chunks = kRingChunks;

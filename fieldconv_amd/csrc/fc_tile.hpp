@@ -66,17 +66,21 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ wre_plane, co
     }
 }
 
-// Accumulator tile -> LDS partial [kp][vertex][MP][2] (D layout: column = vertex = lane&15,
-// row = output 4*(lane>>4)+j).
+// k-partials in LDS: [kp][row m][vertex v] complex, row stride kPartStride floats.  The accumulator tile
+// (D layout: column = vertex = lane&15, row = 4*(lane>>4)+j) is written with one 8-byte store per
+// lane and row: the 16 lanes of a row cover 32 consecutive floats (all banks once) and the +2 pad
+// keeps the four lane groups of an instruction on different banks.
+constexpr int kPartStride = 2 * kTile + 2;
+
+__host__ __device__ constexpr int partial_floats(int NKP, int MP) { return NKP * MP * kPartStride; }
+
 __device__ __forceinline__ void store_partial(float* part, const MmaGeom& g, int mt, int kp, int lane, const f32x4& acc_re,
                                               const f32x4& acc_im) {
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = mt * 16 + 4 * fq + j;
-        float* p = part + ((size_t)(kp * kTile + fr) * g.MP + m) * 2;
-        p[0] = acc_re[j];
-        p[1] = acc_im[j];
+        *reinterpret_cast<float2*>(part + (size_t)(kp * g.MP + m) * kPartStride + 2 * fr) = make_float2(acc_re[j], acc_im[j]);
     }
 }
 
@@ -84,9 +88,9 @@ __device__ __forceinline__ void store_partial(float* part, const MmaGeom& g, int
 __device__ __forceinline__ float2 sum_partials(const float* part, const MmaGeom& g, int v, int m) {
     float re = 0.f, im = 0.f;
     for (int q = 0; q < g.NKP; ++q) {
-        const float* p = part + ((size_t)(q * kTile + v) * g.MP + m) * 2;
-        re += p[0];
-        im += p[1];
+        const float2 p = *reinterpret_cast<const float2*>(part + (size_t)(q * g.MP + m) * kPartStride + 2 * v);
+        re += p.x;
+        im += p.y;
     }
     return make_float2(re, im);
 }
