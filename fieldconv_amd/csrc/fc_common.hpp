@@ -42,6 +42,30 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 // rounded up to a multiple of 4 floats so records stay 16-byte aligned.
 __host__ __device__ constexpr int factored_record_floats(int B) { return round_up(4 + 2 * (2 * B + 1), 4); }
 
+typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source
+typedef __attribute__((address_space(3))) void* lptr_t;         // global_load_lds destination (wave-uniform base)
+
+// Asynchronous global -> LDS copy issued behind the compiler's back: lane l's 16 (4) bytes at `gsrc`
+// land at LDS byte address lds_base + 16*l (4*l).  hipcc knows nothing about these loads, so it
+// neither counts them nor waits for them -- the __builtin_amdgcn_global_load_lds form makes it drain
+// vmcnt(0) before the next LDS access that may alias the destination, which serialises the copy with
+// whatever LDS work follows.  The caller waits with wait_lds_dma() before touching the data (plus a
+// barrier if other wavefronts read it).  M0 carries the destination and is saved/restored.
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)p);
+}
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base));
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base));
+}
+__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
 __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);
@@ -50,8 +74,7 @@ __host__ __device__ constexpr int factored_log_chunk_records(int B) {
 constexpr int kRunStride = 8;      // ints per vertex in fc_csr::runs (ring-run offsets, n_rings <= 8)
 constexpr int kRingChunks = 4;     // 1 KiB chunks per wavefront in the record ring (power of two, >= 3)
 
-typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source
-typedef __attribute__((address_space(3))) void* lptr_t;         // global_load_lds destination (wave-uniform base)
+
 
 // LDS row stride (floats) for a slab with KP (multiple of 16) k-entries per vertex:
 // KP + 8 keeps the 16x4 float4 fragment reads bank-conflict free (stride = 8 mod 16).
