@@ -85,28 +85,53 @@ def _edge_fields(ps, es1, es2, pt, et1, et2):
     return dist, ang_s, xp_ang
 
 
+def _rcb_order(pts, parts):
+    """Recursive coordinate bisection: a permutation that makes every part a contiguous index range of
+    (almost) equal size and a compact patch (split along the longest axis of the current point set)."""
+    order = np.arange(pts.shape[0])
+
+    def split(idx, nparts):
+        if nparts == 1:
+            return [idx]
+        ext = pts[idx].max(0) - pts[idx].min(0)
+        axis = int(np.argmax(ext))
+        left_parts = nparts // 2
+        cut = (idx.size * left_parts) // nparts
+        o = idx[np.argsort(pts[idx, axis], kind='stable')]
+        return split(o[:cut], left_parts) + split(o[cut:], nparts - left_parts)
+    pieces = split(order, parts)
+    bounds = np.cumsum([0] + [p.size for p in pieces]).astype(np.int64)
+    return np.concatenate(pieces), bounds
+
+
 def sphere_partition(n_total, parts, rank, k=32, seed=0):
     """G-geo: `n_total` jittered Fibonacci points on the unit sphere, k nearest neighbours
     (self included) as in-neighbours of every vertex, exact geodesic log map / transport, area
-    weights.  Returns the slice owned by `rank` of `parts` latitude bands, in LOCAL indices:
+    weights.  The vertices are renumbered so that each of the `parts` compact patches (recursive
+    coordinate bisection) is a contiguous range of global ids.  Returns the patch owned by `rank`,
+    in LOCAL indices:
 
         data           SupportData over n_owned + n_halo local vertices (owned first); every edge's
                        target is owned by this rank; edges grouped by (local) source
         n_owned        vertices owned by this rank
         halo_global    (n_halo,) global ids of the remote sources, grouped by owning rank
-        owner_bounds   (parts+1,) global index ranges of the bands
+        owner_bounds   (parts+1,) global index ranges of the patches
     """
     from scipy.spatial import cKDTree
-    bounds = np.linspace(0, n_total, parts + 1).astype(np.int64)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     pts = _fibonacci_sphere(n_total, 0, n_total, seed)
+    if parts > 1:
+        perm, bounds = _rcb_order(pts, parts)
+        pts = pts[perm]
+    else:
+        bounds = np.array([0, n_total], dtype=np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     e1, e2 = _frames(pts)
     tree = cKDTree(pts)
     _, nbr = tree.query(pts[lo:hi], k=k)                        # (n_owned, k) global source ids
     n_owned = hi - lo
     dst_g = np.repeat(np.arange(lo, hi), k)
     src_g = nbr.reshape(-1)
-    remote = np.unique(src_g[(src_g < lo) | (src_g >= hi)])      # sorted -> grouped by owner band
+    remote = np.unique(src_g[(src_g < lo) | (src_g >= hi)])      # sorted -> grouped by owner range
     local_of = np.full(n_total, -1, dtype=np.int64)
     local_of[lo:hi] = np.arange(n_owned)
     local_of[remote] = n_owned + np.arange(remote.size)

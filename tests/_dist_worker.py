@@ -59,9 +59,16 @@ def main():
     gWr = torch.view_as_real(gW.contiguous()).clone()
     dist.all_reduce(gWr)
 
-    # single-process answer on the unpartitioned mesh
-    full, _, _, _ = sphere_partition(n_total, 1, 0, k=k, seed=3)
-    fe, fs, _, _ = FCPrecomp(B, R, full.epsilon)(full)
+    # single-process answer on the whole mesh: the union of every rank's edges (each rank owns the edges into
+    # its own targets), mapped back to global vertex ids
+    all_e, all_s = [], []
+    for r in range(world):
+        dr, n_r, halo_r, _ = sphere_partition(n_total, world, r, k=k, seed=3)
+        er, sr, _, _ = FCPrecomp(B, R, dr.epsilon)(dr)
+        to_global = torch.cat((torch.arange(int(bounds[r]), int(bounds[r]) + n_r), halo_r))
+        all_e.append(to_global[er])
+        all_s.append(sr)
+    fe, fs = torch.cat(all_e), torch.cat(all_s)
     y_ref = orc.fieldconv_forward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy())
     gx_ref, gW_ref = orc.fieldconv_backward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy(), gy_all.numpy())
 
