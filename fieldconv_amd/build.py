@@ -37,20 +37,39 @@ def needs_build():
 
 
 def build_native(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared library; returns its path."""
+    """Compile every HIP source for gfx950 (one hipcc per source, in parallel) and link them into one
+    shared library; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    compile_flags = [f for f in FLAGS if f != '-shared']
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OUT_DIR, src.replace('.hip', '.%d.o' % os.getpid()))
+        cmd = [hipcc] + compile_flags + ['-c', '-o', obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    errors = []
+    for src, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            errors.append(f'{src}:\n{out}')
     tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-    cmd = [_hipcc()] + FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError('hipcc failed:\n' + res.stdout)
-    os.replace(tmp, LIB_PATH)
+    try:
+        if errors:
+            raise RuntimeError('hipcc failed:\n' + '\n'.join(errors))
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc', '-o', tmp] + objs
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('hipcc link failed:\n' + res.stdout)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        for f in objs + [tmp]:
+            if os.path.exists(f):
+                os.remove(f)
     return LIB_PATH
 
 

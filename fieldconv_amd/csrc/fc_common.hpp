@@ -45,27 +45,6 @@ __host__ __device__ constexpr int factored_record_floats(int B) { return round_u
 typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source
 typedef __attribute__((address_space(3))) void* lptr_t;         // global_load_lds destination (wave-uniform base)
 
-// Asynchronous global -> LDS copy issued behind the compiler's back: lane l's 16 (4) bytes at `gsrc`
-// land at LDS byte address lds_base + 16*l (4*l).  hipcc knows nothing about these loads, so it
-// neither counts them nor waits for them -- the __builtin_amdgcn_global_load_lds form makes it drain
-// vmcnt(0) before the next LDS access that may alias the destination, which serialises the copy with
-// whatever LDS work follows.  The caller waits with wait_lds_dma() before touching the data (plus a
-// barrier if other wavefronts read it).  M0 carries the destination and is saved/restored.
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)p);
-}
-__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base));
-}
-__device__ __forceinline__ void lds_dma4(const void* gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base));
-}
-__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
 __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);
@@ -145,75 +124,6 @@ __device__ __forceinline__ void cmac_sx_real(f32x2& acc, f32x2 s, float a) {
 __device__ __forceinline__ void cmac_gconjs(f32x2& acc, f32x2 s, f32x2 g, f32x2 gs) {
     acc = __builtin_elementwise_fma(f32x2{s.x, s.x}, g, acc);
     acc = __builtin_elementwise_fma(f32x2{s.y, s.y}, gs, acc);
-}
-
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// A run of NF (even) floats of a wave-uniform stream, held in SGPRs and loaded with hand-issued
-// scalar loads so that the load/wait placement is ours, not the compiler's (hipcc neither counts
-// nor waits for loads inside asm): issue() starts the s_load_dwordx{16,8,4,2} pieces, retire()
-// is the matching s_waitcnt lgkmcnt(0) and routes every piece through an asm so no use can be
-// scheduled above it.  Scalar loads return out of order, hence lgkmcnt(0) and one chunk in flight.
-template <int NF>
-struct SgprChunk {
-    static_assert(NF % 2 == 0 && NF >= 2 && NF <= 62, "chunk of 2..62 floats");
-    static constexpr int N16 = NF / 16, R16 = NF % 16;
-    static constexpr int N8 = R16 / 8, R8 = R16 % 8;
-    static constexpr int N4 = R8 / 4, R4 = R8 % 4;
-    static constexpr int N2 = R4 / 2;
-    f32x16 a[N16 ? N16 : 1];
-    f32x8 b;
-    f32x4 c;
-    f32x2 d;
-
-    __device__ __forceinline__ void issue(const float* __restrict__ p) {
-        // one base pointer (SGPR pair), byte offsets as instruction immediates
-        if (N16 > 0) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[0]) : "s"(p), "i"(0));
-        if (N16 > 1) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[N16 > 1 ? 1 : 0]) : "s"(p), "i"(64));
-        if (N16 > 2) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a[N16 > 2 ? 2 : 0]) : "s"(p), "i"(128));
-        if (N8) asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(b) : "s"(p), "i"(64 * N16));
-        if (N4) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c) : "s"(p), "i"(64 * N16 + 32 * N8));
-        if (N2) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(d) : "s"(p), "i"(64 * N16 + 32 * N8 + 16 * N4));
-    }
-    __device__ __forceinline__ void retire() {
-        asm volatile("s_waitcnt lgkmcnt(0)");
-        // (volatile asms keep their order; each piece is routed through one so that its uses follow the wait)
-#pragma unroll
-        for (int i = 0; i < N16; ++i) asm volatile("" : "+s"(a[i]));
-        if (N8) asm volatile("" : "+s"(b));
-        if (N4) asm volatile("" : "+s"(c));
-        if (N2) asm volatile("" : "+s"(d));
-    }
-    // complex entry k (floats 2k, 2k+1) as an SGPR pair; k must fold to a constant after unrolling,
-    // the pair is then an aligned sub-register of its piece (no copy)
-    __device__ __forceinline__ float elem(const int i) const {
-        if (i < 16 * N16) return a[i / 16][i % 16];
-        if (i < 16 * N16 + 8 * N8) return b[(i - 16 * N16) % 8];
-        if (i < 16 * N16 + 8 * N8 + 4 * N4) return c[(i - 16 * N16 - 8 * N8) % 4];
-        return d[(i - 16 * N16 - 8 * N8 - 4 * N4) % 2];
-    }
-    __device__ __forceinline__ f32x2 pair(const int k) const { return f32x2{elem(2 * k), elem(2 * k + 1)}; }
-};
-
-// Make the compiler retire its own pending scalar load of `v` here (empty asm consuming the SGPR).
-__device__ __forceinline__ void fc_keep_sgpr(int v) { asm volatile("" ::"s"(v)); }
-
-// Pull [base, base+bytes) towards L2 ahead of the scalar loads that will consume it: every lane
-// reads one float per 64-byte granule, up to 8 wave-instructions (32 KiB) in flight, values summed
-// into dead registers.  Plain loads on purpose: an asm load taking the pointer stops the compiler
-// from proving the stream read-only and it falls back to per-lane vector loads for the stencil.
-__device__ __forceinline__ void prefetch_range(const void* __restrict__ base, long bytes, int lane) {
-    const char* p = reinterpret_cast<const char*>(base);
-    float sink[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long off0 = 0; off0 < bytes; off0 += 8 * kWave * 64) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long off = off0 + (long)(j * kWave + lane) * 64;
-            if (off < bytes) sink[j] += *reinterpret_cast<const float*>(p + off);
-        }
-    }
-    asm volatile("" ::"v"(sink[0]), "v"(sink[1]), "v"(sink[2]), "v"(sink[3]), "v"(sink[4]), "v"(sink[5]), "v"(sink[6]), "v"(sink[7]));
 }
 
 // One rotated copy for a run-time frequency m (|m| <= B): returns u^m, the caller multiplies.

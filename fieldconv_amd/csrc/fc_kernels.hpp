@@ -3,13 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "../../include/fieldconv_hip.h"
 
-// (n_rings, band_limit) pairs with register-resident kernels.  The reference's notebooks use
-// (6,1), (6,2), (6,3); the small ones serve the golden fixtures.  Anything else returns
-// FC_ERR_UNSUPPORTED (fc_supported() == 0).
+// (n_rings, band_limit) pairs with compiled kernels: every n_rings in 2..8 for band limits 1..3 (the
+// reference's notebooks use (6,1), (6,2), (6,3)).  Anything else returns FC_ERR_UNSUPPORTED
+// (fc_supported() == 0).
 #define FC_FOR_EACH_SHAPE(X) \
-    X(3, 1) X(4, 1) X(6, 1) X(8, 1) \
-    X(3, 2) X(4, 2) X(6, 2) X(8, 2) \
-    X(5, 3) X(6, 3)
+    X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(7, 1) X(8, 1) \
+    X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(7, 2) X(8, 2) \
+    X(2, 3) X(3, 3) X(4, 3) X(5, 3) X(6, 3) X(7, 3) X(8, 3)
 
 namespace fc {
 

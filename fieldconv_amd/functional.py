@@ -189,9 +189,27 @@ class _FieldConvParamFn(torch.autograd.Function):
         return gx, g_z, g_s, g_p, None, None, None
 
 
+MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)
+
+
 def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
-    """FieldConv from the raw module parameters (see FieldConv.forward)."""
+    """FieldConv from the raw module parameters (see FieldConv.forward).  Layers wider than 64 channels
+    run as blocks of <= 64 input x <= 64 output channels: the operator is linear in the input channels
+    (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
     _require_device(x, 'field_conv')
+    O, I = zonal.shape[0], zonal.shape[1]
+    if I > MAX_CHANNELS or O > MAX_CHANNELS:
+        outs = []
+        for o0 in range(0, O, MAX_CHANNELS):
+            osl = slice(o0, min(o0 + MAX_CHANNELS, O))
+            acc = None
+            for i0 in range(0, I, MAX_CHANNELS):
+                isl = slice(i0, min(i0 + MAX_CHANNELS, I))
+                part = field_conv_params(x[:, isl], zonal[osl, isl], spherical[osl, isl], phase[osl, isl], ftype, band_limit,
+                                         graph)
+                acc = part if acc is None else acc + part
+            outs.append(acc)
+        return torch.cat(outs, dim=1)
     if x.dtype != torch.complex64:
         raise ValueError('field_conv expects complex64 features')
     if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != zonal.shape[1]:

@@ -157,6 +157,8 @@ CASES = [
     (5, 260, 9, 48, 8, 2, 6, True),        # ECHOBlock-like width change
     (6, 333, 7, 3, 48, 1, 6, False),
     (7, 150, 40, 32, 33, 2, 8, True),
+    (10, 120, 6, 12, 20, 3, 7, True),      # n_rings = 7, band limit 3
+    (11, 90, 5, 24, 8, 2, 2, False),       # n_rings = 2
     (8, 100, 5, 17, 5, 1, 3, True),
     (9, 15, 4, 8, 8, 2, 4, True),          # fewer vertices than one tile
 ]
@@ -232,10 +234,31 @@ def test_empty_graph_and_isolated_vertices(dev):
 def test_unsupported_shapes_fail_loudly(dev):
     from fieldconv_amd._lib import FieldConvNativeError
     from fieldconv_amd.nn import FieldConv
-    conv = FieldConv(4, 4, band_limit=1, n_rings=7).to(dev)       # n_rings=7 is not compiled
+    conv = FieldConv(4, 4, band_limit=1, n_rings=9).to(dev)       # n_rings=9 is not compiled (2..8 are)
     x = torch.zeros(5, 4, dtype=torch.cfloat, device=dev)
     with pytest.raises(FieldConvNativeError):
-        conv(x, torch.zeros(3, 2, dtype=torch.long, device=dev), torch.zeros(3, 7, 3, dtype=torch.cfloat, device=dev))
+        conv(x, torch.zeros(3, 2, dtype=torch.long, device=dev), torch.zeros(3, 9, 3, dtype=torch.cfloat, device=dev))
+
+
+def test_wide_layers_are_split_into_channel_blocks(dev):
+    """More than 64 channels: the module splits input / output channels into blocks of <= 64 (the
+    operator is linear in the input channels and independent across output channels)."""
+    from fieldconv_amd.nn import FieldConv
+    N, k, I, O, B, R = 200, 10, 80, 70, 1, 3
+    edges, sten, x, gy, _ = make_case(21, N, k, I, O, B, R, True)
+    conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=1).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = conv(xd, edges.to(dev), sten.to(dev))
+    params = dict(conv.named_parameters())
+    grads = torch.autograd.grad(y, [xd] + list(params.values()), grad_outputs=gy.to(dev))
+    z, s, p = (H(conv.zonal), H(conv.spherical), H(conv.phase))
+    W = orc.effective_filter(z, s, p, 1, B)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W)
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W, gy.numpy())
+    gz, gs, gp = orc.effective_filter_vjp(gW_ref, z, s, p, 1, B)
+    assert rel_err(H(y), y_ref) < TOL
+    assert rel_err(H(grads[0]), gx_ref) < TOL
+    assert rel_err(H(grads[1]), gz) < TOL and rel_err(H(grads[2]), gs) < TOL and rel_err(H(grads[3]), gp) < TOL
 
 
 # ---------------------------------------------------------------- full benchmark size: properties

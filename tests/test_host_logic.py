@@ -45,7 +45,7 @@ def test_supported_query_and_sizes_need_no_gpu():
     assert lib.fc_supported(ctypes.byref(d)) == 1
     assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d)) == 5 * 2 * 48 * 288
     assert lib.fc_backward_workspace_bytes(ctypes.byref(d)) > 0
-    bad = _lib.FcDims(100, 10, 48, 48, 7, 2)
+    bad = _lib.FcDims(100, 10, 48, 48, 9, 2)
     assert lib.fc_supported(ctypes.byref(bad)) == 0
     wide = _lib.FcDims(100, 10, 128, 48, 6, 2)
     assert lib.fc_supported(ctypes.byref(wide)) == 0
