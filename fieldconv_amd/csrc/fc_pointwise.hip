@@ -11,126 +11,201 @@ namespace fc {
 // out[n, m] = sum_k in[n, k] * Wc(m, k)          (complex, no bias)
 //   TRANSPOSED = false : Wc(m,k) = Re[m*ldw + k] + i Im[m*ldw + k]            (forward, m = o, k = i)
 //   TRANSPOSED = true  : Wc(m,k) = Re[k*ldw + m] - i Im[k*ldw + m]            (input grad, m = i, k = o)
-// Real-expanded on v_mfma_f32_16x16x4_f32: the interleaved (re,im) input row is the B operand as it
-// lies in memory (k_real = 2k + c), the A operand rows are [Wre, -Wim] for the real part of the
-// output and [Wim, Wre] for the imaginary part.  One wavefront = 16 vertices x all output tiles.
+// Real-expanded on v_mfma_f32_16x16x4_f32 with k_real = 2k + c: the interleaved (re,im) input row is
+// the A operand exactly as it lies in memory; the workgroup stages the two expanded filter planes
+//   Wr[m][2k] = Re Wc, Wr[m][2k+1] = -Im Wc      (real part of the output)
+//   Wi[m][2k] = Im Wc, Wi[m][2k+1] =  Re Wc      (imaginary part)
+// in LDS once (row stride = slab_stride, conflict-free float4 fragments) while the first input
+// fragments are already in flight, and every wavefront then walks blocks of 16 vertices with up to 64
+// outputs accumulated together.  D rows = vertices, columns = outputs: each accumulator row is one
+// 128-byte store.  Loads are unconditional from clamped addresses (no control flow around them).
+constexpr int kLinThreads = 256;
+constexpr int kLinWaves = kLinThreads / kWave;
+constexpr int kLinChunk = 6;      // k blocks (8 complex inputs each) loaded ahead of their MFMAs
+constexpr int kLinTiles = 4;      // output tiles accumulated together
+constexpr int kLinStage = 8;      // filter entries in flight per thread while staging
+
+__host__ __device__ inline int lin_plane_floats(int M, int K) { return round_up(M, 16) * slab_stride(round_up(2 * K, 16)); }
+
+__device__ __forceinline__ void lin_load_fragments(float4 (&a)[kLinChunk], const float* row, int kc, int fq, int K, bool vec,
+                                                   float keep) {
+    const int last = 2 * K - 1;
+#pragma unroll
+    for (int u = 0; u < kLinChunk; ++u) {
+        const int kr0 = 16 * (kc + u) + 4 * fq;
+        if (vec) {
+            a[u] = *reinterpret_cast<const float4*>(row + min(kr0, 2 * K - 4));
+            if (kr0 > 2 * K - 4) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            a[u].x = kr0 <= last ? row[min(kr0, last)] : 0.f;
+            a[u].y = kr0 + 1 <= last ? row[min(kr0 + 1, last)] : 0.f;
+            a[u].z = kr0 + 2 <= last ? row[min(kr0 + 2, last)] : 0.f;
+            a[u].w = kr0 + 3 <= last ? row[min(kr0 + 3, last)] : 0.f;
+        }
+        a[u].x *= keep; a[u].y *= keep; a[u].z *= keep; a[u].w *= keep;
+    }
+}
+
 template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void tangent_lin_kernel(const float2* __restrict__ in, const float* __restrict__ wre,
-                                                          const float* __restrict__ wim, float2* __restrict__ out,
-                                                          int N, int K, int M, int ldw) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* __restrict__ in, const float* __restrict__ wre,
+                                                                  const float* __restrict__ wim, float2* __restrict__ out,
+                                                                  int N, int K, int M, int ldw) {
+    extern __shared__ float lds[];
+    const int KR = round_up(2 * K, 16), KS = slab_stride(KR), MP = round_up(M, 16);
+    float* Wr = lds;
+    float* Wi = lds + MP * KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = wave * 16;
-    if (n0 >= N) return;
-    const int n = n0 + fr;
-    const bool nvalid = n < N;
-    const int MT = (M + 15) / 16;
-    const int KB = (2 * K + 15) / 16;
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + fr;
-        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
-        for (int kb = 0; kb < KB; ++kb) {
-            const int k0 = 8 * kb + 2 * fq;        // two complex k per lane: k0, k0 + 1
-            float2 b0 = make_float2(0.f, 0.f), b1 = b0;
-            if (nvalid && k0 < K) b0 = in[(size_t)n * K + k0];
-            if (nvalid && k0 + 1 < K) b1 = in[(size_t)n * K + k0 + 1];
-            float r0 = 0.f, i0 = 0.f, r1 = 0.f, i1 = 0.f;
-            if (m < M) {
-                if (k0 < K) {
-                    const size_t w = TRANSPOSED ? (size_t)k0 * ldw + m : (size_t)m * ldw + k0;
-                    r0 = wre[w];
-                    i0 = TRANSPOSED ? -wim[w] : wim[w];
-                }
-                if (k0 + 1 < K) {
-                    const size_t w = TRANSPOSED ? (size_t)(k0 + 1) * ldw + m : (size_t)m * ldw + k0 + 1;
-                    r1 = wre[w];
-                    i1 = TRANSPOSED ? -wim[w] : wim[w];
+    const int nblocks = (N + 15) / 16, MT = MP / 16, KB = KR / 16;
+    const float* in_f = reinterpret_cast<const float*>(in);
+    const bool vec = (K & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;       // 16-byte aligned rows
+
+    // first input fragments of this wavefront: in flight while the filter is staged
+    const int blk0 = blockIdx.x * kLinWaves + wave;
+    float4 a[kLinChunk];
+    {
+        const int n = min(blk0, nblocks - 1) * 16 + fr;
+        lin_load_fragments(a, in_f + (size_t)min(n, N - 1) * 2 * K, 0, fq, K, vec, n < N ? 1.f : 0.f);
+    }
+
+    for (int idx = threadIdx.x; idx < 2 * MP * KS; idx += kLinThreads) lds[idx] = 0.f;
+    __syncthreads();
+    // filter entries in memory order ([M][K] forward, [K][M] transposed), kLinStage loads in flight
+    const int total = M * K, cols = TRANSPOSED ? M : K;
+    for (int base = 0; base < total; base += kLinStage * kLinThreads) {
+        float re[kLinStage], im[kLinStage];
+        int at[kLinStage];
+#pragma unroll
+        for (int u = 0; u < kLinStage; ++u) {
+            const int idx = min(base + u * kLinThreads + (int)threadIdx.x, total - 1);
+            const int r = idx / cols, c = idx - r * cols;
+            re[u] = wre[(size_t)r * ldw + c];
+            im[u] = TRANSPOSED ? -wim[(size_t)r * ldw + c] : wim[(size_t)r * ldw + c];
+            at[u] = TRANSPOSED ? c * KS + 2 * r : r * KS + 2 * c;
+        }
+#pragma unroll
+        for (int u = 0; u < kLinStage; ++u) {
+            if (base + u * kLinThreads + (int)threadIdx.x < total) {
+                *reinterpret_cast<float2*>(Wr + at[u]) = make_float2(re[u], -im[u]);
+                *reinterpret_cast<float2*>(Wi + at[u]) = make_float2(im[u], re[u]);
+            }
+        }
+    }
+    __syncthreads();
+
+    bool loaded = true;
+    for (int blk = blk0; blk < nblocks; blk += gridDim.x * kLinWaves) {
+        const int n = blk * 16 + fr;
+        const float* row = in_f + (size_t)min(n, N - 1) * 2 * K;
+        const float keep = n < N ? 1.f : 0.f;
+        for (int mg = 0; mg < MT; mg += kLinTiles) {
+            f32x4 acc_re[kLinTiles], acc_im[kLinTiles];
+#pragma unroll
+            for (int t = 0; t < kLinTiles; ++t) { acc_re[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_im[t] = acc_re[t]; }
+            for (int kc = 0; kc < KB; kc += kLinChunk) {
+                if (!loaded) lin_load_fragments(a, row, kc, fq, K, vec, keep);
+                loaded = false;
+#pragma unroll
+                for (int t = 0; t < kLinTiles; ++t) {
+                    if (mg + t < MT) {
+                        const float* pr = Wr + ((mg + t) * 16 + fr) * KS + 4 * fq;
+                        const float* pi = Wi + ((mg + t) * 16 + fr) * KS + 4 * fq;
+#pragma unroll
+                        for (int u = 0; u < kLinChunk; ++u) {
+                            if (kc + u < KB) {
+                                const float4 br = *reinterpret_cast<const float4*>(pr + 16 * (kc + u));
+                                const float4 bi = *reinterpret_cast<const float4*>(pi + 16 * (kc + u));
+                                acc_re[t] = mfma16(a[u].x, br.x, acc_re[t]); acc_im[t] = mfma16(a[u].x, bi.x, acc_im[t]);
+                                acc_re[t] = mfma16(a[u].y, br.y, acc_re[t]); acc_im[t] = mfma16(a[u].y, bi.y, acc_im[t]);
+                                acc_re[t] = mfma16(a[u].z, br.z, acc_re[t]); acc_im[t] = mfma16(a[u].z, bi.z, acc_im[t]);
+                                acc_re[t] = mfma16(a[u].w, br.w, acc_re[t]); acc_im[t] = mfma16(a[u].w, bi.w, acc_im[t]);
+                            }
+                        }
+                    }
                 }
             }
-            acc_re = mfma16(r0, b0.x, acc_re);  acc_im = mfma16(i0, b0.x, acc_im);
-            acc_re = mfma16(-i0, b0.y, acc_re); acc_im = mfma16(r0, b0.y, acc_im);
-            acc_re = mfma16(r1, b1.x, acc_re);  acc_im = mfma16(i1, b1.x, acc_im);
-            acc_re = mfma16(-i1, b1.y, acc_re); acc_im = mfma16(r1, b1.y, acc_im);
-        }
-        // D layout: column = vertex fr, rows = outputs mt*16 + 4*fq + j
-        if (nvalid) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int mo = mt * 16 + 4 * fq + j;
-                if (mo < M) out[(size_t)n * M + mo] = make_float2(acc_re[j], acc_im[j]);
+            for (int t = 0; t < kLinTiles; ++t) {
+                const int mo = (mg + t) * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int no = blk * 16 + 4 * fq + j;
+                    if (no < N && mo < M) out[(size_t)no * M + mo] = make_float2(acc_re[t][j], acc_im[t][j]);
+                }
             }
         }
     }
 }
 
 // Weight gradient gW[o,i] = sum_n gy[n,o] conj(x[n,i]) on MFMA with the vertices as the k dimension.
-// Each wavefront walks every `stride`-th block of 16 vertices and keeps all (o-tile, i-tile)
-// accumulators; partial[wave][o][i] is reduced by tangent_lin_gw_reduce_kernel in a fixed order.
-template <int MAXT>   // max tiles per side (channels <= 16*MAXT)
-__global__ __launch_bounds__(256) void tangent_lin_gw_kernel(const float2* __restrict__ x, const float2* __restrict__ gy,
-                                                             float2* __restrict__ partial, int N, int I, int O,
-                                                             int nwaves_total) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int OT = (O + 15) / 16, IT = (I + 15) / 16;
-    f32x4 are[MAXT][MAXT], aim[MAXT][MAXT];
-#pragma unroll
-    for (int a = 0; a < MAXT; ++a)
-#pragma unroll
-        for (int b = 0; b < MAXT; ++b) { are[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; aim[a][b] = are[a][b]; }
+// One wavefront per (o-tile, i-tile) pair (blockIdx.y picks the group of up to 16 pairs); workgroup g
+// walks every gridDim.x-th block of 16 vertices, so a wavefront owns its 16x16 tile of the partial
+// outright: no cross-wavefront combination, no LDS.  partial[g][o][i] is reduced by
+// tangent_lin_gw_reduce_kernel in a fixed order.
+constexpr int kLinGwGroups = 256;
+constexpr int kLinGwPairs = 16;     // wavefronts per workgroup
 
+__global__ __launch_bounds__(kLinGwPairs * kWave) void tangent_lin_gw_kernel(const float2* __restrict__ x,
+                                                                             const float2* __restrict__ gy,
+                                                                             float2* __restrict__ partial, int N, int I, int O) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int IT = (I + 15) / 16, OT = (O + 15) / 16;
+    const int pair = blockIdx.y * kLinGwPairs + wave;
+    if (pair >= OT * IT) return;
+    const int a = pair / IT, b = pair - a * IT;
+    const int co = a * 16 + fr, ci = b * 16 + fr;
+    const size_t go = min(co, O - 1), xi = min(ci, I - 1);
+    const float keep_o = co < O ? 1.f : 0.f, keep_i = ci < I ? 1.f : 0.f;
+    f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
     const int nblocks = (N + 15) / 16;
-    for (int blk = wave; blk < nblocks; blk += nwaves_total) {
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        float2 g[4], v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {      // unconditional loads from clamped rows, zeroed below
+            const size_t n = min(blk * 16 + 4 * fq + s, N - 1);
+            g[s] = gy[n * O + go];
+            v[s] = x[n * I + xi];
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int n = blk * 16 + 4 * fq + s;
-            float2 g[MAXT], v[MAXT];
-#pragma unroll
-            for (int a = 0; a < MAXT; ++a) {
-                const int o = a * 16 + fr, i = a * 16 + fr;
-                g[a] = (n < N && a < OT && o < O) ? gy[(size_t)n * O + o] : make_float2(0.f, 0.f);
-                v[a] = (n < N && a < IT && i < I) ? x[(size_t)n * I + i] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int a = 0; a < MAXT; ++a)
-#pragma unroll
-                for (int b = 0; b < MAXT; ++b) {
-                    if (a < OT && b < IT) {
-                        // re += g.re x.re + g.im x.im ; im += g.im x.re - g.re x.im
-                        are[a][b] = mfma16(g[a].x, v[b].x, are[a][b]); aim[a][b] = mfma16(g[a].y, v[b].x, aim[a][b]);
-                        are[a][b] = mfma16(g[a].y, v[b].y, are[a][b]); aim[a][b] = mfma16(-g[a].x, v[b].y, aim[a][b]);
-                    }
-                }
+            const float ko = (blk * 16 + 4 * fq + s < N) ? keep_o : 0.f;
+            const float gr = g[s].x * ko, gi = g[s].y * ko, vr = v[s].x * keep_i, vi = v[s].y * keep_i;
+            // re += g.re x.re + g.im x.im ; im += g.im x.re - g.re x.im
+            are = mfma16(gr, vr, are); aim = mfma16(gi, vr, aim);
+            are = mfma16(gi, vi, are); aim = mfma16(-gr, vi, aim);
         }
     }
 #pragma unroll
-    for (int a = 0; a < MAXT; ++a)
-#pragma unroll
-        for (int b = 0; b < MAXT; ++b) {
-            if (a < OT && b < IT) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int o = a * 16 + 4 * fq + j, i = b * 16 + fr;
-                    if (o < O && i < I) partial[((size_t)wave * O + o) * I + i] = make_float2(are[a][b][j], aim[a][b][j]);
-                }
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int o = a * 16 + 4 * fq + j;
+        if (o < O && ci < I) partial[((size_t)blockIdx.x * O + o) * I + ci] = make_float2(are[j], aim[j]);
+    }
 }
 
-__global__ void tangent_lin_gw_reduce_kernel(const float2* __restrict__ partial, float* __restrict__ g_re,
-                                             float* __restrict__ g_im, int nparts, int OI) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= OI) return;
+// Fixed-order sum of the workgroup partials: 64 entries per block, four wavefronts take every fourth
+// partial each and combine through LDS.
+__global__ __launch_bounds__(256) void tangent_lin_gw_reduce_kernel(const float2* __restrict__ partial, float* __restrict__ g_re,
+                                                                    float* __restrict__ g_im, int nparts, int OI) {
+    __shared__ float2 sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
     float re = 0.f, im = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        const float2 v = partial[(size_t)p * OI + idx];
-        re += v.x;
-        im += v.y;
+    if (idx < OI) {
+#pragma unroll 8
+        for (int p = wave; p < nparts; p += 4) {
+            const float2 v = partial[(size_t)p * OI + idx];
+            re += v.x;
+            im += v.y;
+        }
     }
-    g_re[idx] = re;
-    g_im[idx] = im;
+    sh[wave][lane] = make_float2(re, im);
+    __syncthreads();
+    if (wave == 0 && idx < OI) {
+        const float2 a = sh[0][lane], b = sh[1][lane], c = sh[2][lane], d = sh[3][lane];
+        g_re[idx] = (a.x + b.x) + (c.x + d.x);
+        g_im[idx] = (a.y + b.y) + (c.y + d.y);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -152,97 +227,120 @@ __global__ void tangent_nonlin_fwd_kernel(const float2* __restrict__ x, const fl
 }
 
 // gx = e (f'(r) g_r + i f(r)/r g_t) with e = x/|x|, g_r + i g_t = gy conj(e); origin entries: gx = gy.
-// gbias[c] = sum_n [r + b > 0] g_r, accumulated per block in LDS then written as a partial.
-constexpr int kNonlinRows = 64;    // rows per block
-__global__ __launch_bounds__(256) void tangent_nonlin_bwd_kernel(const float2* __restrict__ x,
-                                                                 const float* __restrict__ bias,
-                                                                 const float2* __restrict__ gy,
-                                                                 float2* __restrict__ gx, float* __restrict__ partial,
-                                                                 int N, int C) {
-    extern __shared__ float sh[];      // C floats
-    for (int c = threadIdx.x; c < C; c += blockDim.x) sh[c] = 0.f;
-    __syncthreads();
-    const int r0 = blockIdx.x * kNonlinRows;
-    const int rows = min(kNonlinRows, N - r0);
-    // thread t owns channel slots c = t, t + 256, ... and walks the rows: fixed order -> deterministic
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float b = bias[c];
-        float acc = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            const size_t idx = (size_t)(r0 + r) * C + c;
-            const float2 v = x[idx];
-            const float2 g = gy[idx];
-            float2 o = g;
-            if (!is_origin(v)) {
-                const float rad = sqrtf(v.x * v.x + v.y * v.y);
-                const float inv = 1.f / rad;
-                const float ex = v.x * inv, ey = v.y * inv;
-                const float gr = g.x * ex + g.y * ey;      // Re(g conj(e))
-                const float gt = g.y * ex - g.x * ey;      // Im(g conj(e))
-                const bool act = (rad + b) > 0.f;
-                const float fr_ = act ? gr : 0.f;
-                const float ft = (act ? (rad + b) : 0.f) * inv * gt;
-                o = make_float2(ex * fr_ - ey * ft, ey * fr_ + ex * ft);
-                acc += fr_;
+// gbias[c] = sum_n [r + b > 0] g_r.  A workgroup owns a contiguous range of rows; its threads are laid
+// out as (row lane, channel) so that consecutive threads touch consecutive entries, every thread
+// walks its rows in order, and the row lanes are combined through LDS in a fixed order.
+constexpr int kNonlinThreads = 256;
+constexpr int kNonlinMaxGroups = 512;
+
+__host__ __device__ inline int nonlin_rows_per_group(int N) {
+    int rows = (N + kNonlinMaxGroups - 1) / kNonlinMaxGroups;
+    return rows < 8 ? 8 : rows;
+}
+
+__global__ __launch_bounds__(kNonlinThreads) void tangent_nonlin_bwd_kernel(const float2* __restrict__ x,
+                                                                            const float* __restrict__ bias,
+                                                                            const float2* __restrict__ gy,
+                                                                            float2* __restrict__ gx, float* __restrict__ partial,
+                                                                            int N, int C, int rows_per_group) {
+    extern __shared__ float sh[];      // [row lanes][C]
+    const int L = C < kNonlinThreads ? kNonlinThreads / C : 1;       // row lanes
+    const int r0 = blockIdx.x * rows_per_group;
+    const int rows = min(rows_per_group, N - r0);
+    const int rl = threadIdx.x / C;
+    if (rl < L) {
+        for (int c = threadIdx.x - rl * C; c < C; c += kNonlinThreads) {
+            const float b = bias[c];
+            float acc = 0.f;
+            for (int r = rl; r < rows; r += L) {
+                const size_t idx = (size_t)(r0 + r) * C + c;
+                const float2 v = x[idx];
+                const float2 g = gy[idx];
+                float2 o = g;
+                if (!is_origin(v)) {
+                    const float rad = sqrtf(v.x * v.x + v.y * v.y);
+                    const float inv = 1.f / rad;
+                    const float ex = v.x * inv, ey = v.y * inv;
+                    const float gr = g.x * ex + g.y * ey;      // Re(g conj(e))
+                    const float gt = g.y * ex - g.x * ey;      // Im(g conj(e))
+                    const bool act = (rad + b) > 0.f;
+                    const float fr_ = act ? gr : 0.f;
+                    const float ft = (act ? (rad + b) : 0.f) * inv * gt;
+                    o = make_float2(ex * fr_ - ey * ft, ey * fr_ + ex * ft);
+                    acc += fr_;
+                }
+                gx[idx] = o;
             }
-            gx[idx] = o;
+            sh[rl * C + c] = acc;
         }
-        sh[c] = acc;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) partial[(size_t)blockIdx.x * C + c] = sh[c];
+    for (int c = threadIdx.x; c < C; c += kNonlinThreads) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += sh[l * C + c];
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
 }
 
-__global__ void tangent_nonlin_gb_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gbias,
-                                                int nparts, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// One wavefront per channel: lanes take every 64th partial in order, then a fixed butterfly.
+__global__ __launch_bounds__(64) void tangent_nonlin_gb_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gbias,
+                                                                      int nparts, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * C + c];
-    gbias[c] = s;
+    for (int p = lane; p < nparts; p += 64) s += partial[(size_t)p * C + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) gbias[c] = s;
 }
-
-constexpr int kLinGwWaves = 256;
 
 }  // namespace fc
 
 extern "C" {
 
+namespace {
+int lin_grid(int N) {
+    const int groups = ((N + 15) / 16 + fc::kLinWaves - 1) / fc::kLinWaves;
+    return groups < 4 * fc::kNumCUs ? groups : 4 * fc::kNumCUs;
+}
+int lin_gw_groups(int N) {
+    const int nblocks = (N + 15) / 16;
+    return nblocks < fc::kLinGwGroups ? nblocks : fc::kLinGwGroups;
+}
+}  // namespace
+
 int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w, float* y, int32_t N, int32_t I,
                            int32_t O, void* stream) {
     if (!x || !re_w || !im_w || !y || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
-    const int waves = (N + 15) / 16;
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float2*>(x), re_w, im_w, reinterpret_cast<float2*>(y), N, I, O, I);
+    const size_t lds = 2 * (size_t)fc::lin_plane_floats(O, I) * sizeof(float);
+    if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(lin_grid(N)), dim3(fc::kLinThreads), lds,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w,
+                       reinterpret_cast<float2*>(y), N, I, O, I);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 size_t fc_tangent_lin_backward_workspace_bytes(int32_t N, int32_t I, int32_t O) {
     (void)N;
-    return (size_t)fc::kLinGwWaves * O * I * sizeof(float2);
+    return (size_t)fc::kLinGwGroups * O * I * sizeof(float2);
 }
 
 int fc_tangent_lin_backward(const float* x, const float* gy, const float* re_w, const float* im_w, float* gx,
                             float* g_re, float* g_im, void* workspace, size_t workspace_bytes, int32_t N, int32_t I,
                             int32_t O, void* stream) {
     if (!x || !gy || !re_w || !im_w || !gx || !g_re || !g_im || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
-    if (I > 64 || O > 64) return FC_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < fc_tangent_lin_backward_workspace_bytes(N, I, O)) return FC_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int waves = (N + 15) / 16;
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s,
+    const size_t lds = 2 * (size_t)fc::lin_plane_floats(I, O) * sizeof(float);
+    if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fc::tangent_lin_kernel<true>, dim3(lin_grid(N)), dim3(fc::kLinThreads), lds, s,
                        reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx), N, O, I, I);
     float2* part = reinterpret_cast<float2*>(workspace);
-    const int nblocks = (N + 15) / 16;
-    int nw = fc::kLinGwWaves;
-    if (nw > nblocks) nw = (nblocks + 3) / 4 * 4;
-    if (I <= 32 && O <= 32)
-        hipLaunchKernelGGL(fc::tangent_lin_gw_kernel<2>, dim3(nw / 4), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                           reinterpret_cast<const float2*>(gy), part, N, I, O, nw);
-    else
-        hipLaunchKernelGGL(fc::tangent_lin_gw_kernel<4>, dim3(nw / 4), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                           reinterpret_cast<const float2*>(gy), part, N, I, O, nw);
-    hipLaunchKernelGGL(fc::tangent_lin_gw_reduce_kernel, dim3((O * I + 255) / 256), dim3(256), 0, s, part, g_re, g_im, nw,
+    const int ng = lin_gw_groups(N);
+    const int pairs = ((O + 15) / 16) * ((I + 15) / 16);
+    const int per_group = pairs < fc::kLinGwPairs ? pairs : fc::kLinGwPairs;
+    hipLaunchKernelGGL(fc::tangent_lin_gw_kernel, dim3(ng, (pairs + per_group - 1) / per_group), dim3(per_group * fc::kWave), 0, s,
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), part, N, I, O);
+    hipLaunchKernelGGL(fc::tangent_lin_gw_reduce_kernel, dim3((O * I + 63) / 64), dim3(256), 0, s, part, g_re, g_im, ng,
                        O * I);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
@@ -257,8 +355,9 @@ int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32
 }
 
 size_t fc_tangent_nonlin_backward_workspace_bytes(int32_t N, int32_t C) {
-    const int nblk = (N + fc::kNonlinRows - 1) / fc::kNonlinRows;
-    return (size_t)nblk * C * sizeof(float);
+    const int rows = fc::nonlin_rows_per_group(N);
+    const int ngroups = (N + rows - 1) / rows;
+    return (size_t)ngroups * C * sizeof(float);
 }
 
 int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
@@ -266,12 +365,14 @@ int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* g
     if (!x || !bias || !gy || !gx || !gbias || N <= 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < fc_tangent_nonlin_backward_workspace_bytes(N, C)) return FC_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nblk = (N + fc::kNonlinRows - 1) / fc::kNonlinRows;
+    const int rows = fc::nonlin_rows_per_group(N);
+    const int ngroups = (N + rows - 1) / rows;
+    const int L = C < fc::kNonlinThreads ? fc::kNonlinThreads / C : 1;
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(fc::tangent_nonlin_bwd_kernel, dim3(nblk), dim3(256), C * sizeof(float), s,
+    hipLaunchKernelGGL(fc::tangent_nonlin_bwd_kernel, dim3(ngroups), dim3(fc::kNonlinThreads), (size_t)L * C * sizeof(float), s,
                        reinterpret_cast<const float2*>(x), bias, reinterpret_cast<const float2*>(gy),
-                       reinterpret_cast<float2*>(gx), part, N, C);
-    hipLaunchKernelGGL(fc::tangent_nonlin_gb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, gbias, nblk, C);
+                       reinterpret_cast<float2*>(gx), part, N, C, rows);
+    hipLaunchKernelGGL(fc::tangent_nonlin_gb_reduce_kernel, dim3(C), dim3(64), 0, s, part, gbias, ngroups, C);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -84,6 +84,50 @@ def test_pointwise_golden(dev):
     assert np.array_equal(H(y)[org], c['x'][org])
 
 
+@pytest.mark.parametrize('N,I,O,offset', [(37, 5, 7, 0), (1000, 48, 48, 0), (333, 64, 33, 0), (20000, 48, 48, 0),
+                                          (130, 16, 16, 1), (5, 1, 3, 0), (4099, 24, 40, 0)])
+def test_pointwise_vs_oracle(N, I, O, offset, dev):
+    """Ragged sizes, channel counts off the 16-wide MFMA tile, and an input that starts 8 bytes off a
+    16-byte boundary (offset=1 -> scalar load path)."""
+    from fieldconv_amd.functional import tangent_lin, tangent_nonlin
+    rng = np.random.default_rng(N * 131 + I)
+    cplx = lambda *s: (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+    x, gy = cplx(N, I), cplx(N, O)
+    x[rng.random((N, I)) < 0.05] = 0          # origin-box entries
+    Re, Im = rng.standard_normal((O, I)).astype(np.float32), rng.standard_normal((O, I)).astype(np.float32)
+
+    def dev_c(a):      # optionally misaligned by one complex element
+        flat = torch.empty(a.size + offset, dtype=torch.cfloat, device=dev)
+        v = flat[offset:].view(a.shape)
+        v.copy_(torch.from_numpy(a))
+        return v
+    xt = dev_c(x).requires_grad_(True)
+    Ret, Imt = D(Re, dev).requires_grad_(True), D(Im, dev).requires_grad_(True)
+    y = tangent_lin(xt, Ret, Imt)
+    x64 = x.astype(np.complex128)
+    assert rel_err(H(y), orc.tangent_lin_forward(x64, Re, Im)) < TOL
+    gx, gRe, gIm = torch.autograd.grad(y, [xt, Ret, Imt], grad_outputs=dev_c(gy))
+    rgx, rgRe, rgIm = orc.tangent_lin_backward(x64, Re, Im, gy.astype(np.complex128))
+    assert rel_err(H(gx), rgx) < TOL
+    assert rel_err(H(gRe), rgRe) < TOL
+    assert rel_err(H(gIm), rgIm) < TOL
+
+    bias = (rng.standard_normal((1, I)) * 0.5).astype(np.float32)
+    bt = D(bias, dev).requires_grad_(True)
+    gyn = cplx(N, I)
+    yn = tangent_nonlin(xt, bt)
+    assert rel_err(H(yn), orc.tangent_nonlin_forward(x, bias)) < TOL
+    gxn, gb = torch.autograd.grad(yn, [xt, bt], grad_outputs=dev_c(gyn))
+    rgxn, rgb = orc.tangent_nonlin_backward(x64, bias, gyn.astype(np.complex128))
+    assert rel_err(H(gxn), rgxn) < TOL
+    assert rel_err(H(gb).reshape(-1), np.asarray(rgb).reshape(-1)) < TOL
+    # bitwise reproducible reductions
+    gxn2, gb2 = torch.autograd.grad(tangent_nonlin(xt, bt), [xt, bt], grad_outputs=dev_c(gyn))
+    assert torch.equal(gb, gb2)
+    _, gRe2, _ = torch.autograd.grad(tangent_lin(xt, Ret, Imt), [xt, Ret, Imt], grad_outputs=dev_c(gy))
+    assert torch.equal(gRe, gRe2)
+
+
 @pytest.mark.parametrize('tag', sorted(load_golden('blocks.npz')))
 def test_fc_resnet_block_golden(tag, dev):
     from fieldconv_amd.nn import FCResNetBlock
