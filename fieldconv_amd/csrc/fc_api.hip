@@ -1,6 +1,7 @@
 // extern "C" surface of libfieldconv_hip.so; see include/fieldconv_hip.h for the contract.
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
+#include "fc_tile.hpp"
 
 namespace fc {
 
@@ -43,12 +44,12 @@ int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0;
 
 size_t fc_packed_filter_floats_fwd(const fc_dims* d) {
     if (!fc::dims_valid(d)) return 0;
-    return (size_t)(2 * d->B + 1) * 2 * fc::round_up(d->O, 16) * fc::round_up(d->R * d->I, 16);
+    return fc::packed_image_floats(d->O, d->R * d->I, 2 * d->B + 1, fc::split_mode());
 }
 
 size_t fc_packed_filter_floats_bwd(const fc_dims* d) {
     if (!fc::dims_valid(d)) return 0;
-    return (size_t)(2 * d->B + 1) * 2 * fc::round_up(d->I, 16) * fc::round_up(d->R * d->O, 16);
+    return fc::packed_image_floats(d->I, d->R * d->O, 2 * d->B + 1, fc::split_mode());
 }
 
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream) {

@@ -1,0 +1,440 @@
+// FieldConv backward for gfx950 (the reference has no backward code: it relies on torch autograd
+// through nn/field_conv.py:128-137, i.e. the saved (E,C,R,F) product and index_select/scatter
+// twins).  Here the adjoint is evaluated source-centrically and never touches an edge-sized
+// temporary or an atomic:
+//
+//   H[j,o,r,f]  = sum_{e: src_e = j} gy[dst_e,o] conj(S[e,r,f])            (gather, CSR by source)
+//   gxt[j,i,f]  = 1/F sum_{o,r} H[j,o,r,f] conj(W[o,i,r,f])                (MFMA, K = R*O)
+//   gx[j,i]     = sum_f gxt_f conj(u_f) + [x != 0] (i x/|x|^2) sum_f m_f Im(conj(gxt_f) xt_f)
+//   gW[o,i,r,f] = 1/F sum_j    H[j,o,r,f] conj(xt[j,i,f])                  (MFMA, K = vertices)
+//
+// Two kernels.
+//  fc_backward_data_kernel is the forward kernel transposed: one wavefront per SOURCE vertex gathers
+//  H[j,:,:,:] (lane = output channel o, all frequencies, dense or factored stencil exactly as in
+//  fc_forward.hip), drops one LDS slab per frequency, the workgroup contracts it with the packed
+//  conjugated filter on MFMA, and every thread folds its (vertex, channel) entry of gxt_f into a
+//  running gx.  Each slab is also copied to HBM (`hdump`, 2*16*KS floats per tile and frequency).
+//  fc_backward_filter_kernel needs every tile's H for one frequency and 553 KB of accumulators in
+//  total -- more than a CU's register file -- so blockIdx.y = f: a persistent workgroup keeps
+//  gW[:,:,:,f] (KP x IP complex, spread over its wavefronts' MFMA accumulators) in registers,
+//  streams the dumped slabs of its frequency back with LDS-DMA (double-buffered, no gather at all)
+//  and writes one partial at the end; fc_backward_finish sums the partials in a fixed order.
+//  The 2 x 237 MB of slab traffic at config 2 replace a five-fold repetition of the gather.
+#pragma once
+#include <stdlib.h>
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+#include "fc_tile.hpp"
+
+namespace fc {
+
+
+constexpr int kMaxGwTiles = 8;   // 16x16 complex gW tiles a wavefront can own
+
+// (pointers are separate __restrict__ kernel parameters, see fc_forward.hip)
+struct BwdArgs {
+    int N, I, O;
+    MmaGeom g;           // M = I (rows of gxt), K = R*O in fp32 blocking: layout of the H slabs kept for the filter kernel
+    MmaGeom gd;          // the same contraction in the data kernel's MFMA mode (fp32 or split)
+    uint32_t wpk_bytes;  // size of the packed backward filter image
+    int ntiles;
+    int ngw;             // KST * NMT 16x16 gW tiles per frequency
+    int KD;              // row stride (floats) of the H slabs kept for the filter kernel: KP + 4, so that the
+                         // filter kernel's 4-byte A-fragment reads (rows 4 apart per lane group) hit distinct banks
+    int slab_floats;     // 2 * 16 * KD
+    int slab_stride;     // floats between consecutive (tile, f) slabs in hdump (multiple of 256)
+    int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
+};
+
+template <int R, int B>
+struct BwdShape {
+    static constexpr int F = 2 * B + 1;
+    static constexpr int NG = (F * R + 31) / 32;
+    static constexpr int MG = (F + NG - 1) / NG;
+};
+
+// ------------------------------------------------------------------------------------ data gradient
+template <int R, int B, bool FACTORED, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
+    const float2* __restrict__ gx_, const float2* __restrict__ ggy, const float* __restrict__ gsten,
+    const int32_t* __restrict__ growptr, const int32_t* __restrict__ gnbr, const float* __restrict__ gwpk,
+    float2* __restrict__ ggx, float* __restrict__ hdump, const BwdArgs a) {
+    constexpr int F = 2 * B + 1;
+    constexpr int NG = BwdShape<R, B>::NG;
+    constexpr int MG = BwdShape<R, B>::MG;
+    constexpr int ROWF = 2 * R * F;
+    constexpr int RECF = factored_record_floats(B);
+    constexpr int LOG_CR = factored_log_chunk_records(B);
+    constexpr int CR = 1 << LOG_CR;
+    constexpr int NR = kRingChunks;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MmaGeom& mg = a.gd;
+    const int KS = mg.KS, IP = mg.MP, I = a.I, O = a.O;
+    const int KP = a.g.KP;                                  // k entries per row of the kept H slabs (fp32 blocking)
+    float* const hre = reinterpret_cast<float*>(smem);     // fp32: [16][KS] floats (re), split: [4][16][KS] halves
+    float* const him = hre + kTile * KS;                    // fp32: [16][KS] floats (im)
+    float* const part = him + kTile * KS;                   // [NKP][16][IP][2]
+    float* const vscale = part + partial_floats(mg.NKP, IP);   // split: 2 buffers of [16] vertex scales + [16] inverses
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const ring = vscale + 4 * kTile + wave * NR * 256;   // factored: [NR][256] floats per wavefront
+    float* vs = vscale;                                          // scale buffer of the current frequency group
+
+    for (int idx = tid; idx < 2 * kTile * KS; idx += kThreads) hre[idx] = 0.f;
+    __syncthreads();
+
+    const int it = wave % mg.NMT;
+    const int kp = wave / mg.NMT;
+    const bool mma_active = kp < mg.NKP;
+    const int ol = lane < O ? lane : 0;       // lanes >= O gather channel 0 and are never stored
+    // gx epilogue: thread -> (vertex v, channel i) of the tile, fixed for the whole kernel
+    const int ev = tid / I, ei = tid - ev * I;
+    const bool e_active = tid < kTile * I;
+
+    auto dma_chunk = [&](const int first, const int ch) {
+        const float* src = gsten + ((size_t)first + ((size_t)ch << LOG_CR)) * RECF + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
+    };
+
+    int beg = 0, end = 0, ro[R];      // ro: ring-run offsets of my source (factored), see fc_forward.hip
+#pragma unroll
+    for (int q = 0; q < R; ++q) ro[q] = 0;
+    {
+        const int j0 = blockIdx.x * kTile + wave;
+        if (blockIdx.x < a.ntiles && j0 < a.N) {
+            beg = growptr[j0];
+            end = growptr[j0 + 1];
+            if (FACTORED) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) ro[q] = gnbr[(size_t)j0 * kRunStride + q];
+            }
+        }
+        if (FACTORED) {
+            const int nch = (end - beg + CR - 1) >> LOG_CR;
+            for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
+        }
+    }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
+#pragma unroll
+        for (int q = 0; q < R; ++q) nro[q] = 0;
+        {
+            const int jn = (tile + gridDim.x) * kTile + wave;
+            if (tile + gridDim.x < a.ntiles && jn < a.N) {
+                nbeg = growptr[jn];
+                nend = growptr[jn + 1];
+                if (FACTORED) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) nro[q] = gnbr[(size_t)jn * kRunStride + q];
+                }
+            }
+        }
+        const int nslots = end - beg;
+        const int nch = (nslots + CR - 1) >> LOG_CR;
+        // my (vertex, channel) entry of x for the gx epilogue: issued now, consumed after the first slab
+        const int ejn = tile * kTile + ev;
+        float2 exs = make_float2(0.f, 0.f);
+        if (e_active && ejn < a.N) exs = gx_[(size_t)ejn * I + ei];
+        float2 gxacc = make_float2(0.f, 0.f);
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            constexpr int MGc = MG;
+            const int f0 = g * MGc;
+            f32x2 h[R][MG];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff) h[r][ff] = f32x2{0.f, 0.f};
+
+            // ---------------------------------------------------------------- gather H for my source
+            if constexpr (FACTORED) {
+                if (g > 0) for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);   // walk the slots again
+                auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
+                float2 ga = make_float2(0.f, 0.f), gb = ga;
+                if (nslots > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+                    const int d0 = __float_as_int(rec_ptr(0)[3]);
+                    const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
+                    ga = ggy[(size_t)d0 * O + ol];
+                    gb = ggy[(size_t)d1 * O + ol];
+                }
+                // one slot with compile-time lower ring Q: z_f = g conj(ph_f); h[Q] += w0 z; h[Q+1] += w1 z
+                auto slot = [&](auto qc, const int s, float2& gcur) {
+                    constexpr int Q = decltype(qc)::value;
+                    if ((s & (CR - 1)) == 0 && s > 0) {
+                        const int ch = s >> LOG_CR;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                    }
+                    const float* rp = rec_ptr(s);
+                    const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+                    const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
+                    const f32x2 gv = f32x2{gcur.x, gcur.y}, gs = f32x2{gcur.y, -gcur.x};
+                    gcur = ggy[(size_t)d2 * O + ol];
+                    const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff) {
+                        const int f = f0 + ff;
+                        if (f < F) {
+                            const f32x2 ph = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
+                            f32x2 z = f32x2{ph.x, ph.x} * gv;
+                            z = __builtin_elementwise_fma(f32x2{ph.y, ph.y}, gs, z);
+                            h[Q][ff] = __builtin_elementwise_fma(w0v, z, h[Q][ff]);
+                            h[Q + 1][ff] = __builtin_elementwise_fma(w1v, z, h[Q + 1][ff]);
+                        }
+                    }
+                };
+                if (!(a.dbg & 1)) {
+                    static_for<0, R - 1>([&](auto qc) {
+                        constexpr int Q = decltype(qc)::value;
+                        int s = ro[Q];
+                        const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                        for (; s + 1 < run_end; s += 2) {
+                            slot(qc, s, ga);
+                            slot(qc, s + 1, gb);
+                        }
+                        if (s < run_end) {
+                            slot(qc, s, ga);
+                            const float2 t = ga; ga = gb; gb = t;
+                        }
+                    });
+                }
+                if (g + 1 == NG) {
+                    // my source is done: stream the first record chunks of my next tile's source
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
+                    for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
+                }
+            } else {
+                const int last = end - 1;
+                int nx = 0;
+                float2 ga = make_float2(0.f, 0.f), gb = ga;
+                if (beg < end) {
+                    const int d0 = gnbr[beg];
+                    const int d1 = gnbr[min(beg + 1, last)];
+                    nx = gnbr[min(beg + 2, last)];
+                    ga = ggy[(size_t)d0 * O + ol];
+                    gb = ggy[(size_t)d1 * O + ol];
+                }
+                auto slot = [&](const int e, float2& gcur) {
+                    const f32x2* __restrict__ Se = reinterpret_cast<const f32x2*>(gsten + (size_t)e * ROWF);   // wave-uniform
+                    const int n3 = gnbr[min(e + 3, last)];
+                    const f32x2 gv = f32x2{gcur.x, gcur.y}, gs = f32x2{gcur.y, -gcur.x};
+                    gcur = ggy[(size_t)nx * O + ol];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int ff = 0; ff < MG; ++ff)
+                            if (f0 + ff < F) cmac_gconjs(h[r][ff], Se[r * F + f0 + ff], gv, gs);
+                    nx = n3;
+                };
+                if (!(a.dbg & 1))
+                    for (int e = beg; e < end; e += 2) {
+                        slot(e, ga);
+                        if (e + 1 < end) slot(e + 1, gb);
+                    }
+            }
+
+            // ---------------------------------------------------------------- slabs -> gxt_f -> gx
+            float scale = 1.f;
+            if constexpr (SPLIT) {
+                // one power-of-two scale for this wavefront's vertex and frequency group (fc_tile.hpp, split mode)
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(h[r][ff].x), fabsf(h[r][ff].y)));
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+                float inv;
+                split_scale(mx, scale, inv);
+                if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv; }     // read after the slab barrier below
+            }
+#pragma unroll
+            for (int ff = 0; ff < MG; ++ff) {
+                const int f = f0 + ff;
+                if (f < F) {
+                    float* const dst = hdump + ((size_t)tile * F + f) * a.slab_stride;     // this slab, kept for the filter kernel
+                    if constexpr (!SPLIT) {
+                        if (lane < O) {
+                            int o0 = wave * KS + lane;       // running LDS offset (opaque: see fc_forward_kernels.hpp)
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                hre[o0] = h[r][ff].x;
+                                him[o0] = h[r][ff].y;
+                                o0 += O;
+                                asm volatile("" : "+v"(o0));
+                            }
+                        }
+                        __syncthreads();
+                        {   // 16 B per thread, rows re-strided to KD
+                            const int k4n = KP / 4;
+                            for (int idx = tid; idx < 2 * kTile * k4n; idx += kThreads) {
+                                const int row = idx / k4n, k4 = idx - row * k4n;          // row = plane * 16 + vertex
+                                *reinterpret_cast<float4*>(dst + row * a.KD + 4 * k4) = *reinterpret_cast<const float4*>(hre + row * KS + 4 * k4);
+                            }
+                        }
+                    } else {
+                        if (lane < O) {
+                            lds_f16* const sp = (lds_f16*)hre;
+                            const int splane = kTile * KS;
+                            const f32x2 sv = {scale, scale};
+                            int o0 = wave * KS + lane;       // LDS (halves)
+                            int d0 = wave * a.KD + lane;     // kept slab (floats): re plane, im plane 16 rows further
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                dst[d0] = h[r][ff].x;
+                                dst[d0 + kTile * a.KD] = h[r][ff].y;
+                                const f32x2 v = h[r][ff] * sv;
+                                _Float16 rh, rl, ih, il;
+                                split_halves(v.x, rh, rl);
+                                split_halves(v.y, ih, il);
+                                sp[o0] = rh;
+                                sp[o0 + splane] = rl;
+                                sp[o0 + 2 * splane] = ih;
+                                sp[o0 + 3 * splane] = il;
+                                o0 += O;
+                                d0 += O;
+                                asm volatile("" : "+v"(o0), "+v"(d0));
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    if (mma_active) {
+                        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
+                        if (!(a.dbg & 2)) {
+                            const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
+                            if constexpr (SPLIT)
+                                mma_slab_split(wimg, IP * 4 + f * (4 * IP * mg.KP * 2), (const lds_f16*)hre, mg, it, kp, lane, acc_re, acc_im);
+                            else
+                                mma_slab(wimg, f * (2 * IP * mg.KP * 4), hre, him, mg, it, kp, lane, acc_re, acc_im);
+                        }
+                        store_partial(part, mg, it, kp, lane, acc_re, acc_im);
+                    }
+                    __syncthreads();
+                    if (e_active) {
+                        const int m = f - B;
+                        float2 z = sum_partials(part, mg, ev, ei);
+                        if constexpr (SPLIT) {      // undo the vertex scale and the filter-row scale (powers of two)
+                            const float k = vs[kTile + ev] * gwpk[ei];
+                            z.x *= k;
+                            z.y *= k;
+                        }
+                        const float2 c = unit_power(unit_conj(exs), m);
+                        const float2 xtv = cmul(exs, c);
+                        float2 out = cmul_conj(z, c);
+                        if (m != 0 && !is_origin(exs)) {
+                            const float n2 = exs.x * exs.x + exs.y * exs.y;
+                            const float q = (float)m * (z.x * xtv.y - z.y * xtv.x) / n2;
+                            out.x += -exs.y * q;
+                            out.y += exs.x * q;
+                        }
+                        gxacc.x += out.x;
+                        gxacc.y += out.y;
+                    }
+                    // (`part` is next written after the following slab's first barrier)
+                }
+            }
+            if constexpr (SPLIT) vs = (vs == vscale) ? vscale + 2 * kTile : vscale;   // the next group writes the other buffer
+        }
+        if (e_active && ejn < a.N) ggx[(size_t)ejn * I + ei] = gxacc;
+        beg = nbeg;
+        end = nend;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ro[q] = nro[q];
+    }
+}
+
+struct BwdPlan {
+    MmaGeom g, gd;
+    int IP, KP, KD, ntiles, ngw, P, F, slab_floats, slab_stride;
+    size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes;
+    bool ok, ok_factored;
+};
+
+inline BwdPlan plan_backward(const fc_dims* d, bool split) {
+    BwdPlan p;
+    p.F = 2 * d->B + 1;
+    p.g = make_mma_geom(d->I, d->R * d->O);
+    p.gd = make_mma_geom(d->I, d->R * d->O, split);
+    p.IP = p.g.MP;
+    p.KP = p.g.KP;
+    p.ntiles = (d->N + kTile - 1) / kTile;
+    p.ngw = p.g.KST * p.g.NMT;
+    int P = kNumCUs / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
+    if (P < 1) P = 1;
+    if (P > p.ntiles) P = p.ntiles;
+    p.P = P;
+    p.KD = p.g.KP + 4;
+    p.slab_floats = 2 * kTile * p.KD;
+    p.slab_stride = round_up(p.slab_floats, 256);
+    p.lds_data = (size_t)(2 * kTile * p.gd.KS + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
+    p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
+    p.lds_filter = (size_t)(2 * p.slab_stride + 2 * p.IP * kTile) * sizeof(float);
+    p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
+    p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
+    p.ok = p.lds_data <= kMaxLds && p.lds_filter <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves &&
+           kTile * d->I <= kThreads;
+    p.ok_factored = p.ok && p.lds_data_factored <= kMaxLds;
+    return p;
+}
+
+inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
+    BwdArgs a;
+    a.N = d->N; a.I = d->I; a.O = d->O;
+    a.g = p.g;
+    a.gd = p.gd;
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R * d->O, p.F, p.gd.split != 0) * sizeof(float));
+    a.ntiles = p.ntiles;
+    a.ngw = p.ngw;
+    a.KD = p.KD;
+    a.slab_floats = p.slab_floats;
+    a.slab_stride = p.slab_stride;
+    { const char* e = getenv("FC_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
+    return a;
+}
+
+template <int R, int B, bool FACTORED, bool SPLIT>
+static int launch_backward_data(const float2* x, const float2* gy, const float* sten, const fc_csr* g, const float* wpk,
+                                float2* gx, float* hdump, const BwdArgs& a, const BwdPlan& p, hipStream_t stream) {
+    auto kern = fc_backward_data_kernel<R, B, FACTORED, SPLIT>;
+    const size_t lds = FACTORED ? p.lds_data_factored : p.lds_data;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return FC_ERR_LAUNCH;
+    }
+    const int grid = FACTORED ? (p.ntiles < kNumCUs ? p.ntiles : kNumCUs) : p.ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, gx,
+                       hdump, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+template <bool SPLIT>
+int backward_data_impl_mode(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
+                            void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
+    const BwdPlan p = plan_backward(d, SPLIT);
+    if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
+    const BwdArgs a = make_args(d, p);
+    float* hdump = reinterpret_cast<float*>(ws);
+#define FC_CASE(RR, BB)                                                                                                \
+    if (d->R == RR && d->B == BB)                                                                                      \
+        return factored ? launch_backward_data<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x),                       \
+                                                             reinterpret_cast<const float2*>(gy), sten, g, wpk,        \
+                                                             reinterpret_cast<float2*>(gx), hdump, a, p, stream)       \
+                        : launch_backward_data<RR, BB, false, SPLIT>(reinterpret_cast<const float2*>(x),                      \
+                                                              reinterpret_cast<const float2*>(gy), sten, g, wpk,       \
+                                                              reinterpret_cast<float2*>(gx), hdump, a, p, stream);
+    FC_FOR_EACH_SHAPE(FC_CASE)
+#undef FC_CASE
+    return FC_ERR_UNSUPPORTED;
+}
+
+
+}  // namespace fc

@@ -81,9 +81,8 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {   // a * conj(
 }
 
 // All 2B+1 rotated copies xt[f] = z * u^(f-B) (reference nn/field_conv.py:128-130).
-// Slot B+1 (m = +1) is z*u = |z|, real up to rounding: it is stored as (|z|, *) and consumed by
-// cmac_sx_real (inside the origin box u = 1 and the copy is z itself, whose imaginary part, below
-// 1e-7 in magnitude, is dropped there).
+// Slot B+1 (m = +1) is z*u = |z|, stored as (|z|, 0); inside the origin box u = 1 and every copy is z
+// itself.  Valid for |z|^2 within the fp32 range (|z| < 1.8e19).
 template <int B>
 __device__ __forceinline__ void rotate_all(float2 z, float2 (&xt)[2 * B + 1]) {
     const bool org = is_origin(z);
@@ -115,10 +114,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cmac_sx(f32x2& acc, f32x2 s, f32x2 x, f32x2 xs) {
     acc = __builtin_elementwise_fma(f32x2{s.x, s.x}, x, acc);
     acc = __builtin_elementwise_fma(f32x2{s.y, s.y}, xs, acc);
-}
-// acc += s * a for a REAL per-lane a (the m = +1 slot, x*u = |x|): one instruction.
-__device__ __forceinline__ void cmac_sx_real(f32x2& acc, f32x2 s, float a) {
-    acc = __builtin_elementwise_fma(s, f32x2{a, a}, acc);
 }
 // acc += g * conj(s) = (s.re, s.re)*(g.re, g.im) + (s.im, s.im)*(g.im, -g.re); gs = (g.im, -g.re)
 __device__ __forceinline__ void cmac_gconjs(f32x2& acc, f32x2 s, f32x2 g, f32x2 gs) {

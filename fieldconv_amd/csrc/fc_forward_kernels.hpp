@@ -1,0 +1,475 @@
+// FieldConv forward for gfx950: gather -> rotate -> stencil-multiply -> segmented reduce ->
+// filter contraction, fused in one kernel (replaces reference nn/field_conv.py:128-137).
+//
+// A 16-wavefront workgroup owns a tile of 16 target vertices, one wavefront per target.
+//
+//  Phase A (VALU).  Lane c of the wavefront owns input channel c.  The wavefront walks the
+//    target's in-edges (CSR by target: no atomics, fixed summation order).  The source row
+//    x[src,:] is one coalesced 8-byte-per-lane load, prefetched two slots ahead; the response
+//    contrib[c, r, f] (R*F complex per lane) is accumulated in registers with packed fp32 FMAs.
+//    Two variants differ in how the wave-uniform stencil of a slot reaches the FMAs:
+//      dense     the R*F complex entries come through the scalar cache as SGPR pairs
+//                (any stencil; 8*R*F bytes per edge)
+//      factored  the stencil is rank-1 and 2-sparse in the ring index, S[r,f] = w_r * ph_f with
+//                w_q, w_{q+1} the only non-zeros -- which is what FCPrecomp produces (reference
+//                transforms/fc_precomp.py:24-25,95).  One small record (q, w_q, w_{q+1}, ph_f) per
+//                edge is DMA'd (global_load_lds) into a per-wavefront LDS ring ahead of use and
+//                broadcast-read: about 4F packed FMAs per edge instead of 2*R*F, 64 B instead of 240 B.
+//  Phase B (MFMA).  For each angular frequency f the wavefronts drop their contrib[:, :, f]
+//    slab into LDS ([vertex][k = r*I + c], re and im planes) and the workgroup multiplies it by
+//    the packed filter on v_mfma_f32_16x16x4_f32 (fc_tile.hpp): out^T[o, vertex] += W[o,k] slab[vertex,k].
+//    Wavefront w takes output tile (w % NOT) and every NKP-th 16-wide k block; k-partials are
+//    combined through LDS in a fixed order (bitwise reproducible).
+#pragma once
+#include <stdlib.h>
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+#include "fc_tile.hpp"
+
+namespace fc {
+
+// Pointers travel as separate __restrict__ kernel parameters (not inside this struct) so that the
+// compiler may treat the index and stencil streams as read-only and fetch the wave-uniform ones
+// through the scalar cache (s_load) instead of per-lane vector loads.
+struct FwdArgs {
+    int N, I, O;
+    MmaGeom g;          // M = O, K = R*I
+    int ntiles;
+    int ring_chunks;    // factored: 1 KiB chunks per wavefront in the LDS record ring
+    uint32_t wpk_bytes; // size of the packed filter image
+    int dbg;            // development only (FC_DEBUG env): bit0 skip gather loop, bit1 skip MFMA loop
+};
+
+// Frequencies are processed in NG groups of at most MG so that the per-lane response
+// (R*MG complex numbers) stays within the 128-VGPR budget of a 16-wavefront workgroup.
+template <int R, int B>
+struct FwdShape {
+    static constexpr int F = 2 * B + 1;
+    static constexpr int NG = (F * R + 31) / 32;
+    static constexpr int MG = (F + NG - 1) / NG;
+};
+
+// LDS carve-up shared by both kernels: slab (128*KS bytes in either mode), k-partials, per-vertex scales.
+struct FwdLds {
+    float* slab;     // fp32: [2][16][KS] floats; split: [4][16][KS] halves
+    float* part;     // [NKP][MP][kPartStride]
+    float* vscale;   // split: two buffers (tile parity) of [16] vertex slab scales + [16] inverses
+    float* end;
+};
+__device__ __forceinline__ FwdLds forward_lds(char* smem, const MmaGeom& g) {
+    FwdLds l;
+    l.slab = reinterpret_cast<float*>(smem);
+    l.part = l.slab + 2 * kTile * g.KS;
+    l.vscale = l.part + partial_floats(g.NKP, g.MP);
+    l.end = l.vscale + 4 * kTile;
+    return l;
+}
+__host__ inline size_t forward_lds_floats(const MmaGeom& g) { return (size_t)2 * kTile * g.KS + partial_floats(g.NKP, g.MP) + 4 * kTile; }
+
+// Phase B for one frequency group: slabs -> MFMA accumulate.  c[r][ff] holds this lane's response.
+// first_group: no earlier group has contributed to acc in this tile.  vs: this tile's scale buffer
+// (alternates between consecutive tiles of the workgroup, so a wavefront that runs ahead into the
+// next tile never overwrites scales the epilogue of the previous one still reads).
+template <int R, int B, int MG, bool MULTI_GROUP, bool SPLIT>
+__device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0, const FwdLds& l, float* vs,
+                                                const float* __restrict__ gwpk, const FwdArgs& a, int wave, int lane,
+                                                bool first_group, f32x4& acc_re, f32x4& acc_im) {
+    constexpr int F = 2 * B + 1;
+    const MmaGeom& g = a.g;
+    const int mt = wave % g.NMT, kp = wave / g.NMT;
+    const bool mma_active = kp < g.NKP;
+    if constexpr (!SPLIT) {
+        float* const cre = l.slab;
+        float* const cim = l.slab + kTile * g.KS;
+        const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
+#pragma unroll
+        for (int ff = 0; ff < MG; ++ff) {
+            const int f = f0 + ff;
+            if (f < F) {
+                if (lane < a.I) {
+                    int o0 = wave * g.KS + lane;       // running LDS offset, see the split branch
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        cre[o0] = c[r][ff].x;
+                        cim[o0] = c[r][ff].y;
+                        o0 += a.I;
+                        asm volatile("" : "+v"(o0));
+                    }
+                }
+                __syncthreads();
+                if (mma_active && !(a.dbg & 2))
+                    mma_slab(wimg, f * (2 * g.MP * g.KP * 4), cre, cim, g, mt, kp, lane, acc_re, acc_im);
+                __syncthreads();
+            }
+        }
+    } else {
+    // ---- split mode: this wavefront's vertex gets one power-of-two scale for the whole group
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int ff = 0; ff < MG; ++ff)
+            if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(c[r][ff].x), fabsf(c[r][ff].y)));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float scale, inv;
+    split_scale(mx, scale, inv);
+    if (MULTI_GROUP && !first_group) {
+        // the accumulators are in units of the previous group's scales: bring them to this group's
+        const float old_inv = vs[kTile + (lane & 15)];
+        __syncthreads();
+        if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv; }
+        __syncthreads();
+        const float ratio = old_inv * vs[lane & 15];
+        acc_re *= ratio;
+        acc_im *= ratio;
+    } else if (lane == 0) {
+        vs[wave] = scale;          // read after the slab barriers below
+        vs[kTile + wave] = inv;
+    }
+    lds_f16* const sp = (lds_f16*)l.slab;
+    const int splane = kTile * g.KS;
+    const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
+    const int planes0 = g.MP * 4;                                  // bytes: the planes follow the MP row scales
+    const f32x2 sv = {scale, scale};
+#pragma unroll
+    for (int ff = 0; ff < MG; ++ff) {
+        const int f = f0 + ff;
+        if (f < F) {
+            if (lane < a.I) {
+                // one running LDS offset, advanced by I per ring; the empty asm keeps hipcc from materialising
+                // all 4*R addresses in registers for the whole kernel (they would spill)
+                int o0 = wave * g.KS + lane;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const f32x2 v = c[r][ff] * sv;
+                    _Float16 rh, rl, ih, il;
+                    split_halves(v.x, rh, rl);
+                    split_halves(v.y, ih, il);
+                    sp[o0] = rh;
+                    sp[o0 + splane] = rl;
+                    sp[o0 + 2 * splane] = ih;
+                    sp[o0 + 3 * splane] = il;
+                    o0 += a.I;
+                    asm volatile("" : "+v"(o0));
+                }
+            }
+            __syncthreads();
+            if (mma_active && !(a.dbg & 2))
+                mma_slab_split(wimg, planes0 + f * (4 * g.MP * g.KP * 2), sp, g, mt, kp, lane, acc_re, acc_im);
+            __syncthreads();
+        }
+    }
+    }
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void forward_epilogue(const FwdLds& l, const float* vs, const float* __restrict__ gwpk, const FwdArgs& a, int tile,
+                                                 int wave, int lane, const f32x4& acc_re, const f32x4& acc_im,
+                                                 float2* __restrict__ gy_) {
+    const MmaGeom& g = a.g;
+    const int mt = wave % g.NMT, kp = wave / g.NMT;
+    if (kp < g.NKP) store_partial(l.part, g, mt, kp, lane, acc_re, acc_im);
+    __syncthreads();
+    for (int idx = wave * kWave + lane; idx < kTile * a.O; idx += kThreads) {
+        const int v = idx / a.O, o = idx - v * a.O;
+        const int n = tile * kTile + v;
+        float2 s = sum_partials(l.part, g, v, o);
+        if constexpr (SPLIT) {      // undo the slab scale of vertex v and the filter scale of row o (both powers of two)
+            const float k = vs[kTile + v] * gwpk[o];
+            s.x *= k;
+            s.y *= k;
+        }
+        if (n < a.N) gy_[(size_t)n * a.O + o] = s;
+    }
+    // `part` is rewritten only after the next tile's slab barriers; the next tile uses the other scale buffer
+}
+
+// ------------------------------------------------------------------------------------------ dense
+template <int R, int B, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void fc_forward_kernel(
+    const float2* __restrict__ gx_, const float* __restrict__ gsten, const int32_t* __restrict__ growptr,
+    const int32_t* __restrict__ gnbr, const float* __restrict__ gwpk,
+    float2* __restrict__ gy_, const FwdArgs a) {
+    constexpr int F = 2 * B + 1;
+    constexpr int NG = FwdShape<R, B>::NG;
+    constexpr int MG = FwdShape<R, B>::MG;
+    constexpr int ROWF = 2 * R * F;                              // floats per stencil row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FwdLds l = forward_lds(smem, a.g);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int I = a.I;
+
+    // zero the slab once: the k padding [R*I, KP) is never written again and must not hold NaNs
+    for (int idx = tid; idx < 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    __syncthreads();
+
+    const int cl = lane < I ? lane : 0;      // lanes >= I gather channel 0 and are never stored
+
+    float* vs = l.vscale;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int t = tile * kTile + wave;
+        int beg = 0, end = 0;
+        if (t < a.N) { beg = growptr[t]; end = growptr[t + 1]; }
+        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            constexpr int MGc = MG;
+            const int f0 = g * MGc;
+            f32x2 c[R][MG];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff) c[r][ff] = f32x2{0.f, 0.f};
+
+            const int last = end - 1;
+            int nx = 0;                                       // source of the slot two ahead (wave-uniform)
+            float2 xa = make_float2(0.f, 0.f), xb = xa;       // x rows of the even / odd slot in flight
+            if (beg < end) {
+                const int n0 = gnbr[beg];
+                const int n1 = gnbr[min(beg + 1, last)];
+                nx = gnbr[min(beg + 2, last)];
+                xa = gx_[(size_t)n0 * I + cl];
+                xb = gx_[(size_t)n1 * I + cl];
+            }
+            // one slot: `xcur` holds its source row on entry and the row of slot e+2 on exit
+            auto slot = [&](const int e, float2& xcur) {
+                const f32x2* __restrict__ Se = reinterpret_cast<const f32x2*>(gsten + (size_t)e * ROWF);   // uniform
+                const int n3 = gnbr[min(e + 3, last)];
+                float2 xt[F];
+                rotate_all<B>(xcur, xt);
+                xcur = gx_[(size_t)nx * I + cl];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff) {
+                        const int f = f0 + ff;
+                        if (f < F) {
+                            cmac_sx(c[r][ff], Se[r * F + f], f32x2{xt[f].x, xt[f].y}, f32x2{-xt[f].y, xt[f].x});
+                        }
+                    }
+                nx = n3;
+            };
+            if (!(a.dbg & 1))
+                for (int e = beg; e < end; e += 2) {
+                    slot(e, xa);
+                    if (e + 1 < end) slot(e + 1, xb);
+                }
+            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
+        }
+        forward_epilogue<SPLIT>(l, vs, gwpk, a, tile, wave, lane, acc_re, acc_im, gy_);
+        vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
+    }
+}
+
+// --------------------------------------------------------------------------------------- factored
+// Record of one edge, RECF = ceil4(4 + 2F) floats: [0] lower ring q (int bits), [1] w_q, [2] w_{q+1},
+// [3] source vertex (int bits), [4 + 2f], [5 + 2f] = ph_f.  Records are stored in target-slot order; a wavefront streams the
+// records of its target in chunks of CR = 256 / RECF (one 1 KiB global_load_lds per chunk) through
+// a private LDS ring of NR chunks.
+template <int R, int B, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
+    const float2* __restrict__ gx_, const float* __restrict__ grec, const int32_t* __restrict__ growptr,
+    const int32_t* __restrict__ gruns, const float* __restrict__ gwpk,
+    float2* __restrict__ gy_, const FwdArgs a) {
+    constexpr int F = 2 * B + 1;
+    constexpr int NG = FwdShape<R, B>::NG;
+    constexpr int MG = FwdShape<R, B>::MG;
+    constexpr int RECF = factored_record_floats(B);
+    constexpr int LOG_CR = factored_log_chunk_records(B);        // records per chunk: a power of two, CR*RECF*4 <= 1 KiB
+    constexpr int CR = 1 << LOG_CR;
+    constexpr int NR = kRingChunks;                              // ring slots per wavefront (power of two)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FwdLds l = forward_lds(smem, a.g);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const ring = l.end + wave * NR * 256;                 // [NR][256] floats, this wavefront's
+    const int I = a.I;
+
+    for (int idx = tid; idx < 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    __syncthreads();
+
+    const int cl = lane < I ? lane : 0;
+
+    // chunk ch of the record run that starts at slot `first` -> ring slot ch % NR (1 KiB, asynchronous)
+    auto dma_chunk = [&](const int first, const int ch) {
+        const float* src = grec + ((size_t)first + (size_t)ch * CR) * RECF + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
+    };
+
+    // ro[q] = first slot (relative to beg) whose ring index is >= q: the slots of ring q are [ro[q], ro[q+1])
+    int beg = 0, end = 0, ro[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) ro[q] = 0;
+    {
+        const int t0 = blockIdx.x * kTile + wave;
+        if (blockIdx.x < a.ntiles && t0 < a.N) {
+            beg = growptr[t0];
+            end = growptr[t0 + 1];
+#pragma unroll
+            for (int q = 0; q < R; ++q) ro[q] = gruns[(size_t)t0 * kRunStride + q];
+        }
+        const int nch = (end - beg + CR - 1) >> LOG_CR;
+        for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
+    }
+
+    float* vs = l.vscale;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int nch = (end - beg + CR - 1) >> LOG_CR;
+        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
+
+        // next tile's slot range for this wavefront (its first chunks are DMA'd during phase B)
+        int nbeg = 0, nend = 0, nro[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) nro[q] = 0;
+        {
+            const int tn = (tile + gridDim.x) * kTile + wave;
+            if (tile + gridDim.x < a.ntiles && tn < a.N) {
+                nbeg = growptr[tn];
+                nend = growptr[tn + 1];
+#pragma unroll
+                for (int q = 0; q < R; ++q) nro[q] = gruns[(size_t)tn * kRunStride + q];
+            }
+        }
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            constexpr int MGc = MG;
+            const int f0 = g * MGc;
+            f32x2 c[R][MG];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff) c[r][ff] = f32x2{0.f, 0.f};
+
+            if (g > 0) {   // later frequency groups walk the same slots again: restart the ring
+                for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
+            }
+            const int nslots = end - beg;
+            // record s of this target (s relative to beg) lives at ring[((s >> LOG_CR) & (NR-1)) * 256 + (s & (CR-1)) * RECF]
+            auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
+            float2 xa = make_float2(0.f, 0.f), xb = xa;
+            if (nslots > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+                const int n0 = __float_as_int(rec_ptr(0)[3]);
+                const int n1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
+                xa = gx_[(size_t)n0 * I + cl];
+                xb = gx_[(size_t)n1 * I + cl];
+            }
+            // One slot whose lower ring is the compile-time constant Q: contrib[Q] += w0 z, contrib[Q+1] += w1 z
+            // with z_f = ph_f * xt_f.  `xcur` holds the slot's source row on entry and the row of slot s+2 on
+            // exit.  No scalar memory loads in here (they share lgkmcnt with the LDS reads and return out of
+            // order) and only shifts/masks in the address arithmetic: the CU's single scalar ALU serves all
+            // 16 wavefronts.
+            auto slot = [&](auto qc, const int s, float2& xcur) {
+                constexpr int Q = decltype(qc)::value;
+                if ((s & (CR - 1)) == 0 && s > 0) {
+                    // entering a chunk: its DMA (and every older one) must have landed; the ring slot that
+                    // just became free is refilled NR - 1 chunks ahead
+                    const int ch = s >> LOG_CR;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                }
+                const float* rp = rec_ptr(s);                                     // wave-uniform -> broadcast reads
+                const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+                const float w0 = head.y, w1 = head.z;
+                const int n2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);   // source two slots ahead
+                float2 xt[F];
+                rotate_all<B>(xcur, xt);
+                xcur = gx_[(size_t)n2 * I + cl];
+                const f32x2 w0v = f32x2{w0, w0}, w1v = f32x2{w1, w1};
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff) {
+                    const int f = f0 + ff;
+                    if (f < F) {
+                        const f32x2 ph = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
+                        f32x2 z = f32x2{ph.x, ph.x} * f32x2{xt[f].x, xt[f].y};
+                        z = __builtin_elementwise_fma(f32x2{ph.y, ph.y}, f32x2{-xt[f].y, xt[f].x}, z);
+                        c[Q][ff] = __builtin_elementwise_fma(w0v, z, c[Q][ff]);
+                        c[Q + 1][ff] = __builtin_elementwise_fma(w1v, z, c[Q + 1][ff]);
+                    }
+                }
+            };
+            // The records of a target are sorted by ring index, so the walk is R-1 consecutive runs, each
+            // with statically indexed accumulators (no data-dependent register indexing, no switch).
+            if (!(a.dbg & 1)) {
+                static_for<0, R - 1>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    int s = ro[Q];
+                    const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                    for (; s + 1 < run_end; s += 2) {
+                        slot(qc, s, xa);
+                        slot(qc, s + 1, xb);
+                    }
+                    if (s < run_end) {      // odd tail of the run: rotate the two prefetch registers
+                        slot(qc, s, xa);
+                        const float2 t = xa; xa = xb; xb = t;
+                    }
+                });
+            }
+            if (g + 1 == NG) {
+                // this target is done: start streaming the next tile's first chunks; they land while
+                // the MFMAs below run
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
+                for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
+            }
+            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
+        }
+        forward_epilogue<SPLIT>(l, vs, gwpk, a, tile, wave, lane, acc_re, acc_im, gy_);
+        vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
+        beg = nbeg;
+        end = nend;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ro[q] = nro[q];
+    }
+}
+
+template <int R, int B, bool FACTORED, bool SPLIT>
+static int launch_forward(const float2* x, const float* sten, const fc_csr* g, const float* wpk, float2* y,
+                          const FwdArgs& a, size_t lds_bytes, int grid, hipStream_t stream) {
+    auto kern = FACTORED ? fc_forward_factored_kernel<R, B, SPLIT> : fc_forward_kernel<R, B, SPLIT>;
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return FC_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, y, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+template <bool SPLIT>
+int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
+                      const fc_dims* d, bool factored, hipStream_t stream) {
+    FwdArgs a;
+    a.N = d->N; a.I = d->I; a.O = d->O;
+    a.g = make_mma_geom(d->O, d->R * d->I, SPLIT);
+    a.ntiles = (d->N + kTile - 1) / kTile;
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R * d->I, 2 * d->B + 1, SPLIT) * sizeof(float));
+    { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    size_t lds = forward_lds_floats(a.g) * sizeof(float);
+    a.ring_chunks = 0;
+    if (factored) {
+        a.ring_chunks = kRingChunks;
+        lds += (size_t)kWaves * kRingChunks * 1024;
+    }
+    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
+    // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
+    const int grid = factored ? (a.ntiles < kNumCUs ? a.ntiles : kNumCUs) : a.ntiles;
+#define FC_CASE(RR, BB)                                                                                              \
+    if (d->R == RR && d->B == BB)                                                                                    \
+        return factored ? launch_forward<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x), sten, g, wpk,             \
+                                                       reinterpret_cast<float2*>(y), a, lds, grid, stream)           \
+                        : launch_forward<RR, BB, false, SPLIT>(reinterpret_cast<const float2*>(x), sten, g, wpk,            \
+                                                        reinterpret_cast<float2*>(y), a, lds, grid, stream);
+    FC_FOR_EACH_SHAPE(FC_CASE)
+#undef FC_CASE
+    return FC_ERR_UNSUPPORTED;
+}
+
+}  // namespace fc

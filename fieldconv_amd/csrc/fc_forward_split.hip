@@ -1,0 +1,9 @@
+// FieldConv forward, split-half MFMA instantiation (kernels: fc_forward_kernels.hpp).
+#include "fc_forward_kernels.hpp"
+
+namespace fc {
+
+template int forward_impl_mode<true>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, bool,
+                                     hipStream_t);
+
+}  // namespace fc

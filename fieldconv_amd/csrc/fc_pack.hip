@@ -5,8 +5,10 @@
 //   fc_pack_filter_params   assembles W_eff from the parameters on the fly (one kernel instead of the
 //                           cat / flip / conj / polar / mul chain in torch) and packs it
 //   fc_filter_param_grads   pulls dL/dW_eff back to (zonal, spherical, phase) -- the autograd twin
+#include <stdlib.h>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
+#include "fc_tile.hpp"
 
 namespace fc {
 
@@ -37,78 +39,131 @@ __device__ __forceinline__ float2 filter_entry(const float* __restrict__ zonal, 
     return c;
 }
 
-// fwd image: [F][2][OP][KPf], k = r*I + i, value W/F.   bwd image: [F][2][IP][KPb], k = r*O + o, conj(W)/F.
+// Packed images (layouts: fc_tile.hpp packed_image_floats):
+//   fwd image: rows m = o, k = r*I + i, value W/F          bwd image: rows m = i, k = r*O + o, value conj(W)/F
+// An fp32 image is written one element per thread; a split image one row per workgroup (the row's power-of-two
+// scale needs the row maximum first).
+struct PackArgs {
+    int O, I, R, F, B, ftype;
+    MmaGeom gf, gb;          // forward / backward contraction geometry (with their modes)
+    unsigned blocks_f;       // workgroups that write the forward image; the rest write the backward image
+};
+
+constexpr int kPackThreads = 256;
+constexpr int kPackRowValues = 16;       // (f, k) entries per thread of a split row: F * KP <= 16 * 256
+
 template <bool FROM_PARAMS>
-__global__ void fc_pack_filter_kernel(const float2* __restrict__ w, const float* __restrict__ zonal,
-                                      const float* __restrict__ sph, const float* __restrict__ phase, int ftype, int B,
-                                      float* __restrict__ fwd, float* __restrict__ bwd, int O, int I, int R, int F, int OP,
-                                      int KPf, int IP, int KPb) {
-    const size_t nf = (size_t)F * 2 * OP * KPf;
-    const size_t nb = (size_t)F * 2 * IP * KPb;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const float sc = 1.f / (float)F;
-    int o, i, r, f, pl;
-    bool valid, is_bwd;
-    size_t j;
-    if (idx < nf) {
-        is_bwd = false;
-        j = idx;
-        const int k = j % KPf;
-        o = (j / KPf) % OP;
-        pl = (j / ((size_t)KPf * OP)) % 2;
-        f = j / ((size_t)KPf * OP * 2);
-        r = k / I;
-        i = k - r * I;
-        valid = o < O && k < R * I;
-    } else if (idx < nf + nb) {
-        is_bwd = true;
-        j = idx - nf;
-        const int k = j % KPb;
-        i = (j / KPb) % IP;
-        pl = (j / ((size_t)KPb * IP)) % 2;
-        f = j / ((size_t)KPb * IP * 2);
-        r = k / O;
-        o = k - r * O;
-        valid = i < I && k < R * O;
-    } else {
-        return;
-    }
-    float v = 0.f;
-    if (valid) {
-        const float2 c = FROM_PARAMS ? filter_entry(zonal, sph, phase, ftype, B, R, I, o, i, r, f)
-                                     : w[(((size_t)o * I + i) * R + r) * F + f];
-        v = (pl == 0 ? c.x : (is_bwd ? -c.y : c.y)) * sc;
-    }
-    (is_bwd ? bwd : fwd)[j] = v;
+__device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, const float* __restrict__ zonal,
+                                               const float* __restrict__ sph, const float* __restrict__ phase,
+                                               const PackArgs& a, bool is_bwd, int m, int k, int f) {
+    const int inner = is_bwd ? a.O : a.I;
+    const int r = k / inner, c = k - r * inner;
+    const int o = is_bwd ? c : m, i = is_bwd ? m : c;
+    if (o >= a.O || i >= a.I || r >= a.R) return make_float2(0.f, 0.f);
+    const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, a.ftype, a.B, a.R, a.I, o, i, r, f)
+                                 : w[(((size_t)o * a.I + i) * a.R + r) * a.F + f];
+    const float sc = 1.f / (float)a.F;
+    return make_float2(v.x * sc, (is_bwd ? -v.y : v.y) * sc);
 }
 
-static void pack_geometry(const fc_dims* d, int& F, int& OP, int& KPf, int& IP, int& KPb, size_t& total) {
-    F = 2 * d->B + 1;
-    OP = round_up(d->O, 16);
-    KPf = round_up(d->R * d->I, 16);
-    IP = round_up(d->I, 16);
-    KPb = round_up(d->R * d->O, 16);
-    total = (size_t)F * 2 * OP * KPf + (size_t)F * 2 * IP * KPb;
+template <bool FROM_PARAMS>
+__global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const float2* __restrict__ w, const float* __restrict__ zonal,
+                                                                      const float* __restrict__ sph,
+                                                                      const float* __restrict__ phase, float* __restrict__ fwd,
+                                                                      float* __restrict__ bwd, const PackArgs a) {
+    const bool is_bwd = blockIdx.x >= a.blocks_f;
+    const unsigned blk = is_bwd ? blockIdx.x - a.blocks_f : blockIdx.x;
+    const MmaGeom& g = is_bwd ? a.gb : a.gf;
+    float* const img = is_bwd ? bwd : fwd;
+    if (!g.split) {
+        const size_t j = (size_t)blk * kPackThreads + threadIdx.x;
+        if (j >= (size_t)a.F * 2 * g.MP * g.KP) return;
+        const int k = j % g.KP;
+        const int m = (j / g.KP) % g.MP;
+        const int pl = (j / ((size_t)g.KP * g.MP)) % 2;
+        const int f = j / ((size_t)g.KP * g.MP * 2);
+        const float2 v = packed_value<FROM_PARAMS>(w, zonal, sph, phase, a, is_bwd, m, k, f);
+        img[j] = pl == 0 ? v.x : v.y;
+        return;
+    }
+    // split image, row m = blk
+    __shared__ float red[kPackThreads / kWave];
+    const int m = blk;
+    const int total = a.F * g.KP;
+    float2 vals[kPackRowValues];
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < kPackRowValues; ++u) {
+        const int idx = u * kPackThreads + threadIdx.x;
+        vals[u] = make_float2(0.f, 0.f);
+        if (idx < total) {
+            const int f = idx / g.KP, k = idx - f * g.KP;
+            vals[u] = packed_value<FROM_PARAMS>(w, zonal, sph, phase, a, is_bwd, m, k, f);
+        }
+        mx = fmaxf(mx, fmaxf(fabsf(vals[u].x), fabsf(vals[u].y)));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float scale, inv;
+    split_scale(mx, scale, inv);
+    if (threadIdx.x == 0) img[m] = inv;
+    _Float16* const planes = reinterpret_cast<_Float16*>(img + g.MP);
+    const size_t plane = (size_t)g.MP * g.KP;
+#pragma unroll
+    for (int u = 0; u < kPackRowValues; ++u) {
+        const int idx = u * kPackThreads + threadIdx.x;
+        if (idx < total) {
+            const int f = idx / g.KP, k = idx - f * g.KP;
+            _Float16 rh, rl, ih, il;
+            split_halves(vals[u].x * scale, rh, rl);
+            split_halves(vals[u].y * scale, ih, il);
+            _Float16* p = planes + (size_t)f * 4 * plane + (size_t)m * g.KP + k;
+            p[0] = rh;
+            p[plane] = rl;
+            p[2 * plane] = ih;
+            p[3 * plane] = il;
+        }
+    }
+}
+
+static unsigned pack_blocks(const MmaGeom& g, int F) {
+    return g.split ? (unsigned)g.MP : (unsigned)(((size_t)F * 2 * g.MP * g.KP + kPackThreads - 1) / kPackThreads);
+}
+
+template <bool FROM_PARAMS>
+static int launch_pack(const float* w_eff, const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
+                       float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
+    PackArgs a;
+    a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
+    a.gf = make_mma_geom(d->O, d->R * d->I, split_mode());
+    a.gb = make_mma_geom(d->I, d->R * d->O, split_mode());
+    if ((a.gf.split && a.F * a.gf.KP > kPackRowValues * kPackThreads) || (a.gb.split && a.F * a.gb.KP > kPackRowValues * kPackThreads))
+        return FC_ERR_UNSUPPORTED;
+    a.blocks_f = pack_blocks(a.gf, a.F);
+    const unsigned blocks = a.blocks_f + pack_blocks(a.gb, a.F);
+    hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,
+                       reinterpret_cast<const float2*>(w_eff), zonal, sph, phase, wpk_fwd, wpk_bwd, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
-    int F, OP, KPf, IP, KPb;
-    size_t total;
-    pack_geometry(d, F, OP, KPf, IP, KPb, total);
-    hipLaunchKernelGGL(fc_pack_filter_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const float2*>(w_eff), nullptr, nullptr, nullptr, 0, d->B, wpk_fwd, wpk_bwd, d->O,
-                       d->I, d->R, F, OP, KPf, IP, KPb);
-    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+    return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, stream);
 }
 
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
                             float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
-    int F, OP, KPf, IP, KPb;
-    size_t total;
-    pack_geometry(d, F, OP, KPf, IP, KPb, total);
-    hipLaunchKernelGGL(fc_pack_filter_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, nullptr,
-                       zonal, sph, phase, ftype, d->B, wpk_fwd, wpk_bwd, d->O, d->I, d->R, F, OP, KPf, IP, KPb);
-    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+    return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, stream);
+}
+
+bool split_mode() {
+    static const bool mode = [] {
+        const char* e = getenv("FC_MFMA");
+        return !(e && e[0] == 'f' && e[1] == '3' && e[2] == '2');
+    }();
+    return mode;
 }
 
 // One thread per (o,i): reads gW_eff[o,i,:,:] (R*F complex) and writes the parameter gradients

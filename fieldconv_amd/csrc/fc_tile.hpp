@@ -9,47 +9,81 @@ namespace fc {
 // Contraction geometry of one pass: out[M x 16 vertices] = Wpk[M x K] * slab[16 vertices x K].
 //   forward : M = O (output channels),  K = R*I
 //   backward: M = I (input channels),   K = R*O
+//
+// Two arithmetic modes for the contraction (same results to fp32 rounding level, see mma_slab_split):
+//   fp32   v_mfma_f32_16x16x4_f32 on fp32 operands; k blocks of 16, slab = 2 planes of floats
+//   split  v_mfma_f32_16x16x32_f16 on operands split into two halves (hi + lo); k blocks of 32,
+//          slab = 4 planes of halves.  KP / KS are then counted in halves; the slab occupies
+//          128 * KS bytes in both modes.
 struct MmaGeom {
     int MP;     // ceil16(M)
-    int KP;     // ceil16(K)
-    int KS;     // LDS slab row stride (floats), slab_stride(KP)
+    int KP;     // k entries per row: ceil16(K) (fp32) or ceil32(K) (split)
+    int KS;     // LDS slab row stride in elements, slab_stride(KP)
     int NMT;    // MP / 16 output tiles
     int NKP;    // k partitions (wavefronts per output tile)
-    int KST;    // KP / 16 k blocks
+    int KST;    // k blocks: KP / 16 (fp32) or KP / 32 (split)
+    int split;  // 1: split-half mode
 };
 
-__host__ __device__ inline MmaGeom make_mma_geom(int M, int K) {
+__host__ __device__ inline MmaGeom make_mma_geom(int M, int K, bool split = false) {
     MmaGeom g;
+    const int kblock = split ? 32 : 16;
+    g.split = split ? 1 : 0;
     g.MP = round_up(M, 16);
-    g.KP = round_up(K, 16);
+    g.KP = round_up(K, kblock);
     g.KS = slab_stride(g.KP);
     g.NMT = g.MP / 16;
-    g.KST = g.KP / 16;
+    g.KST = g.KP / kblock;
     g.NKP = kWaves / g.NMT;
     if (g.NKP > g.KST) g.NKP = g.KST;
     if (g.NKP < 1) g.NKP = 1;
     return g;
 }
 
+// Floats in the packed filter image of one contraction (F frequencies, M rows, K entries per row).
+//   fp32 : [F][2 planes re,im][MP][KP] floats
+//   split: [MP] inverse row scales (floats), then [F][4 planes re_hi,re_lo,im_hi,im_lo][MP][KP] halves
+__host__ __device__ inline size_t packed_image_floats(int M, int K, int F, bool split) {
+    const MmaGeom g = make_mma_geom(M, K, split);
+    return split ? (size_t)g.MP + (size_t)F * 2 * g.MP * g.KP : (size_t)F * 2 * g.MP * g.KP;
+}
+
+// Which mode the library runs in: FC_MFMA=f32 selects the fp32 MFMA, anything else the split mode.
+bool split_mode();
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The packed filter is read through a buffer descriptor: the wave-uniform part of every address
+// (frequency, plane, k block) travels in the scalar offset and the per-lane part in ONE 32-bit
+// VGPR, instead of a 64-bit VGPR pointer per plane that hipcc would otherwise keep (and spill)
+// across the whole kernel.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buffer_load16(rsrc_t r, int voffset_bytes, int soffset_bytes) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset_bytes, soffset_bytes, 0));
+}
+typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) _Float16 lds_f16;
+
 // One slab (one angular frequency) through the MFMA pipe for this wavefront's (output tile mt,
 // k partition kp): acc (re, im) += W[mt*16.., k] * slab[vertex, k], complex via four real products
-// on two accumulators.  wre / wim: this frequency's packed planes, [MP][KP] floats each.
-// Filter fragments come straight from L2 as 16 rows x 64 B per instruction and are
-// double-buffered in registers; slab fragments are conflict-free float4 LDS reads.
-__device__ __forceinline__ void mma_slab(const float* __restrict__ wre_plane, const float* __restrict__ wim_plane,
-                                         const float* sre, const float* sim, const MmaGeom& g, int mt, int kp, int lane,
-                                         f32x4& acc_re, f32x4& acc_im) {
+// on two accumulators.  wimg / f_bytes: descriptor of the packed image and byte offset of this
+// frequency's two planes [2][MP][KP] floats.  Filter fragments come straight from L2 as 16 rows x 64 B
+// per instruction and are double-buffered in registers; slab fragments are conflict-free float4 LDS reads.
+__device__ __forceinline__ void mma_slab(rsrc_t wimg, int f_bytes, const float* sre, const float* sim, const MmaGeom& g,
+                                         int mt, int kp, int lane, f32x4& acc_re, f32x4& acc_im) {
     const int fr = lane & 15, fq = lane >> 4;
-    const float* wre = wre_plane + (size_t)(mt * 16 + fr) * g.KP + 4 * fq;
-    const float* wim = wim_plane + (size_t)(mt * 16 + fr) * g.KP + 4 * fq;
+    const int wplane = g.MP * g.KP * 4;                 // bytes
+    const int wv = ((mt * 16 + fr) * g.KP + 4 * fq) * 4;
     const float* bre = sre + fr * g.KS + 4 * fq;
     const float* bim = sim + fr * g.KS + 4 * fq;
-    float4 wr = *reinterpret_cast<const float4*>(wre + 16 * kp);
-    float4 wi = *reinterpret_cast<const float4*>(wim + 16 * kp);
+    auto ldw = [&](int plane, int kb) { return __builtin_bit_cast(float4, buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb)); };
+    float4 wr = ldw(0, kp), wi = ldw(1, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
         const int kn = min(kb + g.NKP, g.KST - 1);          // next block (clamped re-read at the end)
-        const float4 wr_n = *reinterpret_cast<const float4*>(wre + 16 * kn);
-        const float4 wi_n = *reinterpret_cast<const float4*>(wim + 16 * kn);
+        const float4 wr_n = ldw(0, kn), wi_n = ldw(1, kn);
         const float4 br = *reinterpret_cast<const float4*>(bre + 16 * kb);
         const float4 bi = *reinterpret_cast<const float4*>(bim + 16 * kb);
         // re += Wre*Sre - Wim*Sim ; im += Wim*Sre + Wre*Sim
@@ -63,6 +97,83 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ wre_plane, co
         acc_re = mfma16(-wi.w, bi.w, acc_re); acc_im = mfma16(wr.w, bi.w, acc_im);
         wr = wr_n;
         wi = wi_n;
+    }
+}
+
+// ---- split mode ------------------------------------------------------------------------------
+// A fp32 value v is carried as two halves, hi = half(v*s), lo = half(v*s - hi), with s a power of two
+// that brings the largest magnitude of the row (one vertex of the slab / one output row of the filter)
+// to [2^13, 2^14): hi + lo reproduces v*s to 2^-22 relative to the row maximum whatever the half
+// denormal behaviour of the matrix pipe.  The product (hi_w + lo_w)(hi_s + lo_s) is accumulated in
+// fp32 as hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-22 relative): three
+// v_mfma_f32_16x16x32_f16 per real product, 16 cycles each for 32 k, against eight 32-cycle
+// v_mfma_f32_16x16x4_f32 -- 5.3x less matrix-pipe time at fp32-level accuracy.  The scales are exact
+// (powers of two) and are divided out in the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma32h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Power-of-two scale (and its inverse) that maps magnitude m into [2^13, 2^14); 1 for m = 0 / non-finite.
+__host__ __device__ inline void split_scale(float m, float& scale, float& inv) {
+    union { float f; uint32_t u; } bits;
+    bits.f = m;
+    const int e = (int)((bits.u >> 23) & 0xff);        // m in [2^(e-127), 2^(e-126))
+    int se = 267 - e;                                   // biased exponent of 2^(13 - (e - 127))
+    if (e == 0 || e == 255) se = 127;
+    if (se > 253) se = 253;
+    if (se < 1) se = 1;
+    bits.u = (uint32_t)se << 23;
+    scale = bits.f;
+    bits.u = (uint32_t)(254 - se) << 23;
+    inv = bits.f;
+}
+
+__device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// One slab through the matrix pipe in split mode.  wimg: descriptor of the packed image, f_bytes: byte
+// offset of this frequency's four planes [4][MP][KP] halves in it; sp: the slab's four planes
+// [4][16][KS] halves (LDS).  Lane l holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15],
+// j = 0..7, as one 16-byte fragment.
+__device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const lds_f16* sp, const MmaGeom& g, int mt, int kp,
+                                               int lane, f32x4& acc_re, f32x4& acc_im) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wplane = g.MP * g.KP * 2;                 // bytes
+    const int splane = kTile * g.KS;                    // halves
+    const int wv = ((mt * 16 + fr) * g.KP + 8 * fq) * 2;
+    const lds_f16* s0 = sp + fr * g.KS + 8 * fq;
+    auto ldw = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
+    auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + plane * splane + 32 * kb); };
+    const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    u32x4 wrh = ldw(0, kp), wrl = ldw(1, kp), wih = ldw(2, kp), wil = ldw(3, kp);
+    for (int kb = kp; kb < g.KST; kb += g.NKP) {
+        const int kn = min(kb + g.NKP, g.KST - 1);          // next block (clamped re-read at the end)
+        const u32x4 n_wrh = ldw(0, kn), n_wrl = ldw(1, kn), n_wih = ldw(2, kn), n_wil = ldw(3, kn);
+        // re += Wre*Sre - Wim*Sim ; im += Wim*Sre + Wre*Sim, each product = lo*hi + hi*lo + hi*hi.
+        // The real-part fragments of the slab are consumed before the imaginary ones are read, and those
+        // are negated in place, to keep the live register set small next to the gather accumulators.
+        {
+            const u32x4 srh = lds(0, kb), srl = lds(1, kb);
+            acc_re = mfma32h(wrl, srh, acc_re); acc_im = mfma32h(wil, srh, acc_im);
+            acc_re = mfma32h(wrh, srl, acc_re); acc_im = mfma32h(wih, srl, acc_im);
+            acc_re = mfma32h(wrh, srh, acc_re); acc_im = mfma32h(wih, srh, acc_im);
+        }
+        {
+            u32x4 sih = lds(2, kb), sil = lds(3, kb);
+            acc_im = mfma32h(wrl, sih, acc_im);
+            acc_im = mfma32h(wrh, sil, acc_im);
+            acc_im = mfma32h(wrh, sih, acc_im);
+            sih ^= sign;
+            sil ^= sign;
+            acc_re = mfma32h(wil, sih, acc_re);
+            acc_re = mfma32h(wih, sil, acc_re);
+            acc_re = mfma32h(wih, sih, acc_re);
+        }
+        wrh = n_wrh; wrl = n_wrl; wih = n_wih; wil = n_wil;
     }
 }
 

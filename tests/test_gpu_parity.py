@@ -226,6 +226,48 @@ def test_fieldconv_vs_oracle(case, dev):
     assert rel_err(H(gW), gW_ref) < TOL
 
 
+def rowwise_err(a, ref):
+    """max over rows of max|delta_row| / max|ref_row| (rows of zeros in ref must be exactly zero)."""
+    a, ref = np.asarray(a), np.asarray(ref)
+    a, ref = a.reshape(a.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    num = np.abs(a - ref).max(axis=1)
+    den = np.abs(ref).max(axis=1)
+    assert np.all(num[den == 0] == 0)
+    return float((num[den > 0] / den[den > 0]).max())
+
+
+@pytest.mark.parametrize('global_scale', [1.0, 1e-18, 1e12], ids=['unit', 'tiny', 'huge'])
+def test_dynamic_range_rowwise(global_scale, dev):
+    """The MFMA contractions run on operands split into two halves with one power-of-two scale per
+    vertex and per filter row (csrc/fc_tile.hpp).  Features spanning ten orders of magnitude from
+    vertex to vertex, filter rows spanning five, an all-zero vertex, an all-zero filter row and
+    inputs near the ends of the fp32 exponent range must still come out to fp32 accuracy ROW BY ROW
+    (a global max-norm would hide the small rows)."""
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    N, k, I, O, B, R = 400, 12, 48, 40, 2, 6
+    edges, sten, x, gy, W = make_case(77, N, k, I, O, B, R, True, zero_frac=0.0)
+    g = torch.Generator().manual_seed(5)
+    x = x * (10.0 ** (torch.rand(N, 1, generator=g) * 10 - 6)) * global_scale
+    x[7] = 0
+    W = W * (10.0 ** (torch.rand(O, 1, 1, 1, generator=g) * 5 - 3))
+    W[3] = 0
+    gy = gy * (10.0 ** (torch.rand(N, 1, generator=g) * 6 - 3))
+    x, W, gy = x.to(torch.complex64), W.to(torch.complex64), gy.to(torch.complex64)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    c128 = lambda t: t.numpy().astype(np.complex128)
+    y_ref = orc.fieldconv_forward(c128(x), edges.numpy(), c128(sten), c128(W))
+    gx_ref, gW_ref = orc.fieldconv_backward(c128(x), edges.numpy(), c128(sten), c128(W), c128(gy))
+    assert np.all(np.isfinite(H(y))) and np.all(np.isfinite(H(gx))) and np.all(np.isfinite(H(gW)))
+    ey, egx, egw = rowwise_err(H(y), y_ref), rowwise_err(H(gx), gx_ref), rowwise_err(H(gW), gW_ref)
+    print(f'row-wise errors: y {ey:.2e} gx {egx:.2e} gW {egw:.2e}')
+    assert ey < TOL and egx < 5 * TOL and egw < TOL
+
+
 @pytest.mark.parametrize('shape', [(48, 48, 2, 6), (16, 24, 1, 6), (64, 64, 3, 6), (8, 8, 2, 4), (20, 12, 1, 3)],
                          ids=lambda s: 'I%d_O%d_B%d_R%d' % s)
 def test_factored_stencil_path_vs_oracle_and_dense(shape, dev):

@@ -43,7 +43,9 @@ def test_supported_query_and_sizes_need_no_gpu():
     lib = _lib.load()
     d = _lib.FcDims(20000, 640000, 48, 48, 6, 2)
     assert lib.fc_supported(ctypes.byref(d)) == 1
-    assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d)) == 5 * 2 * 48 * 288
+    # split-half image (default mode): 48 row scales + 5 frequencies x 4 half planes x 48 rows x 288 entries
+    assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d)) == 48 + 5 * 2 * 48 * 288
+    assert lib.fc_packed_filter_floats_bwd(ctypes.byref(d)) == 48 + 5 * 2 * 48 * 288
     assert lib.fc_backward_workspace_bytes(ctypes.byref(d)) > 0
     bad = _lib.FcDims(100, 10, 48, 48, 9, 2)
     assert lib.fc_supported(ctypes.byref(bad)) == 0
