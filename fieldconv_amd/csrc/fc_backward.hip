@@ -126,9 +126,20 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
     const int i = idx % I;
     const int k = (idx / I) % (R * O);
     const int f = idx / (I * R * O);
+    // fixed summation order, eight independent loads in flight
     float2 s = make_float2(0.f, 0.f);
-    for (int p = 0; p < P; ++p) {
-        const float2 v = gwp[(((size_t)p * F + f) * KP + k) * IP + i];
+    const size_t stride = (size_t)F * KP * IP;
+    const float2* src = gwp + ((size_t)f * KP + k) * IP + i;
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; }
+    }
+    for (; p < P; ++p) {
+        const float2 v = src[(size_t)p * stride];
         s.x += v.x;
         s.y += v.y;
     }

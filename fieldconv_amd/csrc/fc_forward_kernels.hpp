@@ -36,6 +36,8 @@ struct FwdArgs {
     MmaGeom g;          // M = O, K = R*I
     int ntiles;
     int ring_chunks;    // factored: 1 KiB chunks per wavefront in the LDS record ring
+    int slabs;          // slab buffers in LDS: 2 = consecutive frequencies alternate buffers and need one barrier each;
+                        // the k-partials of the epilogue then live in whichever buffer is idle
     uint32_t wpk_bytes; // size of the packed filter image
     int dbg;            // development only (FC_DEBUG env): bit0 skip gather loop, bit1 skip MFMA loop
 };
@@ -56,22 +58,24 @@ struct FwdLds {
     float* vscale;   // split: two buffers (tile parity) of [16] vertex slab scales + [16] inverses
     float* end;
 };
-__device__ __forceinline__ FwdLds forward_lds(char* smem, const MmaGeom& g) {
+__device__ __forceinline__ FwdLds forward_lds(char* smem, const MmaGeom& g, int slabs) {
     FwdLds l;
     l.slab = reinterpret_cast<float*>(smem);
-    l.part = l.slab + 2 * kTile * g.KS;
-    l.vscale = l.part + partial_floats(g.NKP, g.MP);
+    l.part = l.slab + slabs * 2 * kTile * g.KS;
+    l.vscale = l.part + (slabs == 2 ? 0 : partial_floats(g.NKP, g.MP));
     l.end = l.vscale + 4 * kTile;
     return l;
 }
-__host__ inline size_t forward_lds_floats(const MmaGeom& g) { return (size_t)2 * kTile * g.KS + partial_floats(g.NKP, g.MP) + 4 * kTile; }
+__host__ inline size_t forward_lds_floats(const MmaGeom& g, int slabs) {
+    return (size_t)slabs * 2 * kTile * g.KS + (slabs == 2 ? 0 : partial_floats(g.NKP, g.MP)) + 4 * kTile;
+}
 
 // Phase B for one frequency group: slabs -> MFMA accumulate.  c[r][ff] holds this lane's response.
 // first_group: no earlier group has contributed to acc in this tile.  vs: this tile's scale buffer
 // (alternates between consecutive tiles of the workgroup, so a wavefront that runs ahead into the
 // next tile never overwrites scales the epilogue of the previous one still reads).
 template <int R, int B, int MG, bool MULTI_GROUP, bool SPLIT>
-__device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0, const FwdLds& l, float* vs,
+__device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0, const FwdLds& l, float* vs, int& buf,
                                                 const float* __restrict__ gwpk, const FwdArgs& a, int wave, int lane,
                                                 bool first_group, f32x4& acc_re, f32x4& acc_im) {
     constexpr int F = 2 * B + 1;
@@ -127,7 +131,6 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
         vs[wave] = scale;          // read after the slab barriers below
         vs[kTile + wave] = inv;
     }
-    lds_f16* const sp = (lds_f16*)l.slab;
     const int splane = kTile * g.KS;
     const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
     const int planes0 = g.MP * 4;                                  // bytes: the planes follow the MP row scales
@@ -136,6 +139,11 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
     for (int ff = 0; ff < MG; ++ff) {
         const int f = f0 + ff;
         if (f < F) {
+            // With two slab buffers consecutive frequencies alternate: a wavefront that has finished its MFMAs
+            // on slab t writes slab t+1 into the other buffer at once, and that buffer is free because every
+            // wavefront passed barrier t only after its MFMAs on slab t-1.  One barrier per slab instead of two,
+            // and the conversions of one wavefront overlap the MFMAs of the others.
+            lds_f16* const sp = (lds_f16*)l.slab + buf * 4 * splane;
             if (lane < a.I) {
                 // one running LDS offset, advanced by I per ring; the empty asm keeps hipcc from materialising
                 // all 4*R addresses in registers for the whole kernel (they would spill)
@@ -157,24 +165,28 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
             __syncthreads();
             if (mma_active && !(a.dbg & 2))
                 mma_slab_split(wimg, planes0 + f * (4 * g.MP * g.KP * 2), sp, g, mt, kp, lane, acc_re, acc_im);
-            __syncthreads();
+            if (a.slabs == 2) buf ^= 1;
+            else __syncthreads();
         }
     }
     }
 }
 
+// `part`: the k-partial buffer -- its own LDS region, or with two slab buffers the idle one (the last slab's
+// MFMAs ran on the other; every wavefront finished the MFMAs on this one before that slab's barrier, and the
+// next tile writes its first slab into the other buffer again).
 template <bool SPLIT>
-__device__ __forceinline__ void forward_epilogue(const FwdLds& l, const float* vs, const float* __restrict__ gwpk, const FwdArgs& a, int tile,
+__device__ __forceinline__ void forward_epilogue(const FwdLds& l, float* part, const float* vs, const float* __restrict__ gwpk, const FwdArgs& a, int tile,
                                                  int wave, int lane, const f32x4& acc_re, const f32x4& acc_im,
                                                  float2* __restrict__ gy_) {
     const MmaGeom& g = a.g;
     const int mt = wave % g.NMT, kp = wave / g.NMT;
-    if (kp < g.NKP) store_partial(l.part, g, mt, kp, lane, acc_re, acc_im);
+    if (kp < g.NKP) store_partial(part, g, mt, kp, lane, acc_re, acc_im);
     __syncthreads();
     for (int idx = wave * kWave + lane; idx < kTile * a.O; idx += kThreads) {
         const int v = idx / a.O, o = idx - v * a.O;
         const int n = tile * kTile + v;
-        float2 s = sum_partials(l.part, g, v, o);
+        float2 s = sum_partials(part, g, v, o);
         if constexpr (SPLIT) {      // undo the slab scale of vertex v and the filter scale of row o (both powers of two)
             const float k = vs[kTile + v] * gwpk[o];
             s.x *= k;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
     constexpr int MG = FwdShape<R, B>::MG;
     constexpr int ROWF = 2 * R * F;                              // floats per stencil row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FwdLds l = forward_lds(smem, a.g);
+    const FwdLds l = forward_lds(smem, a.g, a.slabs);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -204,12 +216,13 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
     const int I = a.I;
 
     // zero the slab once: the k padding [R*I, KP) is never written again and must not hold NaNs
-    for (int idx = tid; idx < 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    for (int idx = tid; idx < a.slabs * 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
     __syncthreads();
 
     const int cl = lane < I ? lane : 0;      // lanes >= I gather channel 0 and are never stored
 
     float* vs = l.vscale;
+    int buf = 0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int t = tile * kTile + wave;
         int beg = 0, end = 0;
@@ -259,9 +272,11 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
                     slot(e, xa);
                     if (e + 1 < end) slot(e + 1, xb);
                 }
-            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
+            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
-        forward_epilogue<SPLIT>(l, vs, gwpk, a, tile, wave, lane, acc_re, acc_im, gy_);
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * 2 * kTile * a.g.KS : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
+                                acc_im, gy_);
+        buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
     }
 }
@@ -284,14 +299,14 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     constexpr int CR = 1 << LOG_CR;
     constexpr int NR = kRingChunks;                              // ring slots per wavefront (power of two)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FwdLds l = forward_lds(smem, a.g);
+    const FwdLds l = forward_lds(smem, a.g, a.slabs);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const ring = l.end + wave * NR * 256;                 // [NR][256] floats, this wavefront's
     const int I = a.I;
 
-    for (int idx = tid; idx < 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    for (int idx = tid; idx < a.slabs * 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
     __syncthreads();
 
     const int cl = lane < I ? lane : 0;
@@ -317,8 +332,24 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
     }
+    // Source rows of the first two slots of a target whose first record chunk is in (or on its way to) the
+    // ring: issued one tile ahead, before the epilogue of the previous tile, so their latency is hidden.
+    auto first_rows = [&](const int nslots, float2& r0, float2& r1) {
+        r0 = make_float2(0.f, 0.f);
+        r1 = r0;
+        if (nslots > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+            const int n0 = __float_as_int(ring[3]);
+            const int n1 = __float_as_int(ring[min(1, nslots - 1) * RECF + 3]);
+            r0 = gx_[(size_t)n0 * I + cl];
+            r1 = gx_[(size_t)n1 * I + cl];
+        }
+    };
+    float2 pxa, pxb;
+    first_rows(end - beg, pxa, pxb);
 
     float* vs = l.vscale;
+    int buf = 0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
@@ -353,14 +384,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             const int nslots = end - beg;
             // record s of this target (s relative to beg) lives at ring[((s >> LOG_CR) & (NR-1)) * 256 + (s & (CR-1)) * RECF]
             auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
-            float2 xa = make_float2(0.f, 0.f), xb = xa;
-            if (nslots > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
-                const int n0 = __float_as_int(rec_ptr(0)[3]);
-                const int n1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
-                xa = gx_[(size_t)n0 * I + cl];
-                xb = gx_[(size_t)n1 * I + cl];
-            }
+            float2 xa = pxa, xb = pxb;
+            if (g > 0) first_rows(nslots, xa, xb);
             // One slot whose lower ring is the compile-time constant Q: contrib[Q] += w0 z, contrib[Q+1] += w1 z
             // with z_f = ph_f * xt_f.  `xcur` holds the slot's source row on entry and the row of slot s+2 on
             // exit.  No scalar memory loads in here (they share lgkmcnt with the LDS reads and return out of
@@ -419,9 +444,12 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
                 const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
                 for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
             }
-            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
+            forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
-        forward_epilogue<SPLIT>(l, vs, gwpk, a, tile, wave, lane, acc_re, acc_im, gy_);
+        first_rows(nend - nbeg, pxa, pxb);       // the next tile's first source rows fly during the epilogue
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * 2 * kTile * a.g.KS : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
+                                acc_im, gy_);
+        buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
         beg = nbeg;
         end = nend;
@@ -452,12 +480,11 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     a.ntiles = (d->N + kTile - 1) / kTile;
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R * d->I, 2 * d->B + 1, SPLIT) * sizeof(float));
     { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
-    size_t lds = forward_lds_floats(a.g) * sizeof(float);
-    a.ring_chunks = 0;
-    if (factored) {
-        a.ring_chunks = kRingChunks;
-        lds += (size_t)kWaves * kRingChunks * 1024;
-    }
+    a.ring_chunks = factored ? kRingChunks : 0;
+    const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;
+    a.slabs = (SPLIT && partial_floats(a.g.NKP, a.g.MP) <= 2 * kTile * a.g.KS &&
+               forward_lds_floats(a.g, 2) * sizeof(float) + ring <= kMaxLds) ? 2 : 1;
+    const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
     const int grid = factored ? (a.ntiles < kNumCUs ? a.ntiles : kNumCUs) : a.ntiles;

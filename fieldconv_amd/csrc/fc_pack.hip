@@ -50,9 +50,9 @@ struct PackArgs {
 };
 
 constexpr int kPackThreads = 256;
-constexpr int kPackRowValues = 16;       // (f, k) entries per thread of a split row: F * KP <= 16 * 256
 
-template <bool FROM_PARAMS>
+// WITH_PHASE = false: the same entry without the ftype-1 phase factor (same modulus, no sincos)
+template <bool FROM_PARAMS, bool WITH_PHASE>
 __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, const float* __restrict__ zonal,
                                                const float* __restrict__ sph, const float* __restrict__ phase,
                                                const PackArgs& a, bool is_bwd, int m, int k, int f) {
@@ -60,7 +60,7 @@ __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, con
     const int r = k / inner, c = k - r * inner;
     const int o = is_bwd ? c : m, i = is_bwd ? m : c;
     if (o >= a.O || i >= a.I || r >= a.R) return make_float2(0.f, 0.f);
-    const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, a.ftype, a.B, a.R, a.I, o, i, r, f)
+    const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!WITH_PHASE && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.I, o, i, r, f)
                                  : w[(((size_t)o * a.I + i) * a.R + r) * a.F + f];
     const float sc = 1.f / (float)a.F;
     return make_float2(v.x * sc, (is_bwd ? -v.y : v.y) * sc);
@@ -82,55 +82,46 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
         const int m = (j / g.KP) % g.MP;
         const int pl = (j / ((size_t)g.KP * g.MP)) % 2;
         const int f = j / ((size_t)g.KP * g.MP * 2);
-        const float2 v = packed_value<FROM_PARAMS>(w, zonal, sph, phase, a, is_bwd, m, k, f);
+        const float2 v = packed_value<FROM_PARAMS, true>(w, zonal, sph, phase, a, is_bwd, m, k, f);
         img[j] = pl == 0 ? v.x : v.y;
         return;
     }
-    // split image, row m = blk
+    // split image: workgroup = (row m, frequency f).  The row scale comes from the largest MODULUS of the row
+    // (all frequencies): it bounds both components, needs no phase factor (|c e^{i phi}| = |c|), and every
+    // workgroup of the row recomputes it cheaply instead of synchronising.
     __shared__ float red[kPackThreads / kWave];
-    const int m = blk;
-    const int total = a.F * g.KP;
-    float2 vals[kPackRowValues];
+    const int m = blk / a.F, f = blk - m * a.F;
     float mx = 0.f;
-#pragma unroll
-    for (int u = 0; u < kPackRowValues; ++u) {
-        const int idx = u * kPackThreads + threadIdx.x;
-        vals[u] = make_float2(0.f, 0.f);
-        if (idx < total) {
-            const int f = idx / g.KP, k = idx - f * g.KP;
-            vals[u] = packed_value<FROM_PARAMS>(w, zonal, sph, phase, a, is_bwd, m, k, f);
-        }
-        mx = fmaxf(mx, fmaxf(fabsf(vals[u].x), fabsf(vals[u].y)));
+    for (int idx = threadIdx.x; idx < a.F * g.KP; idx += kPackThreads) {
+        const int ff = idx / g.KP, k = idx - ff * g.KP;
+        const float2 v = packed_value<FROM_PARAMS, false>(w, zonal, sph, phase, a, is_bwd, m, k, ff);
+        mx = fmaxf(mx, v.x * v.x + v.y * v.y);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))) * 1.0000002f;     // never below the true modulus
     float scale, inv;
     split_scale(mx, scale, inv);
-    if (threadIdx.x == 0) img[m] = inv;
+    if (threadIdx.x == 0 && f == 0) img[m] = inv;
     _Float16* const planes = reinterpret_cast<_Float16*>(img + g.MP);
     const size_t plane = (size_t)g.MP * g.KP;
-#pragma unroll
-    for (int u = 0; u < kPackRowValues; ++u) {
-        const int idx = u * kPackThreads + threadIdx.x;
-        if (idx < total) {
-            const int f = idx / g.KP, k = idx - f * g.KP;
-            _Float16 rh, rl, ih, il;
-            split_halves(vals[u].x * scale, rh, rl);
-            split_halves(vals[u].y * scale, ih, il);
-            _Float16* p = planes + (size_t)f * 4 * plane + (size_t)m * g.KP + k;
-            p[0] = rh;
-            p[plane] = rl;
-            p[2 * plane] = ih;
-            p[3 * plane] = il;
-        }
+    for (int k = threadIdx.x; k < g.KP; k += kPackThreads) {
+        const float2 v = packed_value<FROM_PARAMS, true>(w, zonal, sph, phase, a, is_bwd, m, k, f);
+        _Float16 rh, rl, ih, il;
+        split_halves(v.x * scale, rh, rl);
+        split_halves(v.y * scale, ih, il);
+        _Float16* p = planes + (size_t)f * 4 * plane + (size_t)m * g.KP + k;
+        p[0] = rh;
+        p[plane] = rl;
+        p[2 * plane] = ih;
+        p[3 * plane] = il;
     }
 }
 
 static unsigned pack_blocks(const MmaGeom& g, int F) {
-    return g.split ? (unsigned)g.MP : (unsigned)(((size_t)F * 2 * g.MP * g.KP + kPackThreads - 1) / kPackThreads);
+    return g.split ? (unsigned)(g.MP * F) : (unsigned)(((size_t)F * 2 * g.MP * g.KP + kPackThreads - 1) / kPackThreads);
 }
 
 template <bool FROM_PARAMS>
@@ -140,8 +131,6 @@ static int launch_pack(const float* w_eff, const float* zonal, const float* sph,
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
     a.gf = make_mma_geom(d->O, d->R * d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R * d->O, split_mode());
-    if ((a.gf.split && a.F * a.gf.KP > kPackRowValues * kPackThreads) || (a.gb.split && a.F * a.gb.KP > kPackRowValues * kPackThreads))
-        return FC_ERR_UNSUPPORTED;
     a.blocks_f = pack_blocks(a.gf, a.F);
     const unsigned blocks = a.blocks_f + pack_blocks(a.gb, a.F);
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,
@@ -166,21 +155,27 @@ bool split_mode() {
     return mode;
 }
 
-// One thread per (o,i): reads gW_eff[o,i,:,:] (R*F complex) and writes the parameter gradients
+// One thread per (o, i, r): reads gW_eff[o,i,r,:] (F complex) and writes the parameter gradients of
+// its ring; the phase gradient sums over the rings of (o,i) through LDS in a fixed order.
 // (torch convention for a real loss: g = dL/dRe + i dL/dIm; for a real parameter p of a complex
 // w(p): g_p = Re(conj(dw/dp) g_w)).
+constexpr int kGradPairs = 32;      // (o,i) pairs per workgroup; blockDim = kGradPairs * R
+constexpr int kMaxB = 3;
+
 __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, const float* __restrict__ zonal,
                                              const float* __restrict__ sph, const float* __restrict__ phase, int ftype,
                                              float* __restrict__ g_zonal, float* __restrict__ g_sph,
                                              float* __restrict__ g_phase, int O, int I, int R, int B) {
-    const int oi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (oi >= O * I) return;
+    __shared__ float gph[kGradPairs * 8 * (kMaxB + 1)];      // [pair][r][q]
+    const int pair = threadIdx.x / R, r = threadIdx.x - pair * R;
+    const int oi = blockIdx.x * kGradPairs + pair;
+    const bool valid = oi < O * I;
     const int F = 2 * B + 1;
     const int o = oi / I, i = oi - o * I;
-    if (ftype == 2) {
-        for (int r = 0; r < R; ++r) {
-            const size_t oir = (size_t)oi * R + r;
-            const float2* g = gw + oir * F;
+    const size_t oir = (size_t)oi * R + r;
+    if (valid) {
+        const float2* g = gw + oir * F;
+        if (ftype == 2) {
             g_zonal[oir * 2] = g[B].x;
             g_zonal[oir * 2 + 1] = g[B].y;
             for (int b = 0; b < 2 * B; ++b) {
@@ -188,48 +183,48 @@ __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, cons
                 g_sph[(oir * (2 * B) + b) * 2] = v.x;
                 g_sph[(oir * (2 * B) + b) * 2 + 1] = v.y;
             }
-        }
-        return;
-    }
-    // per-|m| phase gradient accumulators (ftype 1): g_phase[q] = sum_{f: |f-B| = q} Re(conj(i P_f) gP_f),
-    // gP_f = sum_r gW[r,f] conj(coeff[r,f])
-    for (int q = 0; q <= B; ++q) {
-        float acc = 0.f;
-        float s = 0.f, co = 1.f;
-        if (ftype == 1) sincosf(phase[(size_t)oi * (B + 1) + q], &s, &co);
-        const float2 P = make_float2(co, s);
-        for (int sign = 0; sign < (q == 0 ? 1 : 2); ++sign) {
-            const int f = sign == 0 ? B + q : B - q;
-            float2 gP = make_float2(0.f, 0.f);
-            for (int r = 0; r < R; ++r) {
-                const size_t oir = (size_t)oi * R + r;
-                const float2 g = gw[oir * F + f];
-                const float2 coeff = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, f);   // without the phase
-                const float2 t = cmul_conj(g, coeff);
-                gP.x += t.x;
-                gP.y += t.y;
-                // coefficient gradient g_coeff = gW conj(P)
-                const float2 gc = cmul_conj(g, P);
-                if (q == 0) g_zonal[oir] = gc.x;
-                else if (sign == 0) {                         // f = B + q: sph[b = q-1] direct
-                    g_sph[(oir * B + (q - 1)) * 2] = gc.x;
-                    g_sph[(oir * B + (q - 1)) * 2 + 1] = gc.y;
-                } else {                                      // f = B - q: conj(sph[b = q-1]) -> add conj(g_coeff)
-                    g_sph[(oir * B + (q - 1)) * 2] += gc.x;
-                    g_sph[(oir * B + (q - 1)) * 2 + 1] -= gc.y;
+        } else {
+            // coefficient gradient g_coeff = gW conj(P); phase gradient pieces Im(conj(P) gP), gP = gW conj(coeff)
+            for (int q = 0; q <= B; ++q) {
+                float s = 0.f, co = 1.f;
+                if (ftype == 1) sincosf(phase[(size_t)oi * (B + 1) + q], &s, &co);
+                const float2 P = make_float2(co, s);
+                const float2 gp = g[B + q];
+                const float2 cp = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B + q);     // without the phase
+                float2 gP = cmul_conj(gp, cp);
+                const float2 gcp = cmul_conj(gp, P);
+                float acc = P.x * gP.y - P.y * gP.x;
+                if (q == 0) {
+                    g_zonal[oir] = gcp.x;
+                } else {
+                    const float2 gm = g[B - q];
+                    const float2 cm = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B - q);
+                    gP = cmul_conj(gm, cm);
+                    const float2 gcm = cmul_conj(gm, P);
+                    acc += P.x * gP.y - P.y * gP.x;
+                    // f = B+q reads sph[q-1] directly, f = B-q its conjugate
+                    g_sph[(oir * B + (q - 1)) * 2] = gcp.x + gcm.x;
+                    g_sph[(oir * B + (q - 1)) * 2 + 1] = gcp.y - gcm.y;
                 }
+                gph[(pair * 8 + r) * (kMaxB + 1) + q] = acc;
             }
-            // d/dphi exp(i phi) = i P ; Re(conj(i P) gP) = Re((-i conj(P)) gP) = Im(conj(P) gP)... expanded:
-            acc += (P.x * gP.y - P.y * gP.x);
         }
-        if (ftype == 1) g_phase[(size_t)oi * (B + 1) + q] = acc;
+    }
+    __syncthreads();
+    if (valid && ftype == 1 && r == 0) {
+        for (int q = 0; q <= B; ++q) {
+            float acc = 0.f;
+            for (int rr = 0; rr < R; ++rr) acc += gph[(pair * 8 + rr) * (kMaxB + 1) + q];
+            g_phase[(size_t)oi * (B + 1) + q] = acc;
+        }
     }
 }
 
 int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream) {
+    if (d->R > 8 || d->B > kMaxB) return FC_ERR_UNSUPPORTED;
     const int total = d->O * d->I;
-    hipLaunchKernelGGL(fc_filter_param_grads_kernel, dim3((total + 127) / 128), dim3(128), 0, stream,
+    hipLaunchKernelGGL(fc_filter_param_grads_kernel, dim3((total + kGradPairs - 1) / kGradPairs), dim3(kGradPairs * d->R), 0, stream,
                        reinterpret_cast<const float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I,
                        d->R, d->B);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
