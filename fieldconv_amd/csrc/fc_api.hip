@@ -44,12 +44,12 @@ int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0;
 
 size_t fc_packed_filter_floats_fwd(const fc_dims* d) {
     if (!fc::dims_valid(d)) return 0;
-    return fc::packed_image_floats(d->O, d->R * d->I, 2 * d->B + 1, fc::split_mode());
+    return fc::packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, fc::split_mode());
 }
 
 size_t fc_packed_filter_floats_bwd(const fc_dims* d) {
     if (!fc::dims_valid(d)) return 0;
-    return fc::packed_image_floats(d->I, d->R * d->O, 2 * d->B + 1, fc::split_mode());
+    return fc::packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, fc::split_mode());
 }
 
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream) {

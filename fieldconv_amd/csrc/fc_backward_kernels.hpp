@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     const MmaGeom& mg = a.gd;
     const int KS = mg.KS, IP = mg.MP, I = a.I, O = a.O;
     const int KP = a.g.KP;                                  // k entries per row of the kept H slabs (fp32 blocking)
-    float* const hre = reinterpret_cast<float*>(smem);     // fp32: [16][KS] floats (re), split: [4][16][KS] halves
+    float* const hre = reinterpret_cast<float*>(smem);     // fp32: [16][KS] floats (re), split: [16][KS] halves, planes interleaved
     float* const him = hre + kTile * KS;                    // fp32: [16][KS] floats (im)
-    float* const part = him + kTile * KS;                   // [NKP][16][IP][2]
+    float* const part = hre + slab_floats(mg);              // [NKP][16][IP][2]
     float* const vscale = part + partial_floats(mg.NKP, IP);   // split: 2 buffers of [16] vertex scales + [16] inverses
 
     const int tid = threadIdx.x;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     float* const ring = vscale + 4 * kTile + wave * NR * 256;   // factored: [NR][256] floats per wavefront
     float* vs = vscale;                                          // scale buffer of the current frequency group
 
-    for (int idx = tid; idx < 2 * kTile * KS; idx += kThreads) hre[idx] = 0.f;
+    for (int idx = tid; idx < slab_floats(mg); idx += kThreads) hre[idx] = 0.f;
     __syncthreads();
 
     const int it = wave % mg.NMT;
@@ -280,25 +280,20 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             }
                         }
                     } else {
-                        if (lane < O) {
-                            lds_f16* const sp = (lds_f16*)hre;
-                            const int splane = kTile * KS;
-                            const f32x2 sv = {scale, scale};
-                            int o0 = wave * KS + lane;       // LDS (halves)
-                            int d0 = wave * a.KD + lane;     // kept slab (floats): re plane, im plane 16 rows further
+                        if (lane < mg.KI) {
+                            lds_u32* const row = (lds_u32*)hre + wave * (KS / 2);    // LDS row of my vertex, see fc_forward_kernels.hpp
+                            int o0 = split_pair_offset(lane);
+                            int d0 = wave * a.KD + lane;                      // kept slab (floats): re plane, im plane 16 rows further
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
-                                dst[d0] = h[r][ff].x;
-                                dst[d0 + kTile * a.KD] = h[r][ff].y;
-                                const f32x2 v = h[r][ff] * sv;
-                                _Float16 rh, rl, ih, il;
-                                split_halves(v.x, rh, rl);
-                                split_halves(v.y, ih, il);
-                                sp[o0] = rh;
-                                sp[o0 + splane] = rl;
-                                sp[o0 + 2 * splane] = ih;
-                                sp[o0 + 3 * splane] = il;
-                                o0 += O;
+                                if (lane < O) {
+                                    dst[d0] = h[r][ff].x;
+                                    dst[d0 + kTile * a.KD] = h[r][ff].y;
+                                }
+                                f16x2 hi, lo;
+                                split_halves2(h[r][ff], scale, hi, lo);
+                                split_pair_store(row, o0, hi, lo, lane);
+                                o0 += 2 * mg.KI;
                                 d0 += O;
                                 asm volatile("" : "+v"(o0), "+v"(d0));
                             }
@@ -360,8 +355,8 @@ struct BwdPlan {
 inline BwdPlan plan_backward(const fc_dims* d, bool split) {
     BwdPlan p;
     p.F = 2 * d->B + 1;
-    p.g = make_mma_geom(d->I, d->R * d->O);
-    p.gd = make_mma_geom(d->I, d->R * d->O, split);
+    p.g = make_mma_geom(d->I, d->R, d->O);
+    p.gd = make_mma_geom(d->I, d->R, d->O, split);
     p.IP = p.g.MP;
     p.KP = p.g.KP;
     p.ntiles = (d->N + kTile - 1) / kTile;
@@ -373,7 +368,7 @@ inline BwdPlan plan_backward(const fc_dims* d, bool split) {
     p.KD = p.g.KP + 4;
     p.slab_floats = 2 * kTile * p.KD;
     p.slab_stride = round_up(p.slab_floats, 256);
-    p.lds_data = (size_t)(2 * kTile * p.gd.KS + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
+    p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
     p.lds_filter = (size_t)(2 * p.slab_stride + 2 * p.IP * kTile) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
@@ -389,7 +384,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.N = d->N; a.I = d->I; a.O = d->O;
     a.g = p.g;
     a.gd = p.gd;
-    a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R * d->O, p.F, p.gd.split != 0) * sizeof(float));
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R, d->O, p.F, p.gd.split != 0) * sizeof(float));
     a.ntiles = p.ntiles;
     a.ngw = p.ngw;
     a.KD = p.KD;

@@ -61,13 +61,13 @@ struct FwdLds {
 __device__ __forceinline__ FwdLds forward_lds(char* smem, const MmaGeom& g, int slabs) {
     FwdLds l;
     l.slab = reinterpret_cast<float*>(smem);
-    l.part = l.slab + slabs * 2 * kTile * g.KS;
+    l.part = l.slab + slabs * slab_floats(g);
     l.vscale = l.part + (slabs == 2 ? 0 : partial_floats(g.NKP, g.MP));
     l.end = l.vscale + 4 * kTile;
     return l;
 }
 __host__ inline size_t forward_lds_floats(const MmaGeom& g, int slabs) {
-    return (size_t)slabs * 2 * kTile * g.KS + (slabs == 2 ? 0 : partial_floats(g.NKP, g.MP)) + 4 * kTile;
+    return (size_t)slabs * slab_floats(g) + (slabs == 2 ? 0 : partial_floats(g.NKP, g.MP)) + 4 * kTile;
 }
 
 // Phase B for one frequency group: slabs -> MFMA accumulate.  c[r][ff] holds this lane's response.
@@ -109,6 +109,7 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
     } else {
     // ---- split mode: this wavefront's vertex gets one power-of-two scale for the whole group
     float mx = 0.f;
+    if (!(a.dbg & 16))
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -131,10 +132,8 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
         vs[wave] = scale;          // read after the slab barriers below
         vs[kTile + wave] = inv;
     }
-    const int splane = kTile * g.KS;
     const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
     const int planes0 = g.MP * 4;                                  // bytes: the planes follow the MP row scales
-    const f32x2 sv = {scale, scale};
 #pragma unroll
     for (int ff = 0; ff < MG; ++ff) {
         const int f = f0 + ff;
@@ -143,22 +142,19 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
             // on slab t writes slab t+1 into the other buffer at once, and that buffer is free because every
             // wavefront passed barrier t only after its MFMAs on slab t-1.  One barrier per slab instead of two,
             // and the conversions of one wavefront overlap the MFMAs of the others.
-            lds_f16* const sp = (lds_f16*)l.slab + buf * 4 * splane;
-            if (lane < a.I) {
-                // one running LDS offset, advanced by I per ring; the empty asm keeps hipcc from materialising
-                // all 4*R addresses in registers for the whole kernel (they would spill)
-                int o0 = wave * g.KS + lane;
+            lds_f16* const sp = (lds_f16*)(l.slab + buf * slab_floats(g));
+            if (lane < g.KI && !(a.dbg & 4)) {
+                // element k = r*KI + lane of my vertex's row (fc_tile.hpp: split_pair_store); one running offset
+                // advanced by a ring per step -- the empty asm keeps hipcc from materialising all R addresses for
+                // the whole kernel.  Lanes in [I, KI) hold copies of channel 0 and land in padding the filter zeroes.
+                lds_u32* const row = (lds_u32*)sp + wave * (g.KS / 2);
+                int o0 = split_pair_offset(lane);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const f32x2 v = c[r][ff] * sv;
-                    _Float16 rh, rl, ih, il;
-                    split_halves(v.x, rh, rl);
-                    split_halves(v.y, ih, il);
-                    sp[o0] = rh;
-                    sp[o0 + splane] = rl;
-                    sp[o0 + 2 * splane] = ih;
-                    sp[o0 + 3 * splane] = il;
-                    o0 += a.I;
+                    f16x2 hi, lo;
+                    split_halves2(c[r][ff], scale, hi, lo);
+                    split_pair_store(row, o0, hi, lo, lane);
+                    o0 += 2 * g.KI;
                     asm volatile("" : "+v"(o0));
                 }
             }
@@ -183,6 +179,7 @@ __device__ __forceinline__ void forward_epilogue(const FwdLds& l, float* part, c
     const int mt = wave % g.NMT, kp = wave / g.NMT;
     if (kp < g.NKP) store_partial(part, g, mt, kp, lane, acc_re, acc_im);
     __syncthreads();
+    if (!(a.dbg & 8))
     for (int idx = wave * kWave + lane; idx < kTile * a.O; idx += kThreads) {
         const int v = idx / a.O, o = idx - v * a.O;
         const int n = tile * kTile + v;
@@ -216,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
     const int I = a.I;
 
     // zero the slab once: the k padding [R*I, KP) is never written again and must not hold NaNs
-    for (int idx = tid; idx < a.slabs * 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    for (int idx = tid; idx < a.slabs * slab_floats(a.g); idx += kThreads) l.slab[idx] = 0.f;
     __syncthreads();
 
     const int cl = lane < I ? lane : 0;      // lanes >= I gather channel 0 and are never stored
@@ -274,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
                 }
             forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
-        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * 2 * kTile * a.g.KS : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
                                 acc_im, gy_);
         buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
@@ -306,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     float* const ring = l.end + wave * NR * 256;                 // [NR][256] floats, this wavefront's
     const int I = a.I;
 
-    for (int idx = tid; idx < a.slabs * 2 * kTile * a.g.KS; idx += kThreads) l.slab[idx] = 0.f;
+    for (int idx = tid; idx < a.slabs * slab_floats(a.g); idx += kThreads) l.slab[idx] = 0.f;
     __syncthreads();
 
     const int cl = lane < I ? lane : 0;
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
         first_rows(nend - nbeg, pxa, pxb);       // the next tile's first source rows fly during the epilogue
-        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * 2 * kTile * a.g.KS : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
                                 acc_im, gy_);
         buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
@@ -476,13 +473,13 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
                       const fc_dims* d, bool factored, hipStream_t stream) {
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
-    a.g = make_mma_geom(d->O, d->R * d->I, SPLIT);
+    a.g = make_mma_geom(d->O, d->R, d->I, SPLIT);
     a.ntiles = (d->N + kTile - 1) / kTile;
-    a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R * d->I, 2 * d->B + 1, SPLIT) * sizeof(float));
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, SPLIT) * sizeof(float));
     { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.ring_chunks = factored ? kRingChunks : 0;
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;
-    a.slabs = (SPLIT && partial_floats(a.g.NKP, a.g.MP) <= 2 * kTile * a.g.KS &&
+    a.slabs = (SPLIT && partial_floats(a.g.NKP, a.g.MP) <= slab_floats(a.g) &&
                forward_lds_floats(a.g, 2) * sizeof(float) + ring <= kMaxLds) ? 2 : 1;
     const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;

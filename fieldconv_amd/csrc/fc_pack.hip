@@ -56,8 +56,8 @@ template <bool FROM_PARAMS, bool WITH_PHASE>
 __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, const float* __restrict__ zonal,
                                                const float* __restrict__ sph, const float* __restrict__ phase,
                                                const PackArgs& a, bool is_bwd, int m, int k, int f) {
-    const int inner = is_bwd ? a.O : a.I;
-    const int r = k / inner, c = k - r * inner;
+    const int KI = is_bwd ? a.gb.KI : a.gf.KI;          // k = r*KI + c, channels c >= their count are padding
+    const int r = k / KI, c = k - r * KI;
     const int o = is_bwd ? c : m, i = is_bwd ? m : c;
     if (o >= a.O || i >= a.I || r >= a.R) return make_float2(0.f, 0.f);
     const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!WITH_PHASE && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.I, o, i, r, f)
@@ -129,8 +129,8 @@ static int launch_pack(const float* w_eff, const float* zonal, const float* sph,
                        float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
     PackArgs a;
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
-    a.gf = make_mma_geom(d->O, d->R * d->I, split_mode());
-    a.gb = make_mma_geom(d->I, d->R * d->O, split_mode());
+    a.gf = make_mma_geom(d->O, d->R, d->I, split_mode());
+    a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
     a.blocks_f = pack_blocks(a.gf, a.F);
     const unsigned blocks = a.blocks_f + pack_blocks(a.gb, a.F);
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,

@@ -13,25 +13,28 @@ namespace fc {
 // Two arithmetic modes for the contraction (same results to fp32 rounding level, see mma_slab_split):
 //   fp32   v_mfma_f32_16x16x4_f32 on fp32 operands; k blocks of 16, slab = 2 planes of floats
 //   split  v_mfma_f32_16x16x32_f16 on operands split into two halves (hi + lo); k blocks of 32,
-//          slab = 4 planes of halves.  KP / KS are then counted in halves; the slab occupies
-//          128 * KS bytes in both modes.
+//          slab = one row per vertex holding the four planes (re_hi, re_lo, im_hi, im_lo) interleaved
+//          in 16-byte fragments: [k / 8][plane][k % 8] halves, so that a plane is an immediate offset.
+// The contraction index is k = r * KI + c (ring r, channel c).
 struct MmaGeom {
     int MP;     // ceil16(M)
-    int KP;     // k entries per row: ceil16(K) (fp32) or ceil32(K) (split)
-    int KS;     // LDS slab row stride in elements, slab_stride(KP)
+    int KI;     // channel stride inside k: the channel count (fp32) or ceil8 of it (split)
+    int KP;     // k entries per row: ceil16(R*KI) (fp32) or ceil32(R*KI) (split)
+    int KS;     // LDS slab row stride: floats per plane row, KP + 8 (fp32); halves per vertex row, 4*KP + 8 (split)
     int NMT;    // MP / 16 output tiles
     int NKP;    // k partitions (wavefronts per output tile)
     int KST;    // k blocks: KP / 16 (fp32) or KP / 32 (split)
     int split;  // 1: split-half mode
 };
 
-__host__ __device__ inline MmaGeom make_mma_geom(int M, int K, bool split = false) {
+__host__ __device__ inline MmaGeom make_mma_geom(int M, int R, int channels, bool split = false) {
     MmaGeom g;
     const int kblock = split ? 32 : 16;
     g.split = split ? 1 : 0;
     g.MP = round_up(M, 16);
-    g.KP = round_up(K, kblock);
-    g.KS = slab_stride(g.KP);
+    g.KI = split ? round_up(channels, 8) : channels;
+    g.KP = round_up(R * g.KI, kblock);
+    g.KS = split ? 4 * g.KP + 8 : slab_stride(g.KP);      // both: 16-byte fragment reads of 16 rows hit distinct banks
     g.NMT = g.MP / 16;
     g.KST = g.KP / kblock;
     g.NKP = kWaves / g.NMT;
@@ -43,10 +46,13 @@ __host__ __device__ inline MmaGeom make_mma_geom(int M, int K, bool split = fals
 // Floats in the packed filter image of one contraction (F frequencies, M rows, K entries per row).
 //   fp32 : [F][2 planes re,im][MP][KP] floats
 //   split: [MP] inverse row scales (floats), then [F][4 planes re_hi,re_lo,im_hi,im_lo][MP][KP] halves
-__host__ __device__ inline size_t packed_image_floats(int M, int K, int F, bool split) {
-    const MmaGeom g = make_mma_geom(M, K, split);
+__host__ __device__ inline size_t packed_image_floats(int M, int R, int channels, int F, bool split) {
+    const MmaGeom g = make_mma_geom(M, R, channels, split);
     return split ? (size_t)g.MP + (size_t)F * 2 * g.MP * g.KP : (size_t)F * 2 * g.MP * g.KP;
 }
+
+// Floats of one LDS slab buffer (16 vertices).
+__host__ __device__ inline int slab_floats(const MmaGeom& g) { return g.split ? kTile * g.KS / 2 : 2 * kTile * g.KS; }
 
 // Which mode the library runs in: FC_MFMA=f32 selects the fp32 MFMA, anything else the split mode.
 bool split_mode();
@@ -134,20 +140,43 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
+// The same for a complex value scaled by s: hi = (re_hi, im_hi), lo = (re_lo, im_lo).  In vector form hipcc
+// emits v_cvt_pk_f16_f32 (round to nearest even) and folds the scale into the residual's packed FMA.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_halves2(f32x2 v, float s, f16x2& hi, f16x2& lo) {
+    const f32x2 vs = v * f32x2{s, s};
+    hi = __builtin_convertvector(vs, f16x2);
+    lo = __builtin_convertvector(vs - __builtin_convertvector(hi, f32x2), f16x2);
+}
+// Writing one ring of a slab row (lane = channel c, element k = r*KI + c).  Neighbouring lanes exchange
+// their packed halves over DPP so that every lane stores two full dwords with ONE ds_write2_b32 instead of
+// four 2-byte stores (the LDS instruction rate of the 16 wavefronts bounds this phase):
+//   even lane: (re_hi[c], re_hi[c+1]) -> plane 0, (re_lo[c], re_lo[c+1]) -> plane 1
+//   odd lane : (im_hi[c-1], im_hi[c]) -> plane 2, (im_lo[c-1], im_lo[c]) -> plane 3
+// split_pair_offset: dword offset of the lane's first store inside the row (ring 0); the second is 4 dwords on.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ int split_pair_offset(int c) { return 16 * (c >> 3) + 8 * (c & 1) + ((c & 7) >> 1); }
+__device__ __forceinline__ void split_pair_store(lds_u32* row, int dword_offset, f16x2 hi, f16x2 lo, int lane) {
+    const uint32_t h = __builtin_bit_cast(uint32_t, hi), l = __builtin_bit_cast(uint32_t, lo);
+    const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)h, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
+    const uint32_t lp = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0xB1, 0xF, 0xF, true);
+    const uint32_t sel = (lane & 1) ? 0x03020706u : 0x05040100u;    // odd: (partner.hi16, own.hi16); even: (own.lo16, partner.lo16)
+    row[dword_offset] = __builtin_amdgcn_perm(hp, h, sel);
+    row[dword_offset + 4] = __builtin_amdgcn_perm(lp, l, sel);
+}
 
 // One slab through the matrix pipe in split mode.  wimg: descriptor of the packed image, f_bytes: byte
-// offset of this frequency's four planes [4][MP][KP] halves in it; sp: the slab's four planes
-// [4][16][KS] halves (LDS).  Lane l holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15],
-// j = 0..7, as one 16-byte fragment.
+// offset of this frequency's four planes [4][MP][KP] halves in it; sp: the slab, [16][KS] halves with
+// the planes interleaved per 8-k fragment (LDS).  Lane l holds A[row l&15][k = 8(l>>4)+j] and
+// B[k = 8(l>>4)+j][col l&15], j = 0..7, as one 16-byte fragment.
 __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const lds_f16* sp, const MmaGeom& g, int mt, int kp,
                                                int lane, f32x4& acc_re, f32x4& acc_im) {
     const int fr = lane & 15, fq = lane >> 4;
     const int wplane = g.MP * g.KP * 2;                 // bytes
-    const int splane = kTile * g.KS;                    // halves
     const int wv = ((mt * 16 + fr) * g.KP + 8 * fq) * 2;
-    const lds_f16* s0 = sp + fr * g.KS + 8 * fq;
+    const lds_f16* s0 = sp + fr * g.KS + 32 * fq;       // fragment (k block 4*kb + fq, plane p) at + 128*kb + 8*p halves
     auto ldw = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
-    auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + plane * splane + 32 * kb); };
+    auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + 128 * kb + 8 * plane); };
     const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     u32x4 wrh = ldw(0, kp), wrl = ldw(1, kp), wih = ldw(2, kp), wil = ldw(3, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
