@@ -173,20 +173,26 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     const float* rp = rec_ptr(s);
                     const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                     const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
-                    const f32x2 gv = f32x2{gcur.x, gcur.y}, gs = f32x2{gcur.y, -gcur.x};
+                    const f32x2 gv = f32x2{gcur.x, gcur.y};
                     gcur = ggy[(size_t)d2 * O + ol];
                     const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
+                    // z_f = g conj(ph_f) in two passes, then the ring updates (see fc_forward_kernels.hpp)
+                    f32x2 ph[MG], z[MG];
 #pragma unroll
-                    for (int ff = 0; ff < MG; ++ff) {
-                        const int f = f0 + ff;
-                        if (f < F) {
-                            const f32x2 ph = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
-                            f32x2 z = f32x2{ph.x, ph.x} * gv;
-                            z = __builtin_elementwise_fma(f32x2{ph.y, ph.y}, gs, z);
-                            h[Q][ff] = __builtin_elementwise_fma(w0v, z, h[Q][ff]);
-                            h[Q + 1][ff] = __builtin_elementwise_fma(w1v, z, h[Q + 1][ff]);
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) {
+                            ph[ff] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * (f0 + ff));
+                            z[ff] = cmul_conj_pk_step1(gv, ph[ff]);
                         }
-                    }
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) z[ff] = cmul_conj_pk_step2(gv, ph[ff], z[ff]);
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) h[Q][ff] = __builtin_elementwise_fma(w0v, z[ff], h[Q][ff]);
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) h[Q + 1][ff] = __builtin_elementwise_fma(w1v, z[ff], h[Q + 1][ff]);
                 };
                 if (!(a.dbg & 1)) {
                     static_for<0, R - 1>([&](auto qc) {

@@ -22,6 +22,7 @@ constexpr int kThreads = kWave * kWaves;
 constexpr float kOriginEps = 1e-7f;   // reference utils/field.py:8
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -80,28 +81,53 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {   // a * conj(
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// All 2B+1 rotated copies xt[f] = z * u^(f-B) (reference nn/field_conv.py:128-130).
+// Complex products on packed fp32, two instructions each: a v_pk_mul_f32 with the real part of one
+// factor broadcast, then a v_pk_fma_f32 that takes the imaginary part broadcast, the other factor
+// with its halves swapped (op_sel) and one half of the product negated (neg_lo / neg_hi).  hipcc does
+// not fold the per-half negation into the modifier (it materialises (-im, re) with v_xor + v_mov,
+// ~20 % of the gather loop), hence the inline instruction; it has no tied operands and no side effects.
+// The two steps are also available separately so that a caller with several independent products can
+// issue all first steps before the second ones (back-to-back dependent packed ops cost a wait state).
+__device__ __forceinline__ f32x2 cmul_pk_step1(f32x2 a, f32x2 b) { return f32x2{a.x, a.x} * b; }
+__device__ __forceinline__ f32x2 cmul_pk_step2(f32x2 a, f32x2 b, f32x2 t) {
+    f32x2 z;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(z) : "v"(a), "v"(b), "v"(t));
+    return z;       // (t.x - a.y b.y, t.y + a.y b.x)
+}
+__device__ __forceinline__ f32x2 cmul_pk(f32x2 a, f32x2 b) {          // a * b
+    return cmul_pk_step2(a, b, cmul_pk_step1(a, b));
+}
+__device__ __forceinline__ f32x2 cmul_conj_pk_step1(f32x2 a, f32x2 b) { return f32x2{b.x, b.x} * a; }
+__device__ __forceinline__ f32x2 cmul_conj_pk_step2(f32x2 a, f32x2 b, f32x2 t) {
+    f32x2 z;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(z) : "v"(b), "v"(a), "v"(t));
+    return z;       // (t.x + b.y a.y, t.y - b.y a.x)
+}
+__device__ __forceinline__ f32x2 cmul_conj_pk(f32x2 a, f32x2 b) {     // a * conj(b)
+    return cmul_conj_pk_step2(a, b, cmul_conj_pk_step1(a, b));
+}
+
+// All 2B+1 rotated copies xt[f] = z * u^(f-B) (reference nn/field_conv.py:128-130), u = exp(-i angle(z)).
 // Slot B+1 (m = +1) is z*u = |z|, stored as (|z|, 0); inside the origin box u = 1 and every copy is z
 // itself.  Valid for |z|^2 within the fp32 range (|z| < 1.8e19).
 template <int B>
-__device__ __forceinline__ void rotate_all(float2 z, float2 (&xt)[2 * B + 1]) {
-    const bool org = is_origin(z);
-    const float n2 = z.x * z.x + z.y * z.y;
-    const float inv = org ? 0.f : __frsqrt_rn(n2);
-    const float2 u = org ? make_float2(1.f, 0.f) : make_float2(z.x * inv, -z.y * inv);
+__device__ __forceinline__ void rotate_all(f32x2 z, f32x2 (&xt)[2 * B + 1]) {
+    const bool org = (fabsf(z.x) < kOriginEps) && (fabsf(z.y) < kOriginEps);
+    const f32x2 sq = z * z;
+    const float n2 = sq.x + sq.y;
+    const float inv = __frsqrt_rn(n2);
+    const f32x2 u = org ? f32x2{1.f, 0.f} : f32x2{z.x * inv, -z.y * inv};
     xt[B] = z;
     if (B >= 1) {
-        xt[B + 1] = org ? z : make_float2(n2 * inv, 0.f);
-        xt[B - 1] = cmul_conj(z, u);
+        xt[B + 1] = org ? z : f32x2{n2 * inv, 0.f};
+        xt[B - 1] = cmul_conj_pk(z, u);
     }
 #pragma unroll
     for (int m = 2; m <= B; ++m) {
-        xt[B + m] = cmul(xt[B + m - 1], u);
-        xt[B - m] = cmul_conj(xt[B - m + 1], u);
+        xt[B + m] = cmul_pk(xt[B + m - 1], u);
+        xt[B - m] = cmul_conj_pk(xt[B - m + 1], u);
     }
 }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Complex multiply-accumulate on packed fp32: acc (re,im) += s * x with s a WAVE-UNIFORM complex
 // number in an SGPR pair and x a per-lane complex number.  Plain wave64 FMAs issue every 4 cycles on

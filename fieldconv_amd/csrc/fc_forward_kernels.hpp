@@ -250,8 +250,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
             auto slot = [&](const int e, float2& xcur) {
                 const f32x2* __restrict__ Se = reinterpret_cast<const f32x2*>(gsten + (size_t)e * ROWF);   // uniform
                 const int n3 = gnbr[min(e + 3, last)];
-                float2 xt[F];
-                rotate_all<B>(xcur, xt);
+                f32x2 xt[F];
+                rotate_all<B>(f32x2{xcur.x, xcur.y}, xt);
                 xcur = gx_[(size_t)nx * I + cl];
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
                     for (int ff = 0; ff < MG; ++ff) {
                         const int f = f0 + ff;
                         if (f < F) {
-                            cmac_sx(c[r][ff], Se[r * F + f], f32x2{xt[f].x, xt[f].y}, f32x2{-xt[f].y, xt[f].x});
+                            cmac_sx(c[r][ff], Se[r * F + f], xt[f], f32x2{-xt[f].y, xt[f].x});
                         }
                     }
                 nx = n3;
@@ -401,21 +401,28 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
                 const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                 const float w0 = head.y, w1 = head.z;
                 const int n2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);   // source two slots ahead
-                float2 xt[F];
-                rotate_all<B>(xcur, xt);
+                f32x2 xt[F];
+                rotate_all<B>(f32x2{xcur.x, xcur.y}, xt);
                 xcur = gx_[(size_t)n2 * I + cl];
                 const f32x2 w0v = f32x2{w0, w0}, w1v = f32x2{w1, w1};
+                // z_f = ph_f * xt_f in two passes over the frequencies, then the ring updates: no packed op
+                // directly follows the one it depends on
+                f32x2 ph[MG], z[MG];
 #pragma unroll
-                for (int ff = 0; ff < MG; ++ff) {
-                    const int f = f0 + ff;
-                    if (f < F) {
-                        const f32x2 ph = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
-                        f32x2 z = f32x2{ph.x, ph.x} * f32x2{xt[f].x, xt[f].y};
-                        z = __builtin_elementwise_fma(f32x2{ph.y, ph.y}, f32x2{-xt[f].y, xt[f].x}, z);
-                        c[Q][ff] = __builtin_elementwise_fma(w0v, z, c[Q][ff]);
-                        c[Q + 1][ff] = __builtin_elementwise_fma(w1v, z, c[Q + 1][ff]);
+                for (int ff = 0; ff < MG; ++ff)
+                    if (f0 + ff < F) {
+                        ph[ff] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * (f0 + ff));
+                        z[ff] = cmul_pk_step1(ph[ff], xt[f0 + ff]);
                     }
-                }
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff)
+                    if (f0 + ff < F) z[ff] = cmul_pk_step2(ph[ff], xt[f0 + ff], z[ff]);
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff)
+                    if (f0 + ff < F) c[Q][ff] = __builtin_elementwise_fma(w0v, z[ff], c[Q][ff]);
+#pragma unroll
+                for (int ff = 0; ff < MG; ++ff)
+                    if (f0 + ff < F) c[Q + 1][ff] = __builtin_elementwise_fma(w1v, z[ff], c[Q + 1][ff]);
             };
             // The records of a target are sorted by ring index, so the walk is R-1 consecutive runs, each
             // with statically indexed accumulators (no data-dependent register indexing, no switch).
