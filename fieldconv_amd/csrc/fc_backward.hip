@@ -5,7 +5,11 @@
 namespace fc {
 
 // ---------------------------------------------------------------------------------- filter gradient
-// T = 16x16 complex gW tiles owned by each wavefront (ceil(ngw / 16)); 8*T accumulator VGPRs.
+// T = 16x16 complex gW tiles owned by each wavefront (ceil(ngw / 16)).
+// The complex product H conj(X), H = a + ib, X = c + id, uses three real products instead of four
+// (Gauss): k1 = (a+b) c, k2 = a (c+d), k3 = b (c-d); re = k1 - k3 = ac + bd, im = k1 - k2 = bc - ad.
+// The X combinations are formed once per tile when the rotated features go to LDS, a+b costs one add
+// per fragment element: 12 MFMAs per 16 vertices and tile instead of 16, 12*T accumulator VGPRs.
 template <int T>
 __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ hdump, float2* __restrict__ ggwp /* [P][F][KP][IP] */,
@@ -13,9 +17,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MmaGeom& mg = a.g;
     const int KD = a.KD, KP = mg.KP, IP = mg.MP, I = a.I;
-    float* const slab0 = reinterpret_cast<float*>(smem);               // [2][slab_stride]: (hre | him) of a tile
-    float* const xtr = slab0 + 2 * a.slab_stride;                      // [IP][16]
-    float* const xti = xtr + IP * kTile;                               // [IP][16]
+    float* const slab0 = reinterpret_cast<float*>(smem);               // [2][slab_stride]: H of a tile, [16 vertices][KD] interleaved (re, im)
+    float* const xtr = slab0 + 2 * a.slab_stride;                      // [IP][16]  c
+    float* const xts = xtr + IP * kTile;                               // [IP][16]  c + d
+    float* const xtd = xts + IP * kTile;                               // [IP][16]  c - d
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -24,7 +29,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const int m = f - B;
     const int fr = lane & 15, fq = lane >> 4;
 
-    for (int idx = tid; idx < 2 * IP * kTile; idx += kThreads) xtr[idx] = 0.f;
+    for (int idx = tid; idx < 3 * IP * kTile; idx += kThreads) xtr[idx] = 0.f;
 
     // my gW tiles: u = wave + 16 n  ->  (row tile rt over k = (r,o), column tile ct over i)
     int gw_h[T], gw_x[T];       // wave-uniform LDS offsets, -1 when the slot is unused
@@ -32,15 +37,15 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     for (int n = 0; n < T; ++n) {
         const int u = wave + kWaves * n;
         const int rt = u / mg.NMT, ct = u - rt * mg.NMT;
-        gw_h[n] = (u < a.ngw) ? rt * 16 : -1;
+        gw_h[n] = (u < a.ngw) ? rt * 32 : -1;            // floats: 16 complex entries per row tile
         gw_x[n] = ct * 16 * kTile;
     }
-    const int h_lane = (4 * fq) * KD + fr;        // A fragment: H[vertex 4fq+s][k = rt*16 + fr]
+    const int h_lane = (4 * fq) * KD + 2 * fr;    // A fragment: H[vertex 4fq+s][k = rt*16 + fr], one 8-byte (re, im) read
     const int x_lane = fr * kTile + 4 * fq;       // B fragment: xt[i = ct*16 + fr][vertex 4fq..4fq+3]
 
-    f32x4 gre[T], gim[T];
+    f32x4 k1[T], k2[T], k3[T];
 #pragma unroll
-    for (int n = 0; n < T; ++n) { gre[n] = f32x4{0.f, 0.f, 0.f, 0.f}; gim[n] = gre[n]; }
+    for (int n = 0; n < T; ++n) { k1[n] = f32x4{0.f, 0.f, 0.f, 0.f}; k2[n] = k1[n]; k3[n] = k1[n]; }
 
     const int npieces = a.slab_stride / 256;      // 1 KiB DMA pieces per slab
     auto dma_slab = [&](const int tile, const int buf) {
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         __syncthreads();            // slab `buf` has landed (the barrier drains the DMA); previous tile's reads are done
         if (lane < IP) {
             xtr[lane * kTile + wave] = xt.x;
-            xti[lane * kTile + wave] = xt.y;
+            xts[lane * kTile + wave] = xt.x + xt.y;
+            xtd[lane * kTile + wave] = xt.x - xt.y;
         }
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
@@ -75,27 +81,24 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        const float* hre = slab0 + buf * a.slab_stride;
-        const float* him = hre + kTile * KD;
-        // gW += H^T . conj(xt):  re += Hre*Xre + Him*Xim ; im += Him*Xre - Hre*Xim
+        const float* hsl = slab0 + buf * a.slab_stride;
+        // gW += H^T . conj(xt)
         if (!(a.dbg & 4)) {
 #pragma unroll
             for (int n = 0; n < T; ++n) {
                 if (gw_h[n] >= 0) {
-                    const float4 xr4 = *reinterpret_cast<const float4*>(xtr + gw_x[n] + x_lane);
-                    const float4 xi4 = *reinterpret_cast<const float4*>(xti + gw_x[n] + x_lane);
-                    const float* ha = hre + gw_h[n] + h_lane;
-                    const float* hb = him + gw_h[n] + h_lane;
-                    const float a0 = ha[0], a1 = ha[KD], a2 = ha[2 * KD], a3 = ha[3 * KD];
-                    const float b0 = hb[0], b1 = hb[KD], b2 = hb[2 * KD], b3 = hb[3 * KD];
-                    gre[n] = mfma16(a0, xr4.x, gre[n]); gim[n] = mfma16(b0, xr4.x, gim[n]);
-                    gre[n] = mfma16(b0, xi4.x, gre[n]); gim[n] = mfma16(-a0, xi4.x, gim[n]);
-                    gre[n] = mfma16(a1, xr4.y, gre[n]); gim[n] = mfma16(b1, xr4.y, gim[n]);
-                    gre[n] = mfma16(b1, xi4.y, gre[n]); gim[n] = mfma16(-a1, xi4.y, gim[n]);
-                    gre[n] = mfma16(a2, xr4.z, gre[n]); gim[n] = mfma16(b2, xr4.z, gim[n]);
-                    gre[n] = mfma16(b2, xi4.z, gre[n]); gim[n] = mfma16(-a2, xi4.z, gim[n]);
-                    gre[n] = mfma16(a3, xr4.w, gre[n]); gim[n] = mfma16(b3, xr4.w, gim[n]);
-                    gre[n] = mfma16(b3, xi4.w, gre[n]); gim[n] = mfma16(-a3, xi4.w, gim[n]);
+                    const float4 c4 = *reinterpret_cast<const float4*>(xtr + gw_x[n] + x_lane);
+                    const float4 s4 = *reinterpret_cast<const float4*>(xts + gw_x[n] + x_lane);
+                    const float4 d4 = *reinterpret_cast<const float4*>(xtd + gw_x[n] + x_lane);
+                    const float* ha = hsl + gw_h[n] + h_lane;
+                    const float2 h0 = *reinterpret_cast<const float2*>(ha), h1 = *reinterpret_cast<const float2*>(ha + KD);
+                    const float2 h2 = *reinterpret_cast<const float2*>(ha + 2 * KD), h3 = *reinterpret_cast<const float2*>(ha + 3 * KD);
+                    const float a0 = h0.x, a1 = h1.x, a2 = h2.x, a3 = h3.x;
+                    const float b0 = h0.y, b1 = h1.y, b2 = h2.y, b3 = h3.y;
+                    k1[n] = mfma16(a0 + b0, c4.x, k1[n]); k2[n] = mfma16(a0, s4.x, k2[n]); k3[n] = mfma16(b0, d4.x, k3[n]);
+                    k1[n] = mfma16(a1 + b1, c4.y, k1[n]); k2[n] = mfma16(a1, s4.y, k2[n]); k3[n] = mfma16(b1, d4.y, k3[n]);
+                    k1[n] = mfma16(a2 + b2, c4.z, k1[n]); k2[n] = mfma16(a2, s4.z, k2[n]); k3[n] = mfma16(b2, d4.z, k3[n]);
+                    k1[n] = mfma16(a3 + b3, c4.w, k1[n]); k2[n] = mfma16(a3, s4.w, k2[n]); k3[n] = mfma16(b3, d4.w, k3[n]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -109,9 +112,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
             const int ct16 = gw_x[n] / kTile;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int k = gw_h[n] + 4 * fq + jj;
+                const int k = gw_h[n] / 2 + 4 * fq + jj;
                 const int i = ct16 + fr;
-                ggwp[(((size_t)blockIdx.x * F + f) * KP + k) * IP + i] = make_float2(gre[n][jj], gim[n][jj]);
+                ggwp[(((size_t)blockIdx.x * F + f) * KP + k) * IP + i] = make_float2(k1[n][jj] - k3[n][jj], k1[n][jj] - k2[n][jj]);
             }
         }
     }

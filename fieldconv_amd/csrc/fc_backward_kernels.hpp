@@ -39,9 +39,10 @@ struct BwdArgs {
     uint32_t wpk_bytes;  // size of the packed backward filter image
     int ntiles;
     int ngw;             // KST * NMT 16x16 gW tiles per frequency
-    int KD;              // row stride (floats) of the H slabs kept for the filter kernel: KP + 4, so that the
-                         // filter kernel's 4-byte A-fragment reads (rows 4 apart per lane group) hit distinct banks
-    int slab_floats;     // 2 * 16 * KD
+    int KD;              // row stride (floats) of the H slabs kept for the filter kernel, one row of interleaved
+                         // (re, im) pairs per vertex: 2*KP + 8, so that the filter kernel's 8-byte A-fragment reads
+                         // (rows 4 apart per lane group) hit distinct banks
+    int slab_floats;     // 16 * KD
     int slab_stride;     // floats between consecutive (tile, f) slabs in hdump (multiple of 256)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
 };
@@ -278,24 +279,24 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             }
                         }
                         __syncthreads();
-                        {   // 16 B per thread, rows re-strided to KD
-                            const int k4n = KP / 4;
-                            for (int idx = tid; idx < 2 * kTile * k4n; idx += kThreads) {
-                                const int row = idx / k4n, k4 = idx - row * k4n;          // row = plane * 16 + vertex
-                                *reinterpret_cast<float4*>(dst + row * a.KD + 4 * k4) = *reinterpret_cast<const float4*>(hre + row * KS + 4 * k4);
+                        {   // 16 B per thread: two (re, im) pairs of a vertex row, rows re-strided to KD
+                            const int k2n = KP / 2;
+                            for (int idx = tid; idx < kTile * k2n; idx += kThreads) {
+                                const int row = idx / k2n, k2 = idx - row * k2n;
+                                const float2 re = *reinterpret_cast<const float2*>(hre + row * KS + 2 * k2);
+                                const float2 im = *reinterpret_cast<const float2*>(him + row * KS + 2 * k2);
+                                *reinterpret_cast<float4*>(dst + row * a.KD + 4 * k2) = make_float4(re.x, im.x, re.y, im.y);
                             }
                         }
                     } else {
                         if (lane < mg.KI) {
                             lds_u32* const row = (lds_u32*)hre + wave * (KS / 2);    // LDS row of my vertex, see fc_forward_kernels.hpp
                             int o0 = split_pair_offset(lane);
-                            int d0 = wave * a.KD + lane;                      // kept slab (floats): re plane, im plane 16 rows further
+                            float2* const dst2 = reinterpret_cast<float2*>(dst);
+                            int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
-                                if (lane < O) {
-                                    dst[d0] = h[r][ff].x;
-                                    dst[d0 + kTile * a.KD] = h[r][ff].y;
-                                }
+                                if (lane < O && !(a.dbg & 8)) dst2[d0] = make_float2(h[r][ff].x, h[r][ff].y);
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
                                 split_pair_store(row, o0, hi, lo, lane);
@@ -371,12 +372,12 @@ inline BwdPlan plan_backward(const fc_dims* d, bool split) {
     if (P < 1) P = 1;
     if (P > p.ntiles) P = p.ntiles;
     p.P = P;
-    p.KD = p.g.KP + 4;
-    p.slab_floats = 2 * kTile * p.KD;
+    p.KD = 2 * p.g.KP + 8;
+    p.slab_floats = kTile * p.KD;
     p.slab_stride = round_up(p.slab_floats, 256);
     p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
-    p.lds_filter = (size_t)(2 * p.slab_stride + 2 * p.IP * kTile) * sizeof(float);
+    p.lds_filter = (size_t)(2 * p.slab_stride + 3 * p.IP * kTile) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
     p.ok = p.lds_data <= kMaxLds && p.lds_filter <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves &&
