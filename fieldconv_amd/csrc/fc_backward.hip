@@ -18,9 +18,11 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const MmaGeom& mg = a.g;
     const int KD = a.KD, KP = mg.KP, IP = mg.MP, I = a.I;
     float* const slab0 = reinterpret_cast<float*>(smem);               // [2][slab_stride]: H of a tile, [16 vertices][KD] interleaved (re, im)
-    float* const xtr = slab0 + 2 * a.slab_stride;                      // [IP][16]  c
-    float* const xts = xtr + IP * kTile;                               // [IP][16]  c + d
-    float* const xtd = xts + IP * kTile;                               // [IP][16]  c - d
+    // rotated features of the tile, rows of kXtStride = 20 floats (16 vertices + pad): the 16-byte B-fragment
+    // reads of 16 consecutive rows then fall into 16 distinct bank groups
+    float* const xtr = slab0 + 2 * a.slab_stride;                      // [IP][20]  c
+    float* const xts = xtr + IP * kXtStride;                           // [IP][20]  c + d
+    float* const xtd = xts + IP * kXtStride;                           // [IP][20]  c - d
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const int m = f - B;
     const int fr = lane & 15, fq = lane >> 4;
 
-    for (int idx = tid; idx < 3 * IP * kTile; idx += kThreads) xtr[idx] = 0.f;
+    for (int idx = tid; idx < 3 * IP * kXtStride; idx += kThreads) xtr[idx] = 0.f;
 
     // my gW tiles: u = wave + 16 n  ->  (row tile rt over k = (r,o), column tile ct over i)
     int gw_h[T], gw_x[T];       // wave-uniform LDS offsets, -1 when the slot is unused
@@ -38,10 +40,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         const int u = wave + kWaves * n;
         const int rt = u / mg.NMT, ct = u - rt * mg.NMT;
         gw_h[n] = (u < a.ngw) ? rt * 32 : -1;            // floats: 16 complex entries per row tile
-        gw_x[n] = ct * 16 * kTile;
+        gw_x[n] = ct * 16 * kXtStride;
     }
     const int h_lane = (4 * fq) * KD + 2 * fr;    // A fragment: H[vertex 4fq+s][k = rt*16 + fr], one 8-byte (re, im) read
-    const int x_lane = fr * kTile + 4 * fq;       // B fragment: xt[i = ct*16 + fr][vertex 4fq..4fq+3]
+    const int x_lane = fr * kXtStride + 4 * fq;   // B fragment: xt[i = ct*16 + fr][vertex 4fq..4fq+3]
 
     f32x4 k1[T], k2[T], k3[T];
 #pragma unroll
@@ -67,9 +69,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));
         __syncthreads();            // slab `buf` has landed (the barrier drains the DMA); previous tile's reads are done
         if (lane < IP) {
-            xtr[lane * kTile + wave] = xt.x;
-            xts[lane * kTile + wave] = xt.x + xt.y;
-            xtd[lane * kTile + wave] = xt.x - xt.y;
+            xtr[lane * kXtStride + wave] = xt.x;
+            xts[lane * kXtStride + wave] = xt.x + xt.y;
+            xtd[lane * kXtStride + wave] = xt.x - xt.y;
         }
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
 #pragma unroll
     for (int n = 0; n < T; ++n) {
         if (gw_h[n] >= 0) {
-            const int ct16 = gw_x[n] / kTile;
+            const int ct16 = gw_x[n] / kXtStride;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int k = gw_h[n] / 2 + 4 * fq + jj;

@@ -29,6 +29,7 @@
 namespace fc {
 
 
+constexpr int kXtStride = 20;    // floats per row of the filter kernel's rotated-feature tiles in LDS
 constexpr int kMaxGwTiles = 8;   // 16x16 complex gW tiles a wavefront can own
 
 // (pointers are separate __restrict__ kernel parameters, see fc_forward.hip)
@@ -377,7 +378,7 @@ inline BwdPlan plan_backward(const fc_dims* d, bool split) {
     p.slab_stride = round_up(p.slab_floats, 256);
     p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
-    p.lds_filter = (size_t)(2 * p.slab_stride + 3 * p.IP * kTile) * sizeof(float);
+    p.lds_filter = (size_t)(2 * p.slab_stride + 3 * p.IP * kXtStride) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
     p.ok = p.lds_data <= kMaxLds && p.lds_filter <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves &&

@@ -63,8 +63,12 @@ int fc_supported(const fc_dims* dims);
 /* ---- filter packing -------------------------------------------------------------------- *
  * W_eff (O,I,R,F) complex64 is what reference nn/field_conv.py:10-33 (weightContrib*) builds
  * from (zonal, spherical, phase); the 1/(2B+1) of :14,:25,:33 is folded in here.
- * wpk_fwd: F x {re,im} x OP x KPf floats,  k = r*I + i,  OP = ceil16(O), KPf = ceil16(R*I)
- * wpk_bwd: F x {re,im} x IP x KPb floats,  k = r*O + o,  conjugated,  IP = ceil16(I), KPb = ceil16(R*O) */
+ * The packed images are opaque to the caller: allocate fc_packed_filter_floats_{fwd,bwd}() floats
+ * each and hand them to the convolution calls.  Default ("split") layout, one image per contraction:
+ *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x OP x KP halves,
+ *   forward rows o, k = r*ceil8(I) + i;  backward rows i, k = r*ceil8(O) + o, conjugated;
+ *   OP = ceil16(rows), KP = ceil32(R * ceil8(channels)).
+ * With FC_MFMA=f32 in the environment: F x {re,im} x OP x ceil16(R*channels) floats. */
 size_t fc_packed_filter_floats_fwd(const fc_dims* dims);
 size_t fc_packed_filter_floats_bwd(const fc_dims* dims);
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
