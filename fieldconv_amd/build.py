@@ -28,12 +28,26 @@ def _hipcc():
     raise RuntimeError('hipcc not found: libfieldconv_hip.so cannot be built')
 
 
+def _source_digest():
+    """Content hash of everything the library is built from (sources, headers, this script)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]:
+        with open(d, 'rb') as f:
+            h.update(os.path.basename(d).encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
+DIGEST_PATH = LIB_PATH + '.src.sha256'
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
+    """True when the library is missing or was built from different sources.  Decided on content,
+    not on time stamps: a copied tree (the GPU box receives a snapshot) must not rebuild."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(DIGEST_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(DIGEST_PATH) as f:
+        return f.read().strip() != _source_digest()
 
 
 def build_native(force=False, verbose=False):
@@ -42,6 +56,7 @@ def build_native(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
+    digest = _source_digest()
     hipcc = _hipcc()
     compile_flags = [f for f in FLAGS if f != '-shared']
     objs, procs = [], []
@@ -66,6 +81,9 @@ def build_native(force=False, verbose=False):
         if res.returncode != 0:
             raise RuntimeError('hipcc link failed:\n' + res.stdout)
         os.replace(tmp, LIB_PATH)
+        with open(DIGEST_PATH + '.tmp.%d' % os.getpid(), 'w') as f:
+            f.write(digest)
+        os.replace(DIGEST_PATH + '.tmp.%d' % os.getpid(), DIGEST_PATH)
     finally:
         for f in objs + [tmp]:
             if os.path.exists(f):
