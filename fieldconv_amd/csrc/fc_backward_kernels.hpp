@@ -104,8 +104,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 #pragma unroll
     for (int q = 0; q < R; ++q) ro[q] = 0;
     {
-        const int j0 = blockIdx.x * kTile + wave;
-        if (blockIdx.x < a.ntiles && j0 < a.N) {
+        const int j0 = first_tile_of_block() * kTile + wave;
+        if (first_tile_of_block() < a.ntiles && j0 < a.N) {
             beg = growptr[j0];
             end = growptr[j0 + 1];
             if (FACTORED) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         }
     }
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
         int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
 #pragma unroll
         for (int q = 0; q < R; ++q) nro[q] = 0;

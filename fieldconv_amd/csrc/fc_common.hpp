@@ -30,6 +30,14 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// First tile of a persistent workgroup.  Workgroups are dealt round-robin to the 8 XCDs; with this
+// remap the 32 workgroups of one XCD walk 32 CONSECUTIVE tiles per round, so the source rows that
+// neighbouring tiles of the mesh share are served by that XCD's own L2.
+__device__ __forceinline__ int first_tile_of_block() {
+    const int b = blockIdx.x, g = gridDim.x;
+    return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
+
 // Compile-time loop: fn(std::integral_constant<int, i>) for i in [BEGIN, END).
 template <int BEGIN, int END, class Fn>
 __device__ __forceinline__ void static_for(Fn&& fn) {

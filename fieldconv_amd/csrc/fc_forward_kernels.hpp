@@ -319,8 +319,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
 #pragma unroll
     for (int q = 0; q < R; ++q) ro[q] = 0;
     {
-        const int t0 = blockIdx.x * kTile + wave;
-        if (blockIdx.x < a.ntiles && t0 < a.N) {
+        const int t0 = first_tile_of_block() * kTile + wave;
+        if (first_tile_of_block() < a.ntiles && t0 < a.N) {
             beg = growptr[t0];
             end = growptr[t0 + 1];
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
 
     float* vs = l.vscale;
     int buf = 0;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
 
