@@ -52,9 +52,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     const int npieces = a.slab_stride / 256;      // 1 KiB DMA pieces per slab
     auto dma_slab = [&](const int tile, const int buf) {
         const float* src = hdump + ((size_t)tile * F + f) * a.slab_stride;
+        if (!(a.dbg & 16))
         for (int p = wave; p < npieces; p += kWaves)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + lane * 4), (lptr_t)(slab0 + buf * a.slab_stride + p * 256), 16,
-                                             0, 0);
+            lds_dma16_untracked(src + p * 256 + lane * 4, slab0 + buf * a.slab_stride + p * 256);
     };
 
     if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
         // rotated feature xt_f of my source row (B operand)
         const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));
-        __syncthreads();            // slab `buf` has landed (the barrier drains the DMA); previous tile's reads are done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of slab `buf` have landed
+        __syncthreads();            // everyone's have; the previous tile's reads are done
         if (lane < IP) {
             xtr[lane * kXtStride + wave] = xt.x;
             xts[lane * kXtStride + wave] = xt.x + xt.y;

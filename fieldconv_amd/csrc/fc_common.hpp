@@ -54,6 +54,15 @@ __host__ __device__ constexpr int factored_record_floats(int B) { return round_u
 typedef __attribute__((address_space(1))) const void* gptr_t;   // global_load_lds source
 typedef __attribute__((address_space(3))) void* lptr_t;         // global_load_lds destination (wave-uniform base)
 
+// LDS-DMA of 16 bytes per lane (1 KiB per wavefront) that the compiler does not track: after the builtin
+// form hipcc drains vmcnt before the next LDS access that may alias the destination, which serialises a
+// prefetch with the compute it is meant to overlap.  The caller owns the ordering: s_waitcnt vmcnt before
+// the destination is read, a barrier before other wavefronts read it.
+__device__ __forceinline__ void lds_dma16_untracked(const void* src_lane, const void* lds_dst_uniform) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_uniform);   // LDS byte address
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src_lane) : "memory", "m0");
+}
+
 // Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
 __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);
