@@ -235,6 +235,40 @@ def echo_lift_cases(out):
         out[f'lift_block_t{ftype}'] = rec
 
 
+def net_cases(out):
+    """The segmentation network's topology (reference segmentation.ipynb:165-236): LiftBlock(3 -> nf),
+    four FCResNetBlocks, ECHOBlock(nf -> classes), composed here from the reference modules; log-softmax
+    NLL loss against seeded labels, gradients of every parameter."""
+    B, R, nf, n_classes, n_des, n_bins = 2, 6, 8, 4, 6, 2
+    N, k = 96, 10
+    g = torch.Generator().manual_seed(1234)
+    torch.manual_seed(1234)
+    edges, sten, ln, wxp = geo_stencil(g, N, k, B, R)
+    pos = torch.randn(N, 3, generator=g)
+    mods = torch.nn.ModuleDict(dict(
+        lift=refnn.LiftBlock(3, nf, n_rings=R, ftype=1),
+        resnet1=refnn.FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet2=refnn.FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet3=refnn.FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet4=refnn.FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        echo=refnn.ECHOBlock(nf, n_classes, n_des=n_des, n_bins=n_bins, band_limit=B, n_rings=R, ftype=1)))
+    x = mods['lift'](pos, edges, sten[..., B:B + 2])
+    for name in ('resnet1', 'resnet2', 'resnet3', 'resnet4'):
+        x = mods[name](x, edges, sten)
+    logits = mods['echo'](x, edges, sten, ln, wxp)
+    labels = torch.randint(0, n_classes, (N,), generator=g)
+    loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
+    params = dict(mods.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()))
+    rec = dict(pos=np_(pos), edges=np_(edges), sten=np_(sten), ln=np_(ln), wxp=np_(wxp), labels=np_(labels),
+               logits=np_(logits), loss=np_(loss), B=B, R=R, nf=nf, n_classes=n_classes, n_des=n_des, n_bins=n_bins)
+    for name, t in mods.state_dict().items():
+        rec['p_' + name] = np_(t)
+    for (name, _), gval in zip(params.items(), grads):
+        rec['g_' + name] = np_(gval)
+    out['segmentation_net'] = rec
+
+
 def main():
     groups = {
         'fieldconv.npz': fieldconv_cases,
@@ -242,6 +276,7 @@ def main():
         'blocks.npz': block_cases,
         'pointwise.npz': pointwise_cases,
         'echo_lift.npz': echo_lift_cases,
+        'net.npz': net_cases,
     }
     for fname, fn in groups.items():
         cases = {}

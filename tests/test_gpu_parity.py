@@ -167,6 +167,36 @@ def test_echo_block_and_lift_block_golden(dev):
         assert rel_err(H(gx), c['gx']) < 1e-4
 
 
+def test_segmentation_net_golden(dev):
+    """Config-3 topology end to end (reference segmentation.ipynb:165-236): LiftBlock -> 4 FCResNetBlocks
+    -> ECHOBlock, loss and every parameter gradient against the reference run captured in net.npz."""
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
+    c = load_golden('net.npz')['segmentation_net']
+    B, R, nf = int(c['B']), int(c['R']), int(c['nf'])
+    mods = torch.nn.ModuleDict(dict(
+        lift=LiftBlock(3, nf, n_rings=R, ftype=1),
+        resnet1=FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet2=FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet3=FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        resnet4=FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1),
+        echo=ECHOBlock(nf, int(c['n_classes']), n_des=int(c['n_des']), n_bins=int(c['n_bins']), band_limit=B, n_rings=R,
+                       ftype=1)))
+    mods = load_params(mods, c).to(dev)
+    edges, sten = D(c['edges'], dev), D(c['sten'], dev)
+    x = mods['lift'](D(c['pos'], dev), edges, sten[..., B:B + 2])          # the strided slice the notebook passes
+    for name in ('resnet1', 'resnet2', 'resnet3', 'resnet4'):
+        x = mods[name](x, edges, sten)
+    logits = mods['echo'](x, edges, sten, D(c['ln'], dev), D(c['wxp'], dev))
+    loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), D(c['labels'], dev))
+    assert rel_err(H(logits), c['logits']) < TOL
+    assert abs(float(loss.detach()) - float(c['loss'])) < 1e-5 * max(1.0, abs(float(c['loss'])))
+    params = dict(mods.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()))
+    worst = max((rel_err(H(g), c['g_' + name]), name) for (name, _), g in zip(params.items(), grads))
+    print('logits err %.2e, worst gradient err %.2e (%s)' % (rel_err(H(logits), c['logits']), worst[0], worst[1]))
+    assert worst[0] < 5 * TOL, worst        # measured 4e-6 through eleven layers
+
+
 # ---------------------------------------------------------------- seeded inputs vs the oracle
 def make_case(seed, N, k, I, O, B, R, sort_by_source=True, zero_frac=0.01):
     g = torch.Generator().manual_seed(seed)
