@@ -97,6 +97,9 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
         args.gpus = world
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')                  # "gloo": several ranks on one GPU (test rigs only)
+    if backend == 'gloo':
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     force_dist = os.environ.get('BENCH_FORCE_DIST', '0') == '1'        # exercise the RCCL path with a single rank
@@ -111,7 +114,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group('nccl', device_id=dev)
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=dev)
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -161,6 +167,14 @@ def main():
     prep_ms = (time.perf_counter() - t0) * 1e3
     get_graph(edges, sten, n_local)                         # the cached instance every convolution will use
 
+    def _all_reduce(t, op=dist.ReduceOp.SUM):
+        if backend == 'gloo':                       # host-staged (test rigs only)
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     def step():
         xl = halo_exchange(x, plan) if plan is not None else x
         y = conv(xl, edges, sten)
@@ -169,7 +183,7 @@ def main():
         grads = torch.autograd.grad(y, [x] + params, grad_outputs=gy)
         if use_dist:
             flat = torch.cat([t.reshape(-1) for t in grads[1:]])
-            dist.all_reduce(flat)
+            _all_reduce(flat)
         return grads
 
     for _ in range(args.warmup):
@@ -192,10 +206,10 @@ def main():
     kernel_timer.enabled = False
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         ecount = torch.tensor([E], device=dev, dtype=torch.int64)
-        dist.all_reduce(ecount)
+        _all_reduce(ecount)
         E_total = int(ecount.item())
     else:
         E_total = E

@@ -33,12 +33,11 @@ class HaloPlan:
         # tell every owner how many (then which) of its rows this rank wants
         rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=device)
         sc = torch.empty_like(rc)
-        dist.all_to_all_single(sc, rc, group=group)
+        _all_to_all(sc, rc, None, None, group)
         self.send_counts = sc.tolist()
         want = halo_global.to(device)
         asked = torch.empty(sum(self.send_counts), dtype=torch.int64, device=device)
-        dist.all_to_all_single(asked, want, output_split_sizes=self.send_counts, input_split_sizes=self.recv_counts,
-                               group=group)
+        _all_to_all(asked, want, self.send_counts, self.recv_counts, group)
         lo = int(bounds[self.rank])
         self.send_idx = (asked - lo).contiguous()              # local owned rows to ship, grouped by peer
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_owned):
@@ -65,10 +64,24 @@ class _HaloExchange(torch.autograd.Function):
         return g_owned, None
 
 
+def _all_to_all(recv, send, recv_counts, send_counts, group):
+    """all_to_all_single; device tensors are staged through the host when the group's backend is gloo (used to
+    run several ranks on ONE GPU in tests -- RCCL refuses two ranks per device; production runs use "nccl")."""
+    kw = {}
+    if recv_counts is not None:
+        kw = dict(output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+    if recv.is_cuda and dist.get_backend(group) == 'gloo':
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), group=group, **kw)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, group=group, **kw)
+
+
 def _a2a(recv, send, recv_counts, send_counts, group):
     r = torch.view_as_real(recv) if recv.is_complex() else recv
     s = torch.view_as_real(send) if send.is_complex() else send
-    dist.all_to_all_single(r, s, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    _all_to_all(r, s, recv_counts, send_counts, group)
 
 
 def halo_exchange(x_owned, plan):

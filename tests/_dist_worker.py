@@ -1,6 +1,8 @@
-"""Worker for tests/test_distributed_cpu.py: world_size-2 gloo run of the vertex-partition + halo
-exchange path.  The local convolution is the CPU oracle (this is a test of the partition / exchange
-logic, which is backend-agnostic torch.distributed code; the HIP kernels are covered by -m gpu)."""
+"""Worker for tests/test_distributed_cpu.py and tests/test_distributed_gpu.py: world_size-2 gloo run of the
+vertex-partition + halo exchange path.  On the CPU the local convolution is the oracle (a test of the
+partition / exchange logic, backend-agnostic torch.distributed code); with FC_DIST_TEST_DEVICE=cuda both
+ranks share cuda:0 and run the HIP kernels (RCCL refuses two ranks per device, hence gloo with host staging
+there), and the oracle is only the checker."""
 import os
 import sys
 
@@ -38,24 +40,35 @@ def features(n_total, C, seed):
 def main():
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
-    n_total, k, C, O, B, R = 400, 8, 5, 4, 1, 3
+    on_gpu = os.environ.get('FC_DIST_TEST_DEVICE', 'cpu') == 'cuda'
+    dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
+    n_total, k, C, O, B, R = (3000, 12, 24, 16, 2, 6) if on_gpu else (400, 8, 5, 4, 1, 3)
     data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     assert edges.shape[0] == n_owned * k
-    plan = HaloPlan(n_owned, halo_global, bounds, device='cpu')
+    plan = HaloPlan(n_owned, halo_global, bounds, device=dev)
     lo = int(bounds[rank])
     x_all = features(n_total, C, 1)
     gy_all = features(n_total, O, 2)
     g = torch.Generator().manual_seed(9)
     W = torch.complex(torch.randn(O, C, R, 2 * B + 1, generator=g), torch.randn(O, C, R, 2 * B + 1, generator=g)).requires_grad_(True)
-    x_owned = x_all[lo:lo + n_owned].clone().requires_grad_(True)
+    x_owned = x_all[lo:lo + n_owned].clone().to(dev).requires_grad_(True)
 
     x_local = halo_exchange(x_owned, plan)
     # the halo rows must be exactly the owners' rows
-    assert torch.equal(x_local[n_owned:].detach(), x_all[halo_global])
-    y_local = OracleConv.apply(x_local, W, edges, sten)
-    y_owned = y_local[:n_owned]
-    gx, gW = torch.autograd.grad(y_owned, [x_owned, W], grad_outputs=gy_all[lo:lo + n_owned])
+    assert torch.equal(x_local[n_owned:].detach().cpu(), x_all[halo_global])
+    if on_gpu:
+        from fieldconv_amd.functional import field_conv
+        from fieldconv_amd.graph import SupportGraph
+        Wd = W.detach().to(dev).requires_grad_(True)
+        graph = SupportGraph(edges.to(dev), sten.to(dev), x_local.shape[0])
+        y_owned = field_conv(x_local, Wd, graph)[:n_owned]
+        gx, gW = torch.autograd.grad(y_owned, [x_owned, Wd], grad_outputs=gy_all[lo:lo + n_owned].to(dev))
+        y_owned, gx, gW = y_owned.cpu(), gx.cpu(), gW.cpu()
+    else:
+        y_local = OracleConv.apply(x_local, W, edges, sten)
+        y_owned = y_local[:n_owned]
+        gx, gW = torch.autograd.grad(y_owned, [x_owned, W], grad_outputs=gy_all[lo:lo + n_owned])
     gWr = torch.view_as_real(gW.contiguous()).clone()
     dist.all_reduce(gWr)
 
