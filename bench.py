@@ -77,6 +77,32 @@ def cpu_baseline(B, R, C, k, threads):
                       f'{best:.2f} s per step'}
 
 
+def reduced_precision_run(args, conv, x, edges, sten, step):
+    """Extra, reported separately (BASELINE configs[1] names bf16/fp32): the same workload with the contractions
+    on single f16 halves (FC_MFMA=f16, fp32 accumulation) in a child process -- the mode is fixed per process --
+    and its deviation from this process's fp32-grade result on the same seeded inputs."""
+    import subprocess
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, 'rp.pt')
+            cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup),
+                   '--verts', str(args.verts), '--k', str(args.k), '--channels', str(args.channels), '--band-limit',
+                   str(args.band_limit), '--n-rings', str(args.n_rings), '--no-cpu-baseline', '--no-extras', '--dump', path]
+            env = dict(os.environ, FC_MFMA='f16')
+            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            child = json.loads(res.stdout.strip().splitlines()[-1])
+            ref = torch.load(path)
+        gx = step()[0].detach().cpu()
+        y = conv(x, edges, sten).detach().cpu()
+        err = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        return {'mfma': 'single f16 halves with per-row power-of-two scales, fp32 accumulation (FC_MFMA=f16)',
+                'value': child['value'], 'unit': child['unit'], 'ms_per_step': child['ms_per_step'],
+                'max_rel_err_y_vs_default': err(ref['y'], y), 'max_rel_err_gx_vs_default': err(ref['gx'], gx)}
+    except Exception as exc:
+        return {'value': None, 'note': f'failed: {type(exc).__name__}: {exc}'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,6 +114,8 @@ def main():
     ap.add_argument('--band-limit', type=int, default=2)
     ap.add_argument('--n-rings', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the reduced-precision child run)')
+    ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (reduced-precision child run)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -262,7 +290,10 @@ def main():
             'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
             'graph_preprocessing_ms': prep_ms,
         }
-        if world == 1 and not use_dist:
+        if args.dump:
+            gd = step()
+            torch.save({'y': conv(x, edges, sten).detach().cpu(), 'gx': gd[0].detach().cpu()}, args.dump)
+        if world == 1 and not use_dist and not args.no_extras:
             # extra (not the metric of record): one FCResNetBlock = 2 FieldConv + TangentLin + 2 modReLU, fwd+bwd
             from fieldconv_amd.nn import FCResNetBlock
             blk = FCResNetBlock(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
@@ -281,6 +312,8 @@ def main():
             bms = (time.perf_counter() - tb) / 10 * 1e3
             out['fc_resnet_block'] = {'ms_per_step': bms, 'medges_per_s': 2 * E / (bms * 1e-3) / 1e6,
                                       'note': 'FCResNetBlock fwd+bwd, edges counted once per FieldConv (2 per block)'}
+        if world == 1 and not use_dist and not args.no_extras and os.environ.get('FC_MFMA') is None:
+            out['reduced_precision'] = reduced_precision_run(args, conv, x, edges, sten, step)
         if world == 1 and not args.no_cpu_baseline:
             ncpu = os.cpu_count() or 2
             threads = max(1, ncpu // 2)                 # physical cores (SMT siblings excluded)

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     } else {
                         if (lane < mg.KI) {
                             lds_u32* const row = (lds_u32*)hre + wave * (KS / 2);    // LDS row of my vertex, see fc_forward_kernels.hpp
-                            int o0 = split_pair_offset(lane);
+                            int o0 = split_pair_offset(lane, mg.split);
                             float2* const dst2 = reinterpret_cast<float2*>(dst);
                             int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
 #pragma unroll
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                                 if (lane < O && !(a.dbg & 8)) dst2[d0] = make_float2(h[r][ff].x, h[r][ff].y);
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
-                                split_pair_store(row, o0, hi, lo, lane);
-                                o0 += 2 * mg.KI;
+                                split_pair_store(row, o0, hi, lo, lane, mg.split);
+                                o0 += mg.split * mg.KI;
                                 d0 += O;
                                 asm volatile("" : "+v"(o0), "+v"(d0));
                             }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         if (!(a.dbg & 2)) {
                             const rsrc_t wimg = make_rsrc(gwpk, a.wpk_bytes);
                             if constexpr (SPLIT)
-                                mma_slab_split(wimg, IP * 4 + f * (4 * IP * mg.KP * 2), (const lds_f16*)hre, mg, it, kp, lane, acc_re, acc_im);
+                                mma_slab_split(wimg, IP * 4 + f * (2 * mg.split * IP * mg.KP * 2), (const lds_f16*)hre, mg, it, kp, lane, acc_re, acc_im);
                             else
                                 mma_slab(wimg, f * (2 * IP * mg.KP * 4), hre, him, mg, it, kp, lane, acc_re, acc_im);
                         }
@@ -360,11 +360,11 @@ struct BwdPlan {
     bool ok, ok_factored;
 };
 
-inline BwdPlan plan_backward(const fc_dims* d, bool split) {
+inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     BwdPlan p;
     p.F = 2 * d->B + 1;
     p.g = make_mma_geom(d->I, d->R, d->O);
-    p.gd = make_mma_geom(d->I, d->R, d->O, split);
+    p.gd = make_mma_geom(d->I, d->R, d->O, halves);
     p.IP = p.g.MP;
     p.KP = p.g.KP;
     p.ntiles = (d->N + kTile - 1) / kTile;
@@ -392,7 +392,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.N = d->N; a.I = d->I; a.O = d->O;
     a.g = p.g;
     a.gd = p.gd;
-    a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R, d->O, p.F, p.gd.split != 0) * sizeof(float));
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R, d->O, p.F, p.gd.split) * sizeof(float));
     a.ntiles = p.ntiles;
     a.ngw = p.ngw;
     a.KD = p.KD;
@@ -421,7 +421,7 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
 template <bool SPLIT>
 int backward_data_impl_mode(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                             void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
-    const BwdPlan p = plan_backward(d, SPLIT);
+    const BwdPlan p = plan_backward(d, SPLIT ? split_mode() : 0);
     if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const BwdArgs a = make_args(d, p);

@@ -148,19 +148,19 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
                 // advanced by a ring per step -- the empty asm keeps hipcc from materialising all R addresses for
                 // the whole kernel.  Lanes in [I, KI) hold copies of channel 0 and land in padding the filter zeroes.
                 lds_u32* const row = (lds_u32*)sp + wave * (g.KS / 2);
-                int o0 = split_pair_offset(lane);
+                int o0 = split_pair_offset(lane, g.split);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     f16x2 hi, lo;
                     split_halves2(c[r][ff], scale, hi, lo);
-                    split_pair_store(row, o0, hi, lo, lane);
-                    o0 += 2 * g.KI;
+                    split_pair_store(row, o0, hi, lo, lane, g.split);
+                    o0 += g.split * g.KI;
                     asm volatile("" : "+v"(o0));
                 }
             }
             __syncthreads();
             if (mma_active && !(a.dbg & 2))
-                mma_slab_split(wimg, planes0 + f * (4 * g.MP * g.KP * 2), sp, g, mt, kp, lane, acc_re, acc_im);
+                mma_slab_split(wimg, planes0 + f * (2 * g.split * g.MP * g.KP * 2), sp, g, mt, kp, lane, acc_re, acc_im);
             if (a.slabs == 2) buf ^= 1;
             else __syncthreads();
         }
@@ -480,9 +480,9 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
                       const fc_dims* d, bool factored, hipStream_t stream) {
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
-    a.g = make_mma_geom(d->O, d->R, d->I, SPLIT);
+    a.g = make_mma_geom(d->O, d->R, d->I, SPLIT ? split_mode() : 0);
     a.ntiles = (d->N + kTile - 1) / kTile;
-    a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, SPLIT) * sizeof(float));
+    a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, a.g.split) * sizeof(float));
     { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.ring_chunks = factored ? kRingChunks : 0;
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;

@@ -112,11 +112,16 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
         _Float16 rh, rl, ih, il;
         split_halves(v.x * scale, rh, rl);
         split_halves(v.y * scale, ih, il);
-        _Float16* p = planes + (size_t)f * 4 * plane + (size_t)m * g.KP + k;
-        p[0] = rh;
-        p[plane] = rl;
-        p[2 * plane] = ih;
-        p[3 * plane] = il;
+        _Float16* p = planes + (size_t)f * 2 * g.split * plane + (size_t)m * g.KP + k;
+        if (g.split == 2) {
+            p[0] = rh;
+            p[plane] = rl;
+            p[2 * plane] = ih;
+            p[3 * plane] = il;
+        } else {
+            p[0] = rh;
+            p[plane] = ih;
+        }
     }
 }
 
@@ -147,10 +152,12 @@ int pack_filter_params_impl(const float* zonal, const float* sph, const float* p
     return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, stream);
 }
 
-bool split_mode() {
-    static const bool mode = [] {
+int split_mode() {
+    static const int mode = [] {
         const char* e = getenv("FC_MFMA");
-        return !(e && e[0] == 'f' && e[1] == '3' && e[2] == '2');
+        if (e && e[0] == 'f' && e[1] == '3' && e[2] == '2') return 0;
+        if (e && e[0] == 'f' && e[1] == '1' && e[2] == '6') return 1;
+        return 2;
     }();
     return mode;
 }

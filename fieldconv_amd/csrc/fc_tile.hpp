@@ -15,6 +15,8 @@ namespace fc {
 //   split  v_mfma_f32_16x16x32_f16 on operands split into two halves (hi + lo); k blocks of 32,
 //          slab = one row per vertex holding the four planes (re_hi, re_lo, im_hi, im_lo) interleaved
 //          in 16-byte fragments: [k / 8][plane][k % 8] halves, so that a plane is an immediate offset.
+//   half   the same kernels with the lo halves dropped (planes re_hi, im_hi): a reduced-precision
+//          mode (relative error ~2^-11 per operand), selected with FC_MFMA=f16 and reported separately.
 // The contraction index is k = r * KI + c (ring r, channel c).
 struct MmaGeom {
     int MP;     // ceil16(M)
@@ -24,17 +26,18 @@ struct MmaGeom {
     int NMT;    // MP / 16 output tiles
     int NKP;    // k partitions (wavefronts per output tile)
     int KST;    // k blocks: KP / 16 (fp32) or KP / 32 (split)
-    int split;  // 1: split-half mode
+    int split;  // halves per operand: 0 fp32 mode, 2 split mode, 1 reduced-precision half mode
 };
 
-__host__ __device__ inline MmaGeom make_mma_geom(int M, int R, int channels, bool split = false) {
+__host__ __device__ inline MmaGeom make_mma_geom(int M, int R, int channels, int halves = 0) {
     MmaGeom g;
+    const bool split = halves != 0;
     const int kblock = split ? 32 : 16;
-    g.split = split ? 1 : 0;
+    g.split = halves;
     g.MP = round_up(M, 16);
     g.KI = split ? round_up(channels, 8) : channels;
     g.KP = round_up(R * g.KI, kblock);
-    g.KS = split ? 4 * g.KP + 8 : slab_stride(g.KP);      // both: 16-byte fragment reads of 16 rows hit distinct banks
+    g.KS = split ? 2 * halves * g.KP + 8 : slab_stride(g.KP);      // all: 16-byte fragment reads of 16 rows hit distinct banks
     g.NMT = g.MP / 16;
     g.KST = g.KP / kblock;
     g.NKP = kWaves / g.NMT;
@@ -46,16 +49,18 @@ __host__ __device__ inline MmaGeom make_mma_geom(int M, int R, int channels, boo
 // Floats in the packed filter image of one contraction (F frequencies, M rows, K entries per row).
 //   fp32 : [F][2 planes re,im][MP][KP] floats
 //   split: [MP] inverse row scales (floats), then [F][4 planes re_hi,re_lo,im_hi,im_lo][MP][KP] halves
-__host__ __device__ inline size_t packed_image_floats(int M, int R, int channels, int F, bool split) {
-    const MmaGeom g = make_mma_geom(M, R, channels, split);
-    return split ? (size_t)g.MP + (size_t)F * 2 * g.MP * g.KP : (size_t)F * 2 * g.MP * g.KP;
+//   half : the same with the 2 planes re_hi, im_hi
+__host__ __device__ inline size_t packed_image_floats(int M, int R, int channels, int F, int halves) {
+    const MmaGeom g = make_mma_geom(M, R, channels, halves);
+    return halves ? (size_t)g.MP + (size_t)F * halves * g.MP * g.KP : (size_t)F * 2 * g.MP * g.KP;
 }
 
 // Floats of one LDS slab buffer (16 vertices).
 __host__ __device__ inline int slab_floats(const MmaGeom& g) { return g.split ? kTile * g.KS / 2 : 2 * kTile * g.KS; }
 
-// Which mode the library runs in: FC_MFMA=f32 selects the fp32 MFMA, anything else the split mode.
-bool split_mode();
+// Halves per operand the library runs with: 2 (split mode, default), 0 with FC_MFMA=f32 (fp32 MFMA),
+// 1 with FC_MFMA=f16 (reduced precision).
+int split_mode();
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -155,14 +160,20 @@ __device__ __forceinline__ void split_halves2(f32x2 v, float s, f16x2& hi, f16x2
 //   odd lane : (im_hi[c-1], im_hi[c]) -> plane 2, (im_lo[c-1], im_lo[c]) -> plane 3
 // split_pair_offset: dword offset of the lane's first store inside the row (ring 0); the second is 4 dwords on.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ int split_pair_offset(int c) { return 16 * (c >> 3) + 8 * (c & 1) + ((c & 7) >> 1); }
-__device__ __forceinline__ void split_pair_store(lds_u32* row, int dword_offset, f16x2 hi, f16x2 lo, int lane) {
+// In half mode (halves = 1) the row holds the planes (re_hi, im_hi): even lanes store the re pair, odd
+// lanes the im pair, one dword each.  A ring advances the offset by halves * KI dwords.
+__device__ __forceinline__ int split_pair_offset(int c, int halves) {
+    return 8 * halves * (c >> 3) + 4 * halves * (c & 1) + ((c & 7) >> 1);
+}
+__device__ __forceinline__ void split_pair_store(lds_u32* row, int dword_offset, f16x2 hi, f16x2 lo, int lane, int halves) {
     const uint32_t h = __builtin_bit_cast(uint32_t, hi), l = __builtin_bit_cast(uint32_t, lo);
     const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)h, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
-    const uint32_t lp = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0xB1, 0xF, 0xF, true);
     const uint32_t sel = (lane & 1) ? 0x03020706u : 0x05040100u;    // odd: (partner.hi16, own.hi16); even: (own.lo16, partner.lo16)
     row[dword_offset] = __builtin_amdgcn_perm(hp, h, sel);
-    row[dword_offset + 4] = __builtin_amdgcn_perm(lp, l, sel);
+    if (halves == 2) {
+        const uint32_t lp = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0xB1, 0xF, 0xF, true);
+        row[dword_offset + 4] = __builtin_amdgcn_perm(lp, l, sel);
+    }
 }
 
 // One slab through the matrix pipe in split mode.  wimg: descriptor of the packed image, f_bytes: byte
@@ -174,10 +185,29 @@ __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const l
     const int fr = lane & 15, fq = lane >> 4;
     const int wplane = g.MP * g.KP * 2;                 // bytes
     const int wv = ((mt * 16 + fr) * g.KP + 8 * fq) * 2;
+    const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    if (g.split == 1) {
+        // reduced precision: planes (re_hi, im_hi) only, one MFMA per real product
+        const lds_f16* s1 = sp + fr * g.KS + 16 * fq;   // fragment (k block 4*kb + fq, plane p) at + 64*kb + 8*p halves
+        auto ldw1 = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
+        auto lds1 = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s1 + 64 * kb + 8 * plane); };
+        u32x4 wr = ldw1(0, kp), wi = ldw1(1, kp);
+        for (int kb = kp; kb < g.KST; kb += g.NKP) {
+            const int kn = min(kb + g.NKP, g.KST - 1);
+            const u32x4 n_wr = ldw1(0, kn), n_wi = ldw1(1, kn);
+            const u32x4 sr = lds1(0, kb);
+            u32x4 si = lds1(1, kb);
+            acc_re = mfma32h(wr, sr, acc_re); acc_im = mfma32h(wi, sr, acc_im);
+            acc_im = mfma32h(wr, si, acc_im);
+            si ^= sign;
+            acc_re = mfma32h(wi, si, acc_re);
+            wr = n_wr; wi = n_wi;
+        }
+        return;
+    }
     const lds_f16* s0 = sp + fr * g.KS + 32 * fq;       // fragment (k block 4*kb + fq, plane p) at + 128*kb + 8*p halves
     auto ldw = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
     auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + 128 * kb + 8 * plane); };
-    const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     u32x4 wrh = ldw(0, kp), wrl = ldw(1, kp), wih = ldw(2, kp), wil = ldw(3, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
         const int kn = min(kb + g.NKP, g.KST - 1);          // next block (clamped re-read at the end)
