@@ -146,6 +146,31 @@ __device__ __forceinline__ void rotate_all(f32x2 z, f32x2 (&xt)[2 * B + 1]) {
     }
 }
 
+// Geometric-phase form of the factored stencil: FCPrecomp's phases are ph_f = c * g^(f-B) with |g| = 1
+// (fSten = exp(i m theta), reference transforms/fc_precomp.py:88-95).  Then z_f = ph_f * x * u^(f-B) =
+// (c x) (g u)^(f-B): one product for c x, one for v = g u, and one per further frequency -- 2 + 2B complex
+// products per edge and lane instead of 4B + 1, and no special m = +1 copy.  Inside the origin box u = 1.
+template <int B>
+__device__ __forceinline__ void rotate_geometric(f32x2 x, f32x2 c, f32x2 g, f32x2 (&z)[2 * B + 1]) {
+    const bool org = (fabsf(x.x) < kOriginEps) && (fabsf(x.y) < kOriginEps);
+    const f32x2 sq = x * x;
+    const float inv = __frsqrt_rn(sq.x + sq.y);
+    const f32x2 u = org ? f32x2{1.f, 0.f} : f32x2{x.x * inv, -x.y * inv};
+    const f32x2 v = cmul_pk(g, u);
+    z[B] = cmul_pk(c, x);
+    if (B >= 1) {
+        z[B + 1] = cmul_pk(z[B], v);
+        z[B - 1] = cmul_conj_pk(z[B], v);
+    }
+#pragma unroll
+    for (int m = 2; m <= B; ++m) {
+        z[B + m] = cmul_pk(z[B + m - 1], v);
+        z[B - m] = cmul_conj_pk(z[B - m + 1], v);
+    }
+}
+constexpr int kGeoRecordFloats = 8;     // [q bits, w_q, w_{q+1}, other endpoint bits, Re c, Im c, Re g, Im g]
+constexpr int kGeoLogChunkRecords = 5;  // 32 records per 1 KiB chunk
+
 // Complex multiply-accumulate on packed fp32: acc (re,im) += s * x with s a WAVE-UNIFORM complex
 // number in an SGPR pair and x a per-lane complex number.  Plain wave64 FMAs issue every 4 cycles on
 // gfx950 (measured 76 TFLOP/s with an SGPR operand); v_pk_fma_f32 does two per lane in the same

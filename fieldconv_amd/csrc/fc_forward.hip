@@ -3,15 +3,15 @@
 
 namespace fc {
 
-template int forward_impl_mode<false>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, bool,
+template int forward_impl_mode<false>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, int,
                                       hipStream_t);
 extern template int forward_impl_mode<true>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*,
-                                            bool, hipStream_t);
+                                            int, hipStream_t);
 
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y, const fc_dims* d,
-                 bool factored, hipStream_t stream) {
-    return split_mode() ? forward_impl_mode<true>(x, sten, g, wpk, y, d, factored, stream)
-                        : forward_impl_mode<false>(x, sten, g, wpk, y, d, factored, stream);
+                 int kind, hipStream_t stream) {
+    return split_mode() ? forward_impl_mode<true>(x, sten, g, wpk, y, d, kind, stream)
+                        : forward_impl_mode<false>(x, sten, g, wpk, y, d, kind, stream);
 }
 
 }  // namespace fc

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_kernel(
 // [3] source vertex (int bits), [4 + 2f], [5 + 2f] = ph_f.  Records are stored in target-slot order; a wavefront streams the
 // records of its target in chunks of CR = 256 / RECF (one 1 KiB global_load_lds per chunk) through
 // a private LDS ring of NR chunks.
-template <int R, int B, bool SPLIT>
+// GEO: records in the geometric-phase form (fc_common.hpp: rotate_geometric), 8 floats per edge.
+template <int R, int B, bool SPLIT, bool GEO>
 __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ grec, const int32_t* __restrict__ growptr,
     const int32_t* __restrict__ gruns, const float* __restrict__ gwpk,
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     constexpr int F = 2 * B + 1;
     constexpr int NG = FwdShape<R, B>::NG;
     constexpr int MG = FwdShape<R, B>::MG;
-    constexpr int RECF = factored_record_floats(B);
-    constexpr int LOG_CR = factored_log_chunk_records(B);        // records per chunk: a power of two, CR*RECF*4 <= 1 KiB
+    constexpr int RECF = GEO ? kGeoRecordFloats : factored_record_floats(B);
+    constexpr int LOG_CR = GEO ? kGeoLogChunkRecords : factored_log_chunk_records(B);   // records per chunk: a power of two, CR*RECF*4 <= 1 KiB
     constexpr int CR = 1 << LOG_CR;
     constexpr int NR = kRingChunks;                              // ring slots per wavefront (power of two)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -401,22 +402,33 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
                 const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                 const float w0 = head.y, w1 = head.z;
                 const int n2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);   // source two slots ahead
-                f32x2 xt[F];
-                rotate_all<B>(f32x2{xcur.x, xcur.y}, xt);
-                xcur = gx_[(size_t)n2 * I + cl];
                 const f32x2 w0v = f32x2{w0, w0}, w1v = f32x2{w1, w1};
-                // z_f = ph_f * xt_f in two passes over the frequencies, then the ring updates: no packed op
-                // directly follows the one it depends on
-                f32x2 ph[MG], z[MG];
+                f32x2 z[MG];
+                if constexpr (GEO) {
+                    const f32x4 cg = *reinterpret_cast<const f32x4*>(rp + 4);
+                    f32x2 zf[F];
+                    rotate_geometric<B>(f32x2{xcur.x, xcur.y}, f32x2{cg.x, cg.y}, f32x2{cg.z, cg.w}, zf);
+                    xcur = gx_[(size_t)n2 * I + cl];
 #pragma unroll
-                for (int ff = 0; ff < MG; ++ff)
-                    if (f0 + ff < F) {
-                        ph[ff] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * (f0 + ff));
-                        z[ff] = cmul_pk_step1(ph[ff], xt[f0 + ff]);
-                    }
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) z[ff] = zf[f0 + ff];
+                } else {
+                    f32x2 xt[F];
+                    rotate_all<B>(f32x2{xcur.x, xcur.y}, xt);
+                    xcur = gx_[(size_t)n2 * I + cl];
+                    // z_f = ph_f * xt_f in two passes over the frequencies, then the ring updates: no packed op
+                    // directly follows the one it depends on
+                    f32x2 ph[MG];
 #pragma unroll
-                for (int ff = 0; ff < MG; ++ff)
-                    if (f0 + ff < F) z[ff] = cmul_pk_step2(ph[ff], xt[f0 + ff], z[ff]);
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) {
+                            ph[ff] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * (f0 + ff));
+                            z[ff] = cmul_pk_step1(ph[ff], xt[f0 + ff]);
+                        }
+#pragma unroll
+                    for (int ff = 0; ff < MG; ++ff)
+                        if (f0 + ff < F) z[ff] = cmul_pk_step2(ph[ff], xt[f0 + ff], z[ff]);
+                }
 #pragma unroll
                 for (int ff = 0; ff < MG; ++ff)
                     if (f0 + ff < F) c[Q][ff] = __builtin_elementwise_fma(w0v, z[ff], c[Q][ff]);
@@ -462,22 +474,24 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     }
 }
 
-template <int R, int B, bool FACTORED, bool SPLIT>
+template <int R, int B, int KIND, bool SPLIT>      // KIND: 0 dense stencil, 1 factored records, 2 geometric records
 static int launch_forward(const float2* x, const float* sten, const fc_csr* g, const float* wpk, float2* y,
                           const FwdArgs& a, size_t lds_bytes, int grid, hipStream_t stream) {
-    auto kern = FACTORED ? fc_forward_factored_kernel<R, B, SPLIT> : fc_forward_kernel<R, B, SPLIT>;
+    auto kern = KIND == 2 ? fc_forward_factored_kernel<R, B, SPLIT, true>
+                : KIND == 1 ? fc_forward_factored_kernel<R, B, SPLIT, false> : fc_forward_kernel<R, B, SPLIT>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return FC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, y, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, KIND ? g->runs : g->nbr, wpk, y, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 template <bool SPLIT>
 int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                      const fc_dims* d, bool factored, hipStream_t stream) {
+                      const fc_dims* d, int kind, hipStream_t stream) {
+    const bool factored = kind != 0;
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
     a.g = make_mma_geom(d->O, d->R, d->I, SPLIT ? split_mode() : 0);
@@ -493,11 +507,13 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
     const int grid = factored ? (a.ntiles < kNumCUs ? a.ntiles : kNumCUs) : a.ntiles;
 #define FC_CASE(RR, BB)                                                                                              \
-    if (d->R == RR && d->B == BB)                                                                                    \
-        return factored ? launch_forward<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x), sten, g, wpk,             \
-                                                       reinterpret_cast<float2*>(y), a, lds, grid, stream)           \
-                        : launch_forward<RR, BB, false, SPLIT>(reinterpret_cast<const float2*>(x), sten, g, wpk,            \
-                                                        reinterpret_cast<float2*>(y), a, lds, grid, stream);
+    if (d->R == RR && d->B == BB) {                                                                                  \
+        const float2* x2 = reinterpret_cast<const float2*>(x);                                                       \
+        float2* y2 = reinterpret_cast<float2*>(y);                                                                   \
+        if (kind == 2) return launch_forward<RR, BB, 2, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);          \
+        if (kind == 1) return launch_forward<RR, BB, 1, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);          \
+        return launch_forward<RR, BB, 0, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);                         \
+    }
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
     return FC_ERR_UNSUPPORTED;

@@ -3,7 +3,7 @@
 
 namespace fc {
 
-template int forward_impl_mode<true>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, bool,
+template int forward_impl_mode<true>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, int,
                                      hipStream_t);
 
 }  // namespace fc

@@ -17,8 +17,9 @@ constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kNumCUs = 256;         // MI355X: 8 XCDs x 32 CUs; persistent grids launch one workgroup per CU
 constexpr int kMaxChannels = 64;     // one channel per lane in the gather phases
 
+// kind: 0 dense stencil rows, 1 factored records, 2 geometric-phase records
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                 const fc_dims* d, bool factored, hipStream_t stream);
+                 const fc_dims* d, int kind, hipStream_t stream);
 size_t backward_workspace_bytes(const fc_dims* d);
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);

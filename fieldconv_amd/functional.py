@@ -116,7 +116,10 @@ def _launch_forward(lib, x, graph, wpk_f, dims, O, st):
     y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
     csr = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
     with _timed('fc_forward'):
-        if graph.factored:
+        if graph.geo_t is not None:
+            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
+                  'fc_forward_geometric')
+        elif graph.factored:
             check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
                   'fc_forward_factored')
         else:

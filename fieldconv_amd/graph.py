@@ -65,9 +65,42 @@ def factor_stencil(sten, tol=2e-6):
     return rec
 
 
+def geometric_phases(rec, F, tol=2e-6):
+    """Geometric-phase form of factored records, or None: ph[e,f] = c[e] * g[e]^(f-B) with |g| = 1 -- what
+    FCPrecomp produces (fSten = exp(i m theta) times a per-edge weight, reference transforms/fc_precomp.py:88-95).
+    rec (E, RECF) as built by factor_stencil -> (E, 8) float32 [q bits, w_q, w_{q+1}, 0, Re c, Im c, Re g, Im g].
+    Every phase is reconstructed and compared; one host synchronisation (the verdict)."""
+    E = rec.shape[0]
+    B = (F - 1) // 2
+    if B < 1:
+        return None
+    ph = torch.view_as_complex(rec[:, 4:4 + 2 * F].reshape(E, F, 2).contiguous())
+    c = ph[:, B]
+    cmag = c.abs()
+    live = cmag > 0
+    one = torch.ones_like(c)
+    g = torch.where(live, ph[:, B + 1] / torch.where(live, c, one), one)
+    scale = ph.abs().amax(1)
+    err = (g.abs() - 1).abs() * cmag                       # |g| = 1 (relative to the phases' size)
+    p, pc = c, c
+    for m in range(1, B + 1):
+        p, pc = p * g, pc * g.conj()
+        err = torch.maximum(err, torch.maximum((ph[:, B + m] - p).abs(), (ph[:, B - m] - pc).abs()))
+    dead = ~live & (scale > 0)                             # c = 0 but other phases are not: not geometric
+    if bool((err > tol * scale).any() | dead.any()):
+        return None
+    geo = torch.zeros((E, 8), dtype=torch.float32, device=rec.device)
+    geo[:, 0:3] = rec[:, 0:3]
+    geo[:, 4] = c.real
+    geo[:, 5] = c.imag
+    geo[:, 6] = g.real
+    geo[:, 7] = g.imag
+    return geo
+
+
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', '_keep')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', '_keep')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -104,7 +137,7 @@ class SupportGraph:
         sten = supp_sten.contiguous()
         self._keep = (supp_edges, supp_sten)      # pins the storages the cache key refers to
         self.factored = False
-        self.rec_t = self.rec_s = self.sten_t = self.sten_s = self.runs_t = self.runs_s = None
+        self.rec_t = self.rec_s = self.sten_t = self.sten_s = self.runs_t = self.runs_s = self.geo_t = None
         # factored fast path: FCPrecomp's stencil is w[e,r] * ph[e,f] with two adjacent non-zero rings
         rec = None
         if allow_factored and E > 0 and self.R >= 2 and os.environ.get('FIELDCONV_DENSE', '0') != '1':
@@ -122,6 +155,12 @@ class SupportGraph:
             rs[:, 3] = self.nbr_s.view(torch.float32)
             self.rec_t = torch.cat((rt, pad), 0)
             self.rec_s = torch.cat((rs, pad), 0)
+            # forward pass: the shorter geometric-phase records when the phases allow it
+            geo = geometric_phases(rec, self.F) if os.environ.get('FIELDCONV_NO_GEO', '0') != '1' else None
+            if geo is not None:
+                gt = geo.index_select(0, perm_t)
+                gt[:, 3] = self.nbr_t.view(torch.float32)
+                self.geo_t = torch.cat((gt, torch.zeros((1024 // 32 + 16, 8), dtype=gt.dtype, device=dev)), 0)
 
             def run_offsets(key):
                 # runs[v, q] = number of v's slots with ring index < q  (N x 8 int32, see fc_csr::runs)

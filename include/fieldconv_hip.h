@@ -101,6 +101,16 @@ int fc_factored_record_floats(int32_t band_limit);
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd,
                         float* y, const fc_dims* dims, void* stream);
 
+/* ---- geometric-phase records (forward only) ---------------------------------------------- *
+ * FCPrecomp's phases are geometric in the frequency: ph[e,f] = c[e] * g[e]^(f-B) with |g| = 1
+ * (fSten = exp(i m theta) times the per-edge weight, reference transforms/fc_precomp.py:88-95).  When the
+ * caller has verified that as well, the forward pass takes records of fc_geometric_record_floats() = 8
+ * floats per edge, same order and padding as above:  [0] q bits, [1] w[q], [2] w[q+1], [3] other endpoint
+ * bits, [4],[5] = Re, Im c, [6],[7] = Re, Im g.  Same result as fc_forward up to fp32 rounding. */
+int fc_geometric_record_floats(void);
+int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_target, const float* wpk_fwd,
+                         float* y, const fc_dims* dims, void* stream);
+
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
  * Three calls on the same stream, sharing `workspace` (fc_backward_workspace_bytes(dims) bytes,
  * 256-byte aligned, untouched in between):

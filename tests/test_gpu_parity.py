@@ -339,6 +339,29 @@ def test_factored_stencil_path_vs_oracle_and_dense(shape, dev):
         assert rel_err(H(gW), gW_ref) < TOL
 
 
+def test_geometric_and_generic_records_agree(dev, monkeypatch):
+    """The forward pass takes the 32-byte geometric-phase records when the phases allow it; the generic
+    factored records and the dense rows must give the same answer on the same mesh."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from fieldconv_amd.transforms import FCPrecomp
+    N, k, I, O, B, R = 900, 20, 40, 24, 3, 6
+    data = sphere_support(N, k, seed=8)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(2)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    x[torch.rand(N, I, generator=g) < 0.03] = 0
+    W = (torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) * 0.05).to(dev)
+    geo = SupportGraph(edges.to(dev), sten.to(dev), N)
+    monkeypatch.setenv('FIELDCONV_NO_GEO', '1')
+    gen = SupportGraph(edges.to(dev), sten.to(dev), N)
+    assert geo.geo_t is not None and gen.geo_t is None and gen.factored
+    y_geo, y_gen = field_conv(x.to(dev), W, geo), field_conv(x.to(dev), W, gen)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), H(W))
+    assert rel_err(H(y_geo), y_ref) < TOL and rel_err(H(y_gen), y_ref) < TOL
+
+
 def test_empty_graph_and_isolated_vertices(dev):
     from fieldconv_amd.functional import field_conv
     from fieldconv_amd.graph import SupportGraph

@@ -224,3 +224,38 @@ def test_trans_field_matches_reference(ftype):
     # LiftBlock output = modReLU(TransField); check through the oracle's modReLU
     out = orc.tangent_nonlin_forward(y.detach().numpy(), c['p_nonlin.bias'])
     assert rel_err(out, c['y']) < 5e-6
+
+
+def test_factored_and_geometric_records_reconstruct_the_stencil():
+    """FCPrecomp stencils are rank-1, 2-sparse in the ring and geometric in the frequency: the records the
+    kernels read must reproduce every stencil entry; stencils without that structure are refused."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.graph import factor_stencil, geometric_phases
+    from fieldconv_amd.transforms import FCPrecomp
+    for B, R in ((1, 3), (2, 6), (3, 5)):
+        data = sphere_support(300, 9, seed=B)
+        edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+        F = 2 * B + 1
+        rec = factor_stencil(sten)
+        assert rec is not None
+        E = sten.shape[0]
+        q = rec[:, 0].view(torch.int32).long()
+        ph = torch.view_as_complex(rec[:, 4:4 + 2 * F].reshape(E, F, 2).contiguous())
+        w = torch.zeros(E, R)
+        w[torch.arange(E), q] = rec[:, 1]
+        w[torch.arange(E), q + 1] = rec[:, 2]
+        assert (w[:, :, None] * ph[:, None, :] - sten).abs().max() <= 3e-6 * sten.abs().max()
+        geo = geometric_phases(rec, F)
+        assert geo is not None and geo.shape == (E, 8)
+        c, g = torch.complex(geo[:, 4], geo[:, 5]), torch.complex(geo[:, 6], geo[:, 7])
+        m = torch.arange(-B, B + 1)
+        ang = torch.angle(g)[:, None] * m[None, :]
+        assert (c[:, None] * torch.polar(torch.ones_like(ang), ang) - ph).abs().max() <= 3e-6 * ph.abs().max()
+        assert torch.equal(geo[:, :3], rec[:, :3])
+        # a perturbed phase breaks the geometric form but not the rank-1 form
+        bad = rec.clone()
+        bad[7, 4] += 0.05 * float(ph.abs().max())
+        assert geometric_phases(bad, F) is None
+    g = torch.Generator().manual_seed(0)
+    dense = torch.complex(torch.randn(50, 4, 5, generator=g), torch.randn(50, 4, 5, generator=g))
+    assert factor_stencil(dense) is None
