@@ -339,6 +339,54 @@ def test_factored_stencil_path_vs_oracle_and_dense(shape, dev):
         assert rel_err(H(gW), gW_ref) < TOL
 
 
+def _random_shapes(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for _ in range(n):
+        R = int(rng.integers(2, 9))
+        B = int(rng.integers(1, 4))
+        I, O = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+        N = int(rng.integers(5, 400))
+        k = int(rng.integers(1, 45))
+        shapes.append((N, k, I, O, B, R, bool(rng.integers(0, 2))))
+    return shapes
+
+
+@pytest.mark.parametrize('shape', _random_shapes(40), ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d_%s' % (s[:6] + ('geo' if s[6] else 'dense',)))
+def test_random_shapes_vs_oracle(shape, dev):
+    """Seeded sweep over (n_rings, band limit, channel counts, mesh size, degree): every compiled shape class
+    (one or two frequency groups, one or two slab buffers, ragged tiles, channels off the tile sizes), on
+    FCPrecomp stencils (factored / geometric records) or random dense ones."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from fieldconv_amd.transforms import FCPrecomp
+    N, k, I, O, B, R, geo = shape
+    if geo:
+        k = min(k, N - 1) if N > 1 else 1
+        data = sphere_support(max(N, k + 2), max(k, 2), seed=N)
+        N = data.num_nodes
+        data.epsilon = float(data.logMag.max()) * 1.0001
+        edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+        g = torch.Generator().manual_seed(N * 7 + I)
+        x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+        x[torch.rand(N, I, generator=g) < 0.02] = 0
+        gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+        W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    else:
+        edges, sten, x, gy, W = make_case(N * 3 + O, N, k, I, O, B, R, bool(N % 2))
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(y), y_ref) < TOL
+    assert rel_err(H(gx), gx_ref) < TOL
+    assert rel_err(H(gW), gW_ref) < TOL
+
+
 def test_geometric_and_generic_records_agree(dev, monkeypatch):
     """The forward pass takes the 32-byte geometric-phase records when the phases allow it; the generic
     factored records and the dense rows must give the same answer on the same mesh."""
