@@ -106,8 +106,8 @@ def reduced_precision_run(args, conv, x, edges, sten, step):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)       # 0.5 ms each: long enough for steady clocks and a full launch queue
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--verts', type=int, default=20000, help='vertices per GPU')
     ap.add_argument('--k', type=int, default=32)
     ap.add_argument('--channels', type=int, default=48)
@@ -224,7 +224,8 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    kernel_timer.reset()
+    kernel_timer.reset(pairs=3 * (args.steps // 4 + 1))
+    kernel_timer.stride = 4            # every 4th launch of each kernel inside the timed region carries a HIP-event pair
     kernel_timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -302,14 +303,14 @@ def main():
             def bstep():
                 yb = blk(x, edges, sten)
                 torch.autograd.grad(yb, [x] + bparams, grad_outputs=gy)
-            for _ in range(3):
-                bstep()
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
             for _ in range(10):
                 bstep()
             torch.cuda.synchronize()
-            bms = (time.perf_counter() - tb) / 10 * 1e3
+            tb = time.perf_counter()
+            for _ in range(50):
+                bstep()
+            torch.cuda.synchronize()
+            bms = (time.perf_counter() - tb) / 50 * 1e3
             out['fc_resnet_block'] = {'ms_per_step': bms, 'medges_per_s': 2 * E / (bms * 1e-3) / 1e6,
                                       'note': 'FCResNetBlock fwd+bwd, edges counted once per FieldConv (2 per block)'}
         if world == 1 and not use_dist and not args.no_extras and os.environ.get('FC_MFMA') is None:

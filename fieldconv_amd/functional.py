@@ -14,14 +14,23 @@ from ._lib import FcCsr, FcDims, check
 class KernelTimer:
     """Optional HIP-event bracket around the single-kernel launches `fc_forward` / `fc_backward`
     (each of those entry points enqueues exactly one kernel on the current stream).  bench.py turns
-    it on for the timed region to obtain per-kernel durations for the roofline figure."""
+    it on for the timed region to obtain per-kernel durations for the roofline figure.  An event pair is a
+    pair of barrier packets on the stream (about 5 us of idle GPU per bracket), so only every `stride`-th
+    launch of a kernel is bracketed."""
 
     def __init__(self):
         self.enabled = False
+        self.stride = 1
         self.events = {}
+        self.count = {}
+        self.pool = []
 
-    def reset(self):
+    def reset(self, pairs=0):
+        """Forget earlier measurements; `pairs` event pairs are created now (hipEventCreate is not free and
+        must not land in the timed region)."""
         self.events = {}
+        self.count = {}
+        self.pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs)]
 
     def elapsed_ms(self):
         """{name: [ms, ...]}; call after torch.cuda.synchronize()."""
@@ -36,13 +45,21 @@ class _timed:
         self.name = name
 
     def __enter__(self):
+        self.on = False
         if kernel_timer.enabled:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
+            n = kernel_timer.count.get(self.name, 0)
+            kernel_timer.count[self.name] = n + 1
+            self.on = n % kernel_timer.stride == 0
+        if self.on:
+            if kernel_timer.pool:
+                self.a, self.b = kernel_timer.pool.pop()
+            else:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if kernel_timer.enabled:
+        if self.on:
             self.b.record()
             kernel_timer.events.setdefault(self.name, []).append((self.a, self.b))
         return False
