@@ -257,8 +257,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 #pragma unroll
                     for (int ff = 0; ff < MG; ++ff)
                         if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(h[r][ff].x), fabsf(h[r][ff].y)));
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+                mx = wave_max_nonneg(mx);
                 float inv;
                 split_scale(mx, scale, inv);
                 if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv; }     // read after the slab barrier below

@@ -38,6 +38,21 @@ __device__ __forceinline__ int first_tile_of_block() {
     return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
 }
 
+// Maximum of a NON-NEGATIVE float over the wavefront, the same value in every lane.  Six v_max with DPP operands
+// (row shifts, then row broadcasts) and one v_readlane instead of six ds_bpermute round trips through the LDS
+// crossbar (__shfl_xor).  Non-negative floats order like their bit patterns, and the zero fill of the shifts is
+// neutral for a maximum.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true));      // row_shr:1
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true));      // row_shr:2
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true));      // row_shr:4
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true));      // row_shr:8  -> lane 15 of each row holds the row maximum
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, true));      // row_bcast:15
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, true));      // row_bcast:31 -> lane 63 holds the maximum
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 // Compile-time loop: fn(std::integral_constant<int, i>) for i in [BEGIN, END).
 template <int BEGIN, int END, class Fn>
 __device__ __forceinline__ void static_for(Fn&& fn) {

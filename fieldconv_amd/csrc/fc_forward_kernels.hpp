@@ -115,8 +115,7 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
 #pragma unroll
         for (int ff = 0; ff < MG; ++ff)
             if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(c[r][ff].x), fabsf(c[r][ff].y)));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    mx = wave_max_nonneg(mx);
     float scale, inv;
     split_scale(mx, scale, inv);
     if (MULTI_GROUP && !first_group) {
