@@ -123,6 +123,200 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     }
 }
 
+// ------------------------------------------------ filter gradient on half-precision operands
+// The same contraction gW[k,i] = sum_v H[v,k] conj(xt[v,i]) on v_mfma_f32_16x16x16_f16 (k dimension = the 16
+// vertices of a tile), from the same fp32 slabs.  The fp32 matrix pipe bounds the kernel above; here
+// every operand is carried as two halves (fc_tile.hpp, split mode) and a product is hi*hi + hi*lo + lo*hi:
+//   first operand : each wavefront converts its vertex's row of the slab once per tile, scaled by the
+//                   power-of-two s_v the data kernel used for that vertex, into an LDS image
+//                   [vertex][plane][k]; the k-major fragments come out of it with ds_read_b64_tr_b16;
+//   second operand: xt[v,i] / s_v -- a scale per vertex cannot be factored out of a sum over vertices, so it
+//                   moves to the other factor -- times one power-of-two scale t[i] per column and tile,
+//                   split into halves, planes [i][vertex].
+// All scales arrive with the slab (BwdArgs::tails), so the conversion has no reduction and no extra barrier.
+// The tile's products start from zero and are added to the fp32 running sums with the factor 1/t[i].
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
+
+__device__ __forceinline__ f32x4 mfma16h(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+
+template <int T>
+__global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
+    const float2* __restrict__ gx_, const float* __restrict__ hdump, float2* __restrict__ ggwp /* [P][F][KP][IP] */,
+    const BwdArgs a, const int F, const int B, const int KV /* valid k entries, R*O */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MmaGeom& mg = a.g;
+    const int KD = a.KD, KP = mg.KP, IP = mg.MP, I = a.I;
+    const int KSI = filter_image_stride(KP);
+    const int xplane = IP * kXbStride;
+    float* const slab0 = reinterpret_cast<float*>(smem);               // [2][slab_stride]: H of a tile, fp32, + scales (DMA target)
+    lds_f16* const img = (lds_f16*)(slab0 + 2 * a.slab_stride);        // [16 vertices][re_hi, re_lo, im_hi, im_lo][KP] halves, row stride KSI
+    lds_f16* const xb = img + kTile * KSI;                             // [c_hi, c_lo, d_hi, d_lo, -d_hi, -d_lo][IP][kXbStride] halves
+    lds_f16* const zeros = xb + 6 * IP * kXbStride;                    // 16 bytes of zeros: the lower half of the [lo; 0] fragments
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y;
+    const int m = f - B;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int idx = tid; idx < (kTile * KSI + 6 * xplane) / 2 + 4; idx += kThreads) slab0[2 * a.slab_stride + idx] = 0.f;
+
+    // my gW tiles all lie in ONE column tile (i0 = 16 * (wave % NMT)), so the second-operand fragments are read once per
+    // tile; the row tiles of that column are dealt round-robin to the wavefronts that share it
+    const int my_ct = wave % mg.NMT, my_idx = wave / mg.NMT;
+    const int ct_waves = (kWaves - my_ct + mg.NMT - 1) / mg.NMT;
+    const int i0 = my_ct * 16;
+    int gw_h[T];                // first k of my row tiles; -1: unused slot
+#pragma unroll
+    for (int n = 0; n < T; ++n) {
+        const int rt = my_idx + n * ct_waves;
+        gw_h[n] = (rt * 16 < KP) ? rt * 16 : -1;
+    }
+    // The MFMA's 32 k entries are the 16 vertices' hi halves followed by their lo halves (first operand) against
+    // [hi; hi] and [lo; 0] of the second: (A_hi | A_lo)(B_hi; B_hi) + (A_hi | A_lo)(B_lo; 0) = hi*hi + lo*hi + hi*lo, two
+    // full-rate v_mfma_f32_16x16x32_f16 per real product.  Lane groups 0/1 carry vertices 0-7 / 8-15 of the hi planes,
+    // groups 2/3 the same vertices of the lo planes.
+    // A fragment: lane 4q+p of a lane group addresses vertex (vb + q), entries k0+4p .. +3 of its plane, and receives entry
+    // k0 + lane%16 of the vertices vb .. vb+3; two reads (vb = 8*(g&1), +4) make the group's eight k entries.
+    const int a_lane = (8 * (fq & 1) + ((lane & 15) >> 2)) * KSI + 4 * (lane & 3) + (fq >= 2 ? KP : 0);
+    const int b_lane = fr * kXbStride + 8 * (fq & 1);    // B fragment: plane[i = i0 + fr][vertices 8*(g&1) .. +7]
+    const bool upper = fq >= 2;
+
+    f32x4 gre[T], gim[T];
+#pragma unroll
+    for (int n = 0; n < T; ++n) { gre[n] = f32x4{0.f, 0.f, 0.f, 0.f}; gim[n] = gre[n]; }
+
+    const int npieces = a.slab_stride / 256;      // 1 KiB DMA pieces per slab
+    auto dma_slab = [&](const int tile, const int buf) {
+        const float* src = hdump + ((size_t)tile * F + f) * a.slab_stride;
+        for (int p = wave; p < npieces; p += kWaves)
+            lds_dma16_untracked(src + p * 256 + lane * 4, slab0 + buf * a.slab_stride + p * 256);
+    };
+
+    if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
+    float2 xv = make_float2(0.f, 0.f);
+    {
+        const int j = blockIdx.x * kTile + wave;
+        if (blockIdx.x < a.ntiles && j < a.N && lane < I) xv = gx_[(size_t)j * I + lane];
+    }
+    const int nchunk = KP / 4;                     // chunks of four k entries; a lane converts chunks lane and lane + 64
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));     // rotated feature of my source row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my pieces of slab `buf` have landed
+        __syncthreads();                                               // everyone's have; the previous tile's MFMAs are done
+        const int tn = tile + gridDim.x;
+        if (tn < a.ntiles) {
+            dma_slab(tn, buf ^ 1);
+            const int jn = tn * kTile + wave;
+            xv = (jn < a.N && lane < I) ? gx_[(size_t)jn * I + lane] : make_float2(0.f, 0.f);
+        } else {
+            xv = make_float2(0.f, 0.f);
+        }
+        const float* const sl = slab0 + buf * a.slab_stride;
+        const float* const tail = sl + a.slab_floats;       // [16] s_v, [16] 1/s_v, [IP] t, [IP] 1/t
+        {   // ---- my vertex's row of H: scale, split, store plane-major
+            const float* row = sl + wave * KD;
+            const float s = tail[wave];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c < nchunk) {
+                    float4 v0 = *reinterpret_cast<const float4*>(row + 8 * c);          // (re, im) of k = 4c, 4c+1
+                    float4 v1 = *reinterpret_cast<const float4*>(row + 8 * c + 4);      // k = 4c+2, 4c+3
+                    // entries past the R*O valid ones were never written by the data kernel
+                    if (4 * c + 0 >= KV) { v0.x = 0.f; v0.y = 0.f; }
+                    if (4 * c + 1 >= KV) { v0.z = 0.f; v0.w = 0.f; }
+                    if (4 * c + 2 >= KV) { v1.x = 0.f; v1.y = 0.f; }
+                    if (4 * c + 3 >= KV) { v1.z = 0.f; v1.w = 0.f; }
+                    f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+                    split_halves2(f32x2{v0.x, v0.y}, s, h0, l0);
+                    split_halves2(f32x2{v0.z, v0.w}, s, h1, l1);
+                    split_halves2(f32x2{v1.x, v1.y}, s, h2, l2);
+                    split_halves2(f32x2{v1.z, v1.w}, s, h3, l3);
+                    lds_f16* p = img + wave * KSI + 4 * c;
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) h4 lds_h4;
+                    *(lds_h4*)(p) = h4{h0.x, h1.x, h2.x, h3.x};                 // re_hi
+                    *(lds_h4*)(p + KP) = h4{l0.x, l1.x, l2.x, l3.x};            // re_lo
+                    *(lds_h4*)(p + 2 * KP) = h4{h0.y, h1.y, h2.y, h3.y};        // im_hi
+                    *(lds_h4*)(p + 3 * KP) = h4{l0.y, l1.y, l2.y, l3.y};        // im_lo
+                }
+            }
+        }
+        if (lane < IP) {   // ---- second operand: xt / s_v * t[i], halves, planes [i][vertex]
+            f16x2 hi, lo;
+            split_halves2(f32x2{xt.x, xt.y}, tail[kTile + wave] * tail[2 * kTile + lane], hi, lo);
+            lds_f16* p = xb + lane * kXbStride + wave;
+            p[0] = hi.x;
+            p[xplane] = lo.x;
+            p[2 * xplane] = hi.y;
+            p[3 * xplane] = lo.y;
+            p[4 * xplane] = -hi.y;
+            p[5 * xplane] = -lo.y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        if (!(a.dbg & 4)) {
+            // second operand, once per tile: [hi; hi] from the hi planes in every lane group, [lo; 0] from the lo planes in
+            // groups 0/1 and from the zero block in groups 2/3
+            const lds_f16* bp = xb + i0 * kXbStride + b_lane;
+            const lds_f16* bl = upper ? zeros : bp + xplane;
+            const int lstep = upper ? 0 : 2 * xplane;
+            const u32x4 c_hh = *reinterpret_cast<lds_u32x4*>(bp), c_l0 = *reinterpret_cast<lds_u32x4*>(bl);
+            const u32x4 d_hh = *reinterpret_cast<lds_u32x4*>(bp + 2 * xplane), d_l0 = *reinterpret_cast<lds_u32x4*>(bl + lstep);
+            const u32x4 nd_hh = *reinterpret_cast<lds_u32x4*>(bp + 4 * xplane), nd_l0 = *reinterpret_cast<lds_u32x4*>(bl + 2 * lstep);
+            const float it = tail[2 * kTile + IP + i0 + fr];
+#pragma unroll
+            for (int n = 0; n < T; ++n) {
+                if (gw_h[n] >= 0) {
+                    // first operand: (hi | lo) of the real and of the imaginary part of H^T
+                    const lds_f16* ap = img + a_lane + gw_h[n];
+                    u32x4 are, aim;
+                    {
+                        const u32x2 r0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap)));
+                        const u32x2 r1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * KSI)));
+                        const u32x2 i0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP)));
+                        const u32x2 i1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP + 4 * KSI)));
+                        are = u32x4{r0.x, r0.y, r1.x, r1.y};
+                        aim = u32x4{i0_.x, i0_.y, i1_.x, i1_.y};
+                    }
+                    // H conj(X), H = a + ib, X = c + id:  re = a c + b d,  im = b c - a d
+                    f32x4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
+                    re = mfma32h(are, c_l0, re);  re = mfma32h(are, c_hh, re);
+                    re = mfma32h(aim, d_l0, re);  re = mfma32h(aim, d_hh, re);
+                    im = mfma32h(aim, c_l0, im);  im = mfma32h(aim, c_hh, im);
+                    im = mfma32h(are, nd_l0, im); im = mfma32h(are, nd_hh, im);
+                    gre[n] += re * it;
+                    gim[n] += im * it;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // flush my gW partial
+#pragma unroll
+    for (int n = 0; n < T; ++n) {
+        if (gw_h[n] >= 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = gw_h[n] + 4 * fq + jj;
+                const int i = i0 + fr;
+                ggwp[(((size_t)blockIdx.x * F + f) * KP + k) * IP + i] = make_float2(gre[n][jj], gim[n][jj]);
+            }
+        }
+    }
+}
+
 // gw_eff[o][i][r][f] = 1/F sum_p gwp[p][f][r*O+o][i]
 __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __restrict__ gw, int P, int F, int R,
                                     int O, int I, int KP, int IP) {
@@ -161,14 +355,18 @@ size_t backward_workspace_bytes(const fc_dims* d) {
 
 template <int T>
 static int launch_backward_filter(const float2* x, const float* hdump, float2* gwp, const BwdArgs& a, const BwdPlan& p,
-                                  int B, hipStream_t stream) {
-    auto kern = fc_backward_filter_kernel<T>;
+                                  const fc_dims* d, hipStream_t stream) {
     if (p.lds_filter > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)p.lds_filter) != hipSuccess)
-            return FC_ERR_LAUNCH;
+        const void* fn = p.fhalf ? reinterpret_cast<const void*>(fc_backward_filter_half_kernel<T>)
+                                 : reinterpret_cast<const void*>(fc_backward_filter_kernel<T>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_filter) != hipSuccess) return FC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a, p.F, B);
+    if (p.fhalf)
+        hipLaunchKernelGGL(fc_backward_filter_half_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a,
+                           p.F, d->B, d->R * d->O);
+    else
+        hipLaunchKernelGGL(fc_backward_filter_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a, p.F,
+                           d->B);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -180,10 +378,14 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
     const float* hdump = reinterpret_cast<const float*>(ws);
     float2* gwp = reinterpret_cast<float2*>(static_cast<char*>(ws) + p.hdump_bytes);
     const float2* x2 = reinterpret_cast<const float2*>(x);
-    const int need = (p.ngw + kWaves - 1) / kWaves;
-    if (need <= 2) return launch_backward_filter<2>(x2, hdump, gwp, a, p, d->B, stream);
-    if (need <= 4) return launch_backward_filter<4>(x2, hdump, gwp, a, p, d->B, stream);
-    if (need <= kMaxGwTiles) return launch_backward_filter<kMaxGwTiles>(x2, hdump, gwp, a, p, d->B, stream);
+    int need = (p.ngw + kWaves - 1) / kWaves;
+    if (p.fhalf) {      // column-grouped assignment: the wavefronts of the smallest column group bound the slot count
+        const int per_col = kWaves / p.g.NMT, row_tiles = p.KP / 16;
+        need = (row_tiles + per_col - 1) / per_col;
+    }
+    if (need <= 2) return launch_backward_filter<2>(x2, hdump, gwp, a, p, d, stream);
+    if (need <= 4) return launch_backward_filter<4>(x2, hdump, gwp, a, p, d, stream);
+    if (need <= kMaxGwTiles) return launch_backward_filter<kMaxGwTiles>(x2, hdump, gwp, a, p, d, stream);
     return FC_ERR_UNSUPPORTED;
 }
 

@@ -29,6 +29,7 @@
 namespace fc {
 
 
+constexpr int kXbStride = 24;    // halves per row of the half-precision filter kernel's second-operand planes (16 vertices + pad)
 constexpr int kXtStride = 20;    // floats per row of the filter kernel's rotated-feature tiles in LDS
 constexpr int kMaxGwTiles = 8;   // 16x16 complex gW tiles a wavefront can own
 
@@ -45,6 +46,9 @@ struct BwdArgs {
                          // (rows 4 apart per lane group) hit distinct banks
     int slab_floats;     // 16 * KD
     int slab_stride;     // floats between consecutive (tile, f) slabs in hdump (multiple of 256)
+    int tails;           // 1: every slab is followed by the scales the half-precision filter kernel needs:
+                         // [16] s_v, [16] 1/s_v (the data kernel's vertex scales), [IP] t[i], [IP] 1/t[i] (column scales
+                         // of x~[v][i] / s_v over the tile's vertices)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
 };
 
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const ring = vscale + 4 * kTile + wave * NR * 256;   // factored: [NR][256] floats per wavefront
+    float* const colmag = vscale + 4 * kTile;                    // tails: [16 vertices][64] magnitudes |x[v][i]| / s_v
+    float* const ring = colmag + (a.tails ? kTile * 64 : 0) + wave * NR * 256;   // factored: [NR][256] floats per wavefront
     float* vs = vscale;                                          // scale buffer of the current frequency group
 
     for (int idx = tid; idx < slab_floats(mg); idx += kThreads) hre[idx] = 0.f;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             }
 
             // ---------------------------------------------------------------- slabs -> gxt_f -> gx
-            float scale = 1.f;
+            float scale = 1.f, inv_scale = 1.f;
             if constexpr (SPLIT) {
                 // one power-of-two scale for this wavefront's vertex and frequency group (fc_tile.hpp, split mode)
                 float mx = 0.f;
@@ -258,9 +263,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     for (int ff = 0; ff < MG; ++ff)
                         if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(h[r][ff].x), fabsf(h[r][ff].y)));
                 mx = wave_max_nonneg(mx);
-                float inv;
-                split_scale(mx, scale, inv);
-                if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv; }     // read after the slab barrier below
+                split_scale(mx, scale, inv_scale);
+                if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv_scale; }     // read after the slab barrier below
             }
 #pragma unroll
             for (int ff = 0; ff < MG; ++ff) {
@@ -305,7 +309,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                                 asm volatile("" : "+v"(o0), "+v"(d0));
                             }
                         }
+                        if (a.tails && lane == 0) {
+                            dst[a.slab_floats + wave] = scale;
+                            dst[a.slab_floats + kTile + wave] = inv_scale;
+                        }
                         __syncthreads();
+                        if (a.tails && ff == 0 && e_active)     // bound of the filter kernel's second operand: |x[v][i]| / s_v
+                            colmag[ev * 64 + ei] = sqrtf(exs.x * exs.x + exs.y * exs.y) * vs[kTile + ev] * 1.0000002f;
                     }
                     if (mma_active) {
                         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
@@ -319,6 +329,23 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         store_partial(part, mg, it, kp, lane, acc_re, acc_im);
                     }
                     __syncthreads();
+                    if constexpr (SPLIT) {
+                        if (a.tails && ff == 0 && tid < IP) {
+                            // power-of-two column scales, the same for every frequency of this group
+                            float cm = 0.f;
+                            if (tid < I)
+                                for (int v = 0; v < kTile; ++v) cm = fmaxf(cm, colmag[v * 64 + tid]);
+                            float t, inv_t;
+                            split_scale(cm, t, inv_t);
+#pragma unroll
+                            for (int f2 = 0; f2 < MG; ++f2)
+                                if (f0 + f2 < F) {
+                                    float* tail = hdump + ((size_t)tile * F + f0 + f2) * a.slab_stride + a.slab_floats + 2 * kTile;
+                                    tail[tid] = t;
+                                    tail[IP + tid] = inv_t;
+                                }
+                        }
+                    }
                     if (e_active) {
                         const int m = f - B;
                         float2 z = sum_partials(part, mg, ev, ei);
@@ -352,9 +379,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     }
 }
 
+// Row stride (halves) of the half-precision filter kernel's image of a tile, [16 vertices][4 planes][KP]: a multiple of
+// 128 plus 16, so that the 8-byte transposed reads of eight consecutive vertices fall into distinct banks.
+__host__ __device__ inline int filter_image_stride(int KP) { return round_up(4 * KP, 128) + 16; }
+
 struct BwdPlan {
     MmaGeom g, gd;
-    int IP, KP, KD, ntiles, ngw, P, F, slab_floats, slab_stride;
+    int IP, KP, KD, ntiles, ngw, P, F, slab_floats, slab_stride, fhalf;
     size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes;
     bool ok, ok_factored;
 };
@@ -374,10 +405,14 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.P = P;
     p.KD = 2 * p.g.KP + 8;
     p.slab_floats = kTile * p.KD;
-    p.slab_stride = round_up(p.slab_floats, 256);
-    p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile) * sizeof(float);
+    // filter kernel on half-precision operands (fc_backward.hip) when its image fits beside the two fp32 slabs
+    const int stride_tails = round_up(p.slab_floats + 2 * kTile + 2 * p.IP, 256);
+    const size_t lds_half = (size_t)(2 * stride_tails + (kTile * filter_image_stride(p.KP) + 6 * p.IP * kXbStride) / 2 + 4) * sizeof(float);
+    p.fhalf = (halves != 0 && p.IP <= 64 && p.KP <= 512 && lds_half <= kMaxLds) ? 1 : 0;
+    p.slab_stride = p.fhalf ? stride_tails : round_up(p.slab_floats, 256);
+    p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile + (p.fhalf ? kTile * 64 : 0)) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
-    p.lds_filter = (size_t)(2 * p.slab_stride + 3 * p.IP * kXtStride) * sizeof(float);
+    p.lds_filter = p.fhalf ? lds_half : (size_t)(2 * p.slab_stride + 3 * p.IP * kXtStride) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
     p.ok = p.lds_data <= kMaxLds && p.lds_filter <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves &&
@@ -397,6 +432,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.KD = p.KD;
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
+    a.tails = p.fhalf;
     { const char* e = getenv("FC_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
     return a;
 }
