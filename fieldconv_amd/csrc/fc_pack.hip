@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
         _Float16 rh, rl, ih, il;
         split_halves(v.x * scale, rh, rl);
         split_halves(v.y * scale, ih, il);
-        _Float16* p = planes + (size_t)f * 2 * g.split * plane + (size_t)m * g.KP + k;
+        _Float16* p = planes + (size_t)f * 2 * g.split * plane + ((size_t)(k >> 5) * g.MP + m) * 32 + (k & 31);       // k-block major
         if (g.split == 2) {
             p[0] = rh;
             p[plane] = rl;

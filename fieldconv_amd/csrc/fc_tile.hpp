@@ -48,7 +48,7 @@ __host__ __device__ inline MmaGeom make_mma_geom(int M, int R, int channels, int
 
 // Floats in the packed filter image of one contraction (F frequencies, M rows, K entries per row).
 //   fp32 : [F][2 planes re,im][MP][KP] floats
-//   split: [MP] inverse row scales (floats), then [F][4 planes re_hi,re_lo,im_hi,im_lo][MP][KP] halves
+//   split: [MP] inverse row scales (floats), then [F][4 planes re_hi,re_lo,im_hi,im_lo][KP/32 k blocks][MP][32] halves
 //   half : the same with the 2 planes re_hi, im_hi
 __host__ __device__ inline size_t packed_image_floats(int M, int R, int channels, int F, int halves) {
     const MmaGeom g = make_mma_geom(M, R, channels, halves);
@@ -183,13 +183,16 @@ __device__ __forceinline__ void split_pair_store(lds_u32* row, int dword_offset,
 __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const lds_f16* sp, const MmaGeom& g, int mt, int kp,
                                                int lane, f32x4& acc_re, f32x4& acc_im) {
     const int fr = lane & 15, fq = lane >> 4;
+    // split images are k-block major, [plane][k block][MP rows][32 halves]: the 16 rows x 64 B a wavefront loads per
+    // plane and k block are one contiguous KiB (eight full cache lines) instead of sixteen half lines
     const int wplane = g.MP * g.KP * 2;                 // bytes
-    const int wv = ((mt * 16 + fr) * g.KP + 8 * fq) * 2;
+    const int wv = ((mt * 16 + fr) * 32 + 8 * fq) * 2;
+    const int wkb = g.MP * 64;                          // bytes per k block
     const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     if (g.split == 1) {
         // reduced precision: planes (re_hi, im_hi) only, one MFMA per real product
         const lds_f16* s1 = sp + fr * g.KS + 16 * fq;   // fragment (k block 4*kb + fq, plane p) at + 64*kb + 8*p halves
-        auto ldw1 = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
+        auto ldw1 = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + wkb * kb); };
         auto lds1 = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s1 + 64 * kb + 8 * plane); };
         u32x4 wr = ldw1(0, kp), wi = ldw1(1, kp);
         for (int kb = kp; kb < g.KST; kb += g.NKP) {
@@ -206,7 +209,7 @@ __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const l
         return;
     }
     const lds_f16* s0 = sp + fr * g.KS + 32 * fq;       // fragment (k block 4*kb + fq, plane p) at + 128*kb + 8*p halves
-    auto ldw = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb); };
+    auto ldw = [&](int plane, int kb) { return buffer_load16(wimg, wv, f_bytes + plane * wplane + wkb * kb); };
     auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + 128 * kb + 8 * plane); };
     u32x4 wrh = ldw(0, kp), wrl = ldw(1, kp), wih = ldw(2, kp), wil = ldw(3, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
