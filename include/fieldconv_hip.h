@@ -65,7 +65,7 @@ int fc_supported(const fc_dims* dims);
  * from (zonal, spherical, phase); the 1/(2B+1) of :14,:25,:33 is folded in here.
  * The packed images are opaque to the caller: allocate fc_packed_filter_floats_{fwd,bwd}() floats
  * each and hand them to the convolution calls.  Default ("split") layout, one image per contraction:
- *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x OP x KP halves,
+ *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves,
  *   forward rows o, k = r*ceil8(I) + i;  backward rows i, k = r*ceil8(O) + o, conjugated;
  *   OP = ceil16(rows), KP = ceil32(R * ceil8(channels)).
  * With FC_MFMA=f32 in the environment: F x {re,im} x OP x ceil16(R*channels) floats. */
