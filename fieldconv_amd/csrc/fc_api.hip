@@ -23,6 +23,13 @@ static bool dims_supported(const fc_dims* d) {
     return true;
 }
 
+// The factored kernels address feature rows with 32-bit byte offsets: N * C * 8 must stay below 4 GiB
+// (8 million vertices at 64 channels).
+static bool rows_fit_32bit(const fc_dims* d) {
+    const uint64_t c = (uint64_t)(d->I > d->O ? d->I : d->O);
+    return (uint64_t)d->N * c * 8 < (1ull << 32);
+}
+
 }  // namespace fc
 
 extern "C" {
@@ -86,7 +93,7 @@ int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_tar
                         const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!rec_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
-    if (!fc::dims_supported(dims) || dims->R > 8) return FC_ERR_UNSUPPORTED;
+    if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
     return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, 1, static_cast<hipStream_t>(stream));
 }
 
@@ -96,7 +103,7 @@ int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_ta
                          const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!geo_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
-    if (!fc::dims_supported(dims) || dims->R > 8) return FC_ERR_UNSUPPORTED;
+    if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
     return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, static_cast<hipStream_t>(stream));
 }
 
@@ -128,7 +135,7 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
     const int rc = check_bwd(x, gy, rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;
     if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
-    if (dims->R > 8) return FC_ERR_UNSUPPORTED;
+    if (dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
     return fc::backward_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, true,
                                   static_cast<hipStream_t>(stream));
 }

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
                     const int d0 = __float_as_int(rec_ptr(0)[3]);
                     const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
-                    ga = ggy[(size_t)d0 * O + ol];
-                    gb = ggy[(size_t)d1 * O + ol];
+                    ga = gather_row(ggy, d0, 8u * O, 8u * ol);
+                    gb = gather_row(ggy, d1, 8u * O, 8u * ol);
                 }
                 // one slot with compile-time lower ring Q: z_f = g conj(ph_f); h[Q] += w0 z; h[Q+1] += w1 z
                 auto slot = [&](auto qc, const int s, float2& gcur) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                     const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
                     const f32x2 gv = f32x2{gcur.x, gcur.y};
-                    gcur = ggy[(size_t)d2 * O + ol];
+                    gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
                     const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
                     // z_f = g conj(ph_f) in two passes, then the ring updates (see fc_forward_kernels.hpp)
                     f32x2 ph[MG], z[MG];

@@ -53,6 +53,14 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// Row gather with a 32-bit byte offset: base (wave-uniform, SGPR pair) + vertex * row bytes + lane part fits the
+// scalar-base form of global_load, one v_mad instead of a 64-bit multiply and add per slot.  The callers guarantee
+// N * C * 8 < 2^32 (checked on the host).
+__device__ __forceinline__ float2 gather_row(const float2* __restrict__ base, int vertex, uint32_t row_bytes, uint32_t lane_bytes) {
+    const uint32_t off = (uint32_t)vertex * row_bytes + lane_bytes;
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + off);
+}
+
 // Compile-time loop: fn(std::integral_constant<int, i>) for i in [BEGIN, END).
 template <int BEGIN, int END, class Fn>
 __device__ __forceinline__ void static_for(Fn&& fn) {

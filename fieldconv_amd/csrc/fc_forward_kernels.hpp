@@ -338,8 +338,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
             const int n0 = __float_as_int(ring[3]);
             const int n1 = __float_as_int(ring[min(1, nslots - 1) * RECF + 3]);
-            r0 = gx_[(size_t)n0 * I + cl];
-            r1 = gx_[(size_t)n1 * I + cl];
+            r0 = gather_row(gx_, n0, 8u * I, 8u * cl);
+            r1 = gather_row(gx_, n1, 8u * I, 8u * cl);
         }
     };
     float2 pxa, pxb;
@@ -407,14 +407,14 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
                     const f32x4 cg = *reinterpret_cast<const f32x4*>(rp + 4);
                     f32x2 zf[F];
                     rotate_geometric<B>(f32x2{xcur.x, xcur.y}, f32x2{cg.x, cg.y}, f32x2{cg.z, cg.w}, zf);
-                    xcur = gx_[(size_t)n2 * I + cl];
+                    xcur = gather_row(gx_, n2, 8u * I, 8u * cl);
 #pragma unroll
                     for (int ff = 0; ff < MG; ++ff)
                         if (f0 + ff < F) z[ff] = zf[f0 + ff];
                 } else {
                     f32x2 xt[F];
                     rotate_all<B>(f32x2{xcur.x, xcur.y}, xt);
-                    xcur = gx_[(size_t)n2 * I + cl];
+                    xcur = gather_row(gx_, n2, 8u * I, 8u * cl);
                     // z_f = ph_f * xt_f in two passes over the frequencies, then the ring updates: no packed op
                     // directly follows the one it depends on
                     f32x2 ph[MG];
