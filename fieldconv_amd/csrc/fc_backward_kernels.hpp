@@ -160,7 +160,11 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             // ---------------------------------------------------------------- gather H for my source
             if constexpr (FACTORED) {
                 if (g > 0) for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);   // walk the slots again
-                auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
+                auto rec_ptr = [&](const int s) {
+                // when the records fill their 1 KiB chunks exactly the ring is one contiguous array of NR*CR records
+                if constexpr (CR * RECF == 256) return ring + ((s * RECF) & (NR * 256 - 1));
+                else return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF;
+            };
                 float2 ga = make_float2(0.f, 0.f), gb = ga;
                 if (nslots > 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed

@@ -380,7 +380,11 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             }
             const int nslots = end - beg;
             // record s of this target (s relative to beg) lives at ring[((s >> LOG_CR) & (NR-1)) * 256 + (s & (CR-1)) * RECF]
-            auto rec_ptr = [&](const int s) { return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF; };
+            auto rec_ptr = [&](const int s) {
+                // when the records fill their 1 KiB chunks exactly the ring is one contiguous array of NR*CR records
+                if constexpr (CR * RECF == 256) return ring + ((s * RECF) & (NR * 256 - 1));
+                else return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF;
+            };
             float2 xa = pxa, xb = pxb;
             if (g > 0) first_rows(nslots, xa, xb);
             // One slot whose lower ring is the compile-time constant Q: contrib[Q] += w0 z, contrib[Q+1] += w1 z
