@@ -1,0 +1,211 @@
+// ECHO descriptors for gfx950 (reference nn/echo.py:94-148): for every vertex n and channel c
+// a histogram over the dS cells of a rasterised disk, hist[n,c,b] = sum over in-edges e of the bilinear votes of
+// the point ln_e * exp(-i angle(x[src_e,c])) carrying the value x[src_e,c] * wxp_e; the descriptor is |hist|.
+// The reference does this with `nonzero` compaction (host sync), four index_adds over E*C*4 votes and autograd;
+// here: one target-centric kernel (a wavefront per vertex, lane = channel, lane-private histogram rows in LDS, no
+// global atomics) and one source-centric kernel for the input gradient.
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+
+namespace fc {
+
+constexpr int kEchoWaves = 4;                 // vertices per workgroup
+constexpr int kEchoMaxBins = 4;               // n_bins <= 4: (2*4+1)^2 = 81 raster cells
+constexpr int kEchoMaxCells = (2 * kEchoMaxBins + 1) * (2 * kEchoMaxBins + 1);
+
+// Cells of the (2n+1)^2 raster inside the disk of radius n + 0.25, numbered in row-major order; cells outside alias
+// bin 0 (reference nn/echo.py:11-27).  Returns the number of bins.
+__host__ __device__ inline int echo_hist_dim(int n) {
+    int d = 0;
+    for (int i = -n; i <= n; ++i)
+        for (int j = -n; j <= n; ++j) d += (16 * (i * i + j * j) <= (4 * n + 1) * (4 * n + 1)) ? 1 : 0;       // r^2 <= (n + 1/4)^2
+    return d;
+}
+__device__ inline void echo_build_dmap(int* dmap, int n) {     // one thread
+    const int w = 2 * n + 1;
+    int d = 0;
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < w; ++j) {
+            const bool in = 16 * ((i - n) * (i - n) + (j - n) * (j - n)) <= (4 * n + 1) * (4 * n + 1);
+            dmap[i * w + j] = in ? d : 0;
+            d += in ? 1 : 0;
+        }
+}
+
+// Bilinear vote of the point p (complex, scaled to raster units q = p * n): four weights and four cells
+// (reference nn/echo.py:30-61).  dq0[k], dq1[k]: derivatives of weight k with respect to Re q, Im q.
+struct EchoVote {
+    float w[4];
+    int cell[4];
+    float dq0[4], dq1[4];
+};
+__device__ __forceinline__ EchoVote echo_rasterize(float2 p, int n) {
+    const float nf = (float)n;
+    const float q0 = p.x * nf, q1 = p.y * nf;
+    const float c0 = fminf(fmaxf(ceilf(q0), -nf), nf), c1 = fminf(fmaxf(ceilf(q1), -nf), nf);
+    const float f0 = fminf(fmaxf(floorf(q0), -nf), nf), f1 = fminf(fmaxf(floorf(q1), -nf), nf);
+    const float up0 = c0 - q0, up1 = c1 - q1, dn0 = q0 - f0, dn1 = q1 - f1;
+    const int w = 2 * n + 1;
+    const int ic0 = (int)c0 + n, ic1 = (int)c1 + n, if0 = (int)f0 + n, if1 = (int)f1 + n;
+    EchoVote v;
+    v.w[0] = up0 * up1; v.cell[0] = w * if0 + if1; v.dq0[0] = -up1; v.dq1[0] = -up0;
+    v.w[1] = dn0 * dn1; v.cell[1] = w * ic0 + ic1; v.dq0[1] = dn1;  v.dq1[1] = dn0;
+    v.w[2] = dn0 * up1; v.cell[2] = w * ic0 + if1; v.dq0[2] = up1;  v.dq1[2] = -dn0;
+    v.w[3] = up0 * dn1; v.cell[3] = w * if0 + ic1; v.dq0[3] = -dn1; v.dq1[3] = up0;
+    return v;
+}
+
+// frame = exp(-i softAngle(x)) (1 inside the origin box), reference nn/echo.py:113-118 / utils/field.py:40-48
+__device__ __forceinline__ float2 echo_frame(float2 x, bool& live) {
+    live = !is_origin(x);
+    return unit_conj(x);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
+    const float2* __restrict__ x, const float2* __restrict__ ln_t, const float2* __restrict__ wxp_t,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, float2* __restrict__ hist, float* __restrict__ desc,
+    int N, int C, int n, int dS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* const dmap = reinterpret_cast<int*>(smem);                                  // [kEchoMaxCells]
+    float* const hl = reinterpret_cast<float*>(smem) + kEchoMaxCells + 3;           // [waves][C][dS][2]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) echo_build_dmap(dmap, n);
+    float* const mine = hl + (size_t)wave * C * dS * 2;
+    for (int idx = lane; idx < C * dS * 2; idx += kWave) mine[idx] = 0.f;
+    __syncthreads();
+    const int v = blockIdx.x * kEchoWaves + wave;
+    if (v >= N) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int cl = lane < C ? lane : 0;
+    float* const row = mine + (size_t)cl * dS * 2;
+    for (int e = beg; e < end; ++e) {
+        const int src = nbr[e];
+        const float2 le = ln_t[e], we = wxp_t[e];
+        const float2 xv = x[(size_t)src * C + cl];
+        bool live;
+        const float2 fr = echo_frame(xv, live);
+        const EchoVote vt = echo_rasterize(cmul(le, fr), n);
+        const float2 xw = live ? cmul(xv, we) : make_float2(0.f, 0.f);
+        if (lane < C) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* cellp = row + 2 * dmap[vt.cell[k]];
+                cellp[0] += xw.x * vt.w[k];          // lane-private row: plain read-modify-write, in program order
+                cellp[1] += xw.y * vt.w[k];
+            }
+        }
+    }
+    // the block [C][dS] of this vertex, contiguous in LDS and in the outputs
+    float2* const hout = hist + (size_t)v * C * dS;
+    float* const dout = desc + (size_t)v * C * dS;
+    for (int idx = lane; idx < C * dS; idx += kWave) {
+        const float2 h = make_float2(mine[2 * idx], mine[2 * idx + 1]);
+        hout[idx] = h;
+        dout[idx] = is_origin(h) ? 0.f : sqrtf(h.x * h.x + h.y * h.y);        // softAbs, reference utils/field.py:29-37
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// gx[j,c] = sum over out-edges e of j: conj(wxp_e) sum_k w_k gh_k      (through the vote's value)
+//         + the angle term: the votes' weights depend on q = n * ln_e * frame, frame = exp(-i angle(x[j,c]))
+// with gh[dst,c,b] = g_desc * hist / |hist| (0 where hist is inside the origin box).
+__global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
+    const float2* __restrict__ x, const float2* __restrict__ ln_s, const float2* __restrict__ wxp_s,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, const float2* __restrict__ hist,
+    const float* __restrict__ g_desc, float2* __restrict__ gx, int N, int C, int n, int dS) {
+    __shared__ int dmap[kEchoMaxCells];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) echo_build_dmap(dmap, n);
+    __syncthreads();
+    const int j = blockIdx.x * kEchoWaves + wave;
+    if (j >= N) return;
+    const int beg = rowptr[j], end = rowptr[j + 1];
+    const int cl = lane < C ? lane : 0;
+    const float2 xv = x[(size_t)j * C + cl];
+    bool live;
+    const float2 fr = echo_frame(xv, live);
+    float2 gval = make_float2(0.f, 0.f);        // gradient through the vote values
+    float2 gframe = make_float2(0.f, 0.f);      // gradient with respect to frame
+    for (int e = beg; e < end; ++e) {
+        const int dst = nbr[e];
+        const float2 le = ln_s[e], we = wxp_s[e];
+        const EchoVote vt = echo_rasterize(cmul(le, fr), n);
+        const float2 xw = cmul(xv, we);
+        const size_t base = ((size_t)dst * C + cl) * dS;
+        float2 acc = make_float2(0.f, 0.f);
+        float gq0 = 0.f, gq1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = dmap[vt.cell[k]];
+            const float2 h = hist[base + b];
+            const float g = g_desc[base + b];
+            float2 gh = make_float2(0.f, 0.f);
+            if (!is_origin(h)) {
+                const float s = g * __frsqrt_rn(h.x * h.x + h.y * h.y);
+                gh = make_float2(h.x * s, h.y * s);
+            }
+            acc.x += vt.w[k] * gh.x;
+            acc.y += vt.w[k] * gh.y;
+            const float t = gh.x * xw.x + gh.y * xw.y;          // Re(conj(gh) xw)
+            gq0 += t * vt.dq0[k];
+            gq1 += t * vt.dq1[k];
+        }
+        const float2 gv = cmul_conj(acc, we);                   // acc * conj(wxp)
+        gval.x += gv.x;
+        gval.y += gv.y;
+        const float2 ga = make_float2((float)n * gq0, (float)n * gq1);      // gradient with respect to aligned = ln * frame
+        const float2 gf = cmul_conj(ga, le);                    // ga * conj(ln)
+        gframe.x += gf.x;
+        gframe.y += gf.y;
+    }
+    float2 out = make_float2(0.f, 0.f);
+    if (live) {
+        // frame = exp(-i theta): dL/dtheta = Im(conj(gframe) frame); theta = angle(x): gx += dL/dtheta * i x / |x|^2
+        const float gth = gframe.x * fr.y - gframe.y * fr.x;
+        const float inv2 = 1.f / (xv.x * xv.x + xv.y * xv.y);
+        out = make_float2(gval.x - xv.y * gth * inv2, gval.y + xv.x * gth * inv2);
+    }
+    if (lane < C) gx[(size_t)j * C + lane] = out;
+}
+
+}  // namespace fc
+
+extern "C" {
+
+int fc_echo_hist_dim(int32_t n_bins) { return (n_bins >= 1 && n_bins <= fc::kEchoMaxBins) ? fc::echo_hist_dim(n_bins) : 0; }
+
+int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const fc_csr* by_target, float* hist, float* desc,
+                    int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream) {
+    if (!x || !by_target || !by_target->rowptr || !hist || !desc || N <= 0 || E < 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
+    if (E > 0 && (!ln_t || !wxp_t || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
+    if (C > fc::kWave || n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
+    const int dS = fc::echo_hist_dim(n_bins);
+    const size_t lds = (size_t)(fc::kEchoMaxCells + 3 + fc::kEchoWaves * C * dS * 2) * sizeof(float);
+    if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
+    auto kern = fc::echo_forward_kernel;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return FC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((N + fc::kEchoWaves - 1) / fc::kEchoWaves), dim3(fc::kEchoWaves * fc::kWave), lds,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_t),
+                       reinterpret_cast<const float2*>(wxp_t), by_target->rowptr, by_target->nbr, reinterpret_cast<float2*>(hist),
+                       desc, N, C, n_bins, dS);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, const fc_csr* by_source, const float* hist,
+                     const float* g_desc, float* gx, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream) {
+    if (!x || !by_source || !by_source->rowptr || !hist || !g_desc || !gx || N <= 0 || E < 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
+    if (E > 0 && (!ln_s || !wxp_s || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
+    if (C > fc::kWave || n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fc::echo_backward_kernel, dim3((N + fc::kEchoWaves - 1) / fc::kEchoWaves), dim3(fc::kEchoWaves * fc::kWave), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_s),
+                       reinterpret_cast<const float2*>(wxp_s), by_source->rowptr, by_source->nbr, reinterpret_cast<const float2*>(hist),
+                       g_desc, reinterpret_cast<float2*>(gx), N, C, n_bins, fc::echo_hist_dim(n_bins));
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -333,3 +333,54 @@ def tangent_nonlin(x, bias):
     if x.dim() != 2 or bias.numel() != x.shape[1]:
         raise ValueError(f'x has shape {tuple(x.shape)} but bias has {bias.numel()} channels')
     return _TangentNonLinFn.apply(x, bias)
+
+
+class _EchoFn(torch.autograd.Function):
+    """reference nn/echo.py:94-148 (ECHO.forward)"""
+
+    @staticmethod
+    def forward(ctx, x, ln, wxp, csr, n_bins):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, C = x.shape
+        dS = lib.fc_echo_hist_dim(n_bins)
+        if dS == 0:
+            raise ValueError(f'ECHO: n_bins must be in 1..4, got {n_bins}')
+        with torch.cuda.device(x.device):
+            ln_t = ln.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
+            wxp_t = wxp.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
+            hist = torch.empty((N, C, dS), dtype=torch.complex64, device=x.device)
+            desc = torch.empty((N, C, dS), dtype=torch.float32, device=x.device)
+            by_t = _csr(csr.rowptr_t, csr.nbr_t, None)
+            check(lib.fc_echo_forward(_p(x), _p(ln_t), _p(wxp_t), ctypes.byref(by_t), _p(hist), _p(desc), N, csr.E, C, n_bins,
+                                      _stream()), 'fc_echo_forward')
+        ctx.save_for_backward(x, ln, wxp, hist)
+        ctx.csr, ctx.n_bins = csr, n_bins
+        return desc
+
+    @staticmethod
+    def backward(ctx, g_desc):
+        lib = _lib.load()
+        x, ln, wxp, hist = ctx.saved_tensors
+        csr = ctx.csr
+        N, C = x.shape
+        g_desc = g_desc.contiguous()
+        with torch.cuda.device(x.device):
+            ln_s = ln.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
+            wxp_s = wxp.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
+            gx = torch.empty_like(x)
+            by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
+            check(lib.fc_echo_backward(_p(x), _p(ln_s), _p(wxp_s), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), N, csr.E, C,
+                                       ctx.n_bins, _stream()), 'fc_echo_backward')
+        return gx, None, None, None, None
+
+
+def echo_descriptors(x, supp_edges, ln, wxp, n_bins):
+    """ECHO descriptors |hist| (N, C, dS) of the tangent field x on the device (reference nn/echo.py:94-148)."""
+    _require_device(x, 'echo_descriptors')
+    if x.dtype != torch.complex64 or x.dim() != 2:
+        raise ValueError('echo_descriptors expects complex64 features of shape (N, C)')
+    if x.shape[1] > 64:
+        raise ValueError('echo_descriptors supports at most 64 channels')
+    from .graph import get_edge_csr
+    return _EchoFn.apply(x, ln, wxp, get_edge_csr(supp_edges, x.shape[0]), int(n_bins))

@@ -208,5 +208,49 @@ def get_graph(supp_edges, supp_sten, N):
     return g
 
 
+class EdgeCSR:
+    """The edge list grouped by target and by source, with the permutations that bring per-edge data (ln, wxp) into
+    slot order.  Used by the ECHO descriptor kernels, which see the edges but no stencil (reference nn/echo.py:94)."""
+    __slots__ = ('N', 'E', 'rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', '_keep')
+
+    def __init__(self, supp_edges, N):
+        if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
+            raise ValueError('supp_edges must have shape (E, 2)')
+        dev = supp_edges.device
+        self.N, self.E = int(N), int(supp_edges.shape[0])
+        self._keep = supp_edges
+        src = supp_edges[:, 0].to(torch.int64)
+        dst = supp_edges[:, 1].to(torch.int64)
+
+        def group(key, other):
+            if self.E == 0:
+                return (torch.zeros(self.N + 1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                        torch.zeros(0, dtype=torch.int64, device=dev))
+            sorted_key, perm = torch.sort(key, stable=True)
+            counts = torch.bincount(sorted_key, minlength=self.N)[: self.N]
+            rowptr = torch.zeros(self.N + 1, dtype=torch.int32, device=dev)
+            rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            return rowptr, other[perm].to(torch.int32).contiguous(), perm
+        self.rowptr_t, self.nbr_t, self.perm_t = group(dst, src)
+        self.rowptr_s, self.nbr_s, self.perm_s = group(src, dst)
+
+
+_edge_cache = collections.OrderedDict()
+
+
+def get_edge_csr(supp_edges, N):
+    key = (_key(supp_edges), int(N))
+    g = _edge_cache.get(key)
+    if g is not None:
+        _edge_cache.move_to_end(key)
+        return g
+    g = EdgeCSR(supp_edges, N)
+    _edge_cache[key] = g
+    while len(_edge_cache) > _CACHE_SIZE:
+        _edge_cache.popitem(last=False)
+    return g
+
+
 def clear_cache():
     _cache.clear()
+    _edge_cache.clear()

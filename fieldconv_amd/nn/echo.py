@@ -1,6 +1,7 @@
-"""ECHO descriptors (reference nn/echo.py).  Device-agnostic torch composite for now: SURVEY 8(f1)
-lists the splat as the next kernel to move to HIP.  Written without `nonzero` compaction (no host
-sync): zero features are masked instead of filtered, which gives the same sums."""
+"""ECHO descriptors (reference nn/echo.py).  On a ROCm device the splat and its gradient are HIP kernels
+(csrc/fc_echo.hip through fc_echo_forward / fc_echo_backward); the torch composite below is the host-side
+restatement the CPU tests check against the reference fixtures.  It is written without `nonzero` compaction:
+zero features are masked instead of filtered, which gives the same sums."""
 import torch
 import torch.nn as nn
 
@@ -48,6 +49,9 @@ class ECHO(nn.Module):
         self.hdim = dim
 
     def forward(self, x, supp_edges, ln, wxp):
+        if x.is_cuda:       # device tensors always take the HIP kernels (unsupported shapes raise, no torch fallback there)
+            from ..functional import echo_descriptors
+            return echo_descriptors(x, supp_edges, ln, wxp, self.n_bins)
         N, C, dS = x.shape[0], self.channels, self.hdim
         src, dst = supp_edges[:, 0], supp_edges[:, 1]
         live = torch.logical_not(isOrigin(x))                                   # (N,C)

@@ -150,6 +150,23 @@ def test_fc_resnet_block_golden(tag, dev):
         assert rel_err(H(g), c['g_' + name]) < 2 * TOL, name
 
 
+def test_echo_descriptors_golden(dev):
+    """ECHO descriptor splat and its input gradient (HIP kernels, reference nn/echo.py:94-148) against the reference
+    run: zero rows, origin-box entries and the integer-coordinate / out-of-disk quirks are in the fixture's inputs."""
+    from fieldconv_amd.nn import ECHO
+    c = load_golden('echo_lift.npz')['echo']
+    m = ECHO(c['x'].shape[1], int(c['n_bins'])).to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = m(x, D(c['edges'], dev), D(c['ln'], dev), D(c['wxp'], dev))
+    assert y.shape == c['y'].shape
+    assert rel_err(H(y), c['y']) < TOL
+    gx, = torch.autograd.grad(y, [x], grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(gx), c['gx']) < 2e-4          # histogram votes: piecewise-linear, fp32 floor/ceil sensitive
+    # run-to-run reproducible (no atomics)
+    y2 = m(x, D(c['edges'], dev), D(c['ln'], dev), D(c['wxp'], dev))
+    assert torch.equal(y, y2)
+
+
 def test_echo_block_and_lift_block_golden(dev):
     from fieldconv_amd.nn import ECHOBlock, LiftBlock
     c = load_golden('echo_lift.npz')['echo_block']
