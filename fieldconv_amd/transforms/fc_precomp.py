@@ -30,9 +30,26 @@ class FCPrecomp(object):
         self.B = band_limit
         self.R = n_rings
         self.max_r = epsilon
+        self._memo = None           # (key of the last inputs, outputs)
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device), t.dtype)
 
     def __call__(self, data):
         r, theta, w, supp_edges, xp = data.logMag, data.logAng, data.w, data.supp_edges, data.xp
+        # The reference runs this in every Net.forward (segmentation.ipynb:202).  The result is a pure function of the
+        # five input tensors: when the same (unmodified) tensors come back, e.g. the same mesh in the next epoch, the
+        # very same output tensors are returned, so that the support-graph cache keyed on them (graph.get_graph)
+        # hits as well instead of re-sorting the edges.
+        key = (self.B, self.R, float(self.max_r)) + tuple(self._key(t) for t in (r, theta, w, supp_edges, xp))
+        if self._memo is not None and self._memo[0] == key:
+            return self._memo[1]
+        out = self._compute(r, theta, w, supp_edges, xp)
+        self._memo = (key, out, (r, theta, w, supp_edges, xp))      # the inputs are kept alive: their addresses are the key
+        return out
+
+    def _compute(self, r, theta, w, supp_edges, xp):
         B, R = self.B, self.R
         r = r / self.max_r
         keep = torch.nonzero(r <= 1.0).squeeze(-1)
