@@ -1,0 +1,334 @@
+// TransField, the learned 'gradient' that lifts scalar features to tangent-vector features (reference
+// nn/trans_field.py:78-113 with weightContribReal / weightContribOffset :9-24):
+//   ang[n,i,r] = - sum_{e: dst=n} (x[src_e,i] - x[n,i]) s1[e,r]          s1 = lift_sten[e,r,1]
+//   mag[n,i,r] =   sum_{e: dst=n}  x[src_e,i] |s0[e,r]|                  s0 = lift_sten[e,r,0]
+//   y[n,o]     =   sum_i |sum_r mag zonalMag[o,i,r]| * exp(i (angle(sum_r ang zonalAng[o,i,r]) + phase[o,i]))
+// The reference does this with two scatter_adds over E*C_in*R elements, two einsums and polar / angle chains under
+// autograd.  Here: one target-centric kernel (wavefront per vertex, lanes = (i,r) pairs for the aggregation, then
+// lanes = o for the combination) and a backward of three kernels: per-vertex adjoint with per-wavefront parameter
+// partials, a fixed-order reduction of those, and a source-centric gather for the input gradient.  No atomics.
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+
+namespace fc {
+
+constexpr int kTfWaves = 4;          // vertices per workgroup
+constexpr int kTfMaxIn = 4;          // scalar input channels (the networks lift 3)
+constexpr int kTfMaxR = 8;
+constexpr int kTfGridWaves = 1024;   // wavefronts of the backward kernel = parameter-gradient partials
+
+__device__ __forceinline__ float soft_abs(float2 z) { return is_origin(z) ? 0.f : sqrtf(z.x * z.x + z.y * z.y); }
+
+struct TfArgs { int N, E, Cin, O, R, ftype, sten_stride; };
+
+// lift_sten rows are addressed through the slot -> edge permutation: no permuted copy of the stencil
+// (row stride in complex elements: 2 for a packed (E,R,2) array, 2B+1 when the caller passes the m = 0 column of the full stencil)
+__device__ __forceinline__ void tf_load_sten(const float2* __restrict__ lsten, int edge, int R, int r, int stride, float2& s0, float2& s1) {
+    const float2* p = lsten + ((size_t)edge * R + r) * stride;
+    s0 = p[0];
+    s1 = p[1];
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
+    const float* __restrict__ x, const float2* __restrict__ lsten, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ nbr, const int64_t* __restrict__ perm, const float* __restrict__ zA, const float* __restrict__ zM,
+    const float* __restrict__ phase, float2* __restrict__ y, float2* __restrict__ ang_out, float* __restrict__ mag_out,
+    float2* __restrict__ s1sum_out, const TfArgs a) {
+    __shared__ float2 s_ang[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float s_mag[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float2 s_cs[kWave * kTfMaxIn];              // (cos, sin) of phase[o][i]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Cin = a.Cin, R = a.R, O = a.O, IR = Cin * R;
+    for (int idx = threadIdx.x; idx < O * Cin; idx += kTfWaves * kWave) {
+        float s, c;
+        sincosf(phase[idx], &s, &c);
+        s_cs[idx] = make_float2(c, s);
+    }
+    __syncthreads();
+    const int n = blockIdx.x * kTfWaves + wave;
+    if (n >= a.N) return;
+    // ---- aggregation: lane = (i, r)
+    const int li = lane < IR ? lane / R : 0, lr = lane < IR ? lane - (lane / R) * R : 0;
+    float2 ang = make_float2(0.f, 0.f), s1sum = ang;
+    float mag = 0.f;
+    const float xd = x[(size_t)n * Cin + li];
+    const int beg = rowptr[n], end = rowptr[n + 1];
+    for (int e = beg; e < end; ++e) {
+        const int src = nbr[e];
+        const int edge = (int)perm[e];
+        float2 s0, s1;
+        tf_load_sten(lsten, edge, R, lr, a.sten_stride, s0, s1);
+        const float xs = x[(size_t)src * Cin + li];
+        const float d = xs - xd;
+        ang.x += d * s1.x;
+        ang.y += d * s1.y;
+        mag += xs * soft_abs(s0);
+        s1sum.x += s1.x;
+        s1sum.y += s1.y;
+    }
+    ang = make_float2(-ang.x, -ang.y);
+    if (lane < IR) {
+        s_ang[wave][lane] = ang;
+        s_mag[wave][lane] = mag;
+        ang_out[(size_t)n * IR + lane] = ang;
+        mag_out[(size_t)n * IR + lane] = mag;
+        if (li == 0) s1sum_out[(size_t)n * R + lr] = s1sum;
+    }
+    // (same wavefront wrote and reads s_ang / s_mag: LDS operations of a wavefront complete in order)
+    // ---- combination: lane = o
+    if (lane < O) {
+        float2 out = make_float2(0.f, 0.f);
+        for (int i = 0; i < Cin; ++i) {
+            float2 A = make_float2(0.f, 0.f);
+            float M = 0.f;
+            const float* wa = zA + ((size_t)lane * Cin + i) * R;
+            const float* wm = zM + ((size_t)lane * Cin + i) * R;
+            for (int r = 0; r < R; ++r) {
+                const float2 sa = s_ang[wave][i * R + r];
+                A.x += sa.x * wa[r];
+                A.y += sa.y * wa[r];
+                M += s_mag[wave][i * R + r] * wm[r];
+            }
+            // exp(i softAngle(A)) = A / |A|, or 1 inside the origin box (reference utils/field.py:40-48)
+            const float2 u = is_origin(A) ? make_float2(1.f, 0.f) : make_float2(A.x * __frsqrt_rn(A.x * A.x + A.y * A.y), A.y * __frsqrt_rn(A.x * A.x + A.y * A.y));
+            const float2 E = cmul(u, s_cs[lane * Cin + i]);
+            const float rho = fabsf(M);
+            out.x += rho * E.x;
+            out.y += rho * E.y;
+        }
+        y[(size_t)n * O + lane] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward, per vertex
+// Persistent wavefronts; lane = o keeps its rows of the parameter gradients in registers and writes one partial at the end.
+__global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_kernel(
+    const float2* __restrict__ ang_in, const float* __restrict__ mag_in, const float2* __restrict__ s1sum,
+    const float* __restrict__ zA, const float* __restrict__ zM, const float* __restrict__ phase, const float2* __restrict__ gy,
+    float2* __restrict__ g_ang, float* __restrict__ g_mag, float* __restrict__ gx_dst, float* __restrict__ partial,
+    const TfArgs a, const int total_waves) {
+    __shared__ float2 s_ang[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float s_mag[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float2 s_gA[kTfWaves][kWave * kTfMaxIn];
+    __shared__ float s_gM[kTfWaves][kWave * kTfMaxIn];
+    __shared__ float s_t[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float2 s_cs[kWave * kTfMaxIn];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Cin = a.Cin, R = a.R, O = a.O, IR = Cin * R;
+    for (int idx = threadIdx.x; idx < O * Cin; idx += kTfWaves * kWave) {
+        float s, c;
+        sincosf(phase[idx], &s, &c);
+        s_cs[idx] = make_float2(c, s);
+    }
+    __syncthreads();
+    const int gw = blockIdx.x * kTfWaves + wave;
+    const int li = lane < IR ? lane / R : 0, lr = lane < IR ? lane - (lane / R) * R : 0;
+    float gzA[kTfMaxIn][kTfMaxR], gzM[kTfMaxIn][kTfMaxR], gph[kTfMaxIn];
+#pragma unroll
+    for (int i = 0; i < kTfMaxIn; ++i) {
+        gph[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < kTfMaxR; ++r) { gzA[i][r] = 0.f; gzM[i][r] = 0.f; }
+    }
+    for (int n = gw; n < a.N; n += total_waves) {
+        if (lane < IR) {
+            s_ang[wave][lane] = ang_in[(size_t)n * IR + lane];
+            s_mag[wave][lane] = mag_in[(size_t)n * IR + lane];
+        }
+        const float2 g = lane < O ? gy[(size_t)n * O + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < kTfMaxIn; ++i) {
+            if (i < Cin) {
+                float2 A = make_float2(0.f, 0.f);
+                float M = 0.f;
+                const int oc = lane < O ? lane : 0;
+                const float* wa = zA + ((size_t)oc * Cin + i) * R;
+                const float* wm = zM + ((size_t)oc * Cin + i) * R;
+#pragma unroll
+                for (int r = 0; r < kTfMaxR; ++r)
+                    if (r < R) {
+                        const float2 sa = s_ang[wave][i * R + r];
+                        A.x += sa.x * wa[r];
+                        A.y += sa.y * wa[r];
+                        M += s_mag[wave][i * R + r] * wm[r];
+                    }
+                const bool orgA = is_origin(A);
+                const float n2 = A.x * A.x + A.y * A.y;
+                const float inv = orgA ? 0.f : __frsqrt_rn(n2);
+                const float2 u = orgA ? make_float2(1.f, 0.f) : make_float2(A.x * inv, A.y * inv);
+                const float2 E = cmul(u, s_cs[oc * Cin + i]);
+                const float rho = fabsf(M);
+                const float g_rho = g.x * E.x + g.y * E.y;                      // Re(conj(g) E)
+                const float g_phi = rho * (g.y * E.x - g.x * E.y);              // Re(conj(g) i rho E)
+                const float gM = M < 0.f ? -g_rho : g_rho;                      // softAbsolute (reference utils/field.py:18-26)
+                // angle(A): g_A = g_phi * i A / |A|^2 ; none inside the origin box
+                const float sA = orgA ? 0.f : g_phi * inv * inv;
+                const float2 gA = make_float2(-A.y * sA, A.x * sA);
+                if (lane < O) {
+                    gph[i] += g_phi;
+#pragma unroll
+                    for (int r = 0; r < kTfMaxR; ++r)
+                        if (r < R) {
+                            const float2 sa = s_ang[wave][i * R + r];
+                            gzA[i][r] += gA.x * sa.x + gA.y * sa.y;                 // zonalAng is real: Re(conj(gA) ang)
+                            gzM[i][r] += gM * s_mag[wave][i * R + r];
+                        }
+                }
+                s_gA[wave][lane * Cin + i] = lane < O ? gA : make_float2(0.f, 0.f);
+                s_gM[wave][lane * Cin + i] = lane < O ? gM : 0.f;
+            }
+        }
+        // ---- adjoint of the two contractions over o: lane = (i, r)
+        float2 ga = make_float2(0.f, 0.f);
+        float gm = 0.f;
+        if (lane < IR) {
+            for (int o = 0; o < O; ++o) {
+                const float wa = zA[((size_t)o * Cin + li) * R + lr], wm = zM[((size_t)o * Cin + li) * R + lr];
+                const float2 t = s_gA[wave][o * Cin + li];
+                ga.x += t.x * wa;
+                ga.y += t.y * wa;
+                gm += s_gM[wave][o * Cin + li] * wm;
+            }
+            g_ang[(size_t)n * IR + lane] = ga;
+            g_mag[(size_t)n * IR + lane] = gm;
+            // ang depends on x[n,i] through + x[n,i] * sum_e s1[e,r]
+            const float2 ss = s1sum[(size_t)n * R + lr];
+            s_t[wave][lane] = ga.x * ss.x + ga.y * ss.y;
+        }
+        if (lane < Cin) {
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc += s_t[wave][lane * R + r];
+            gx_dst[(size_t)n * Cin + lane] = acc;
+        }
+    }
+    // partial[wave][o][Cin][2R+1]
+    if (lane < O) {
+        float* p = partial + ((size_t)gw * O + lane) * Cin * (2 * R + 1);
+#pragma unroll
+        for (int i = 0; i < kTfMaxIn; ++i)
+            if (i < Cin) {
+#pragma unroll
+                for (int r = 0; r < kTfMaxR; ++r)
+                    if (r < R) {
+                        p[i * (2 * R + 1) + r] = gzA[i][r];
+                        p[i * (2 * R + 1) + R + r] = gzM[i][r];
+                    }
+                p[i * (2 * R + 1) + 2 * R] = gph[i];
+            }
+    }
+}
+
+// fixed-order sum of the per-wavefront partials: one thread per (o, i, slot)
+__global__ void trans_field_reduce_kernel(const float* __restrict__ partial, float* __restrict__ g_zA, float* __restrict__ g_zM,
+                                          float* __restrict__ g_phase, int nparts, int O, int Cin, int R, int ftype) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * R + 1, total = O * Cin * per;
+    if (idx >= total) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * total + idx];
+    const int oi = idx / per, slot = idx - oi * per;
+    if (slot < R) g_zA[(size_t)oi * R + slot] = s;
+    else if (slot < 2 * R) g_zM[(size_t)oi * R + slot - R] = s;
+    else if (ftype != 0) g_phase[oi] = s;
+}
+
+// ------------------------------------------------------------------------------------------ backward, input gradient
+// gx[j,i] = gx_dst[j,i] + sum_{e: src=j} sum_r ( -Re(conj(g_ang[dst_e,i,r]) s1[e,r]) + g_mag[dst_e,i,r] |s0[e,r]| )
+__global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_input_kernel(
+    const float2* __restrict__ lsten, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr,
+    const int64_t* __restrict__ perm, const float2* __restrict__ g_ang, const float* __restrict__ g_mag,
+    const float* __restrict__ gx_dst, float* __restrict__ gx, const TfArgs a) {
+    __shared__ float s_t[kTfWaves][kTfMaxIn * kTfMaxR];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Cin = a.Cin, R = a.R, IR = Cin * R;
+    const int j = blockIdx.x * kTfWaves + wave;
+    if (j >= a.N) return;
+    const int lr = lane < IR ? lane - (lane / R) * R : 0;
+    const int lc = lane < IR ? lane : 0;
+    float acc = 0.f;
+    const int beg = rowptr[j], end = rowptr[j + 1];
+    for (int e = beg; e < end; ++e) {
+        const int dst = nbr[e];
+        const int edge = (int)perm[e];
+        float2 s0, s1;
+        tf_load_sten(lsten, edge, R, lr, a.sten_stride, s0, s1);
+        const float2 ga = g_ang[(size_t)dst * IR + lc];
+        const float gm = g_mag[(size_t)dst * IR + lc];
+        acc += gm * soft_abs(s0) - (ga.x * s1.x + ga.y * s1.y);
+    }
+    if (lane < IR) s_t[wave][lane] = acc;
+    if (lane < Cin) {
+        float s = gx_dst[(size_t)j * Cin + lane];
+        for (int r = 0; r < R; ++r) s += s_t[wave][lane * R + r];
+        gx[(size_t)j * Cin + lane] = s;
+    }
+}
+
+static bool tf_supported(int Cin, int O, int R) { return Cin >= 1 && Cin <= kTfMaxIn && R >= 1 && R <= kTfMaxR && O >= 1 && O <= kWave; }
+
+}  // namespace fc
+
+extern "C" {
+
+int fc_trans_field_forward(const float* x, const float* lift_sten, const fc_csr* by_target, const int64_t* slot_to_edge,
+                           const float* zonal_ang, const float* zonal_mag, const float* phase, float* y, float* ang, float* mag,
+                           float* s1sum, int32_t N, int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride, void* stream) {
+    if (!x || !by_target || !by_target->rowptr || !zonal_ang || !zonal_mag || !phase || !y || !ang || !mag || !s1sum || N <= 0 || E < 0)
+        return FC_ERR_BAD_ARGUMENT;
+    if (E > 0 && (!lift_sten || !by_target->nbr || !slot_to_edge)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::tf_supported(Cin, O, R)) return FC_ERR_UNSUPPORTED;
+    if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
+    const fc::TfArgs a{N, E, Cin, O, R, 1, sten_stride};
+    hipLaunchKernelGGL(fc::trans_field_forward_kernel, dim3((N + fc::kTfWaves - 1) / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0,
+                       static_cast<hipStream_t>(stream), x, reinterpret_cast<const float2*>(lift_sten), by_target->rowptr, by_target->nbr,
+                       slot_to_edge, zonal_ang, zonal_mag, phase, reinterpret_cast<float2*>(y), reinterpret_cast<float2*>(ang), mag,
+                       reinterpret_cast<float2*>(s1sum), a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+size_t fc_trans_field_backward_workspace_bytes(int32_t N, int32_t Cin, int32_t O, int32_t R) {
+    if (N <= 0 || !fc::tf_supported(Cin, O, R)) return 0;
+    const size_t IR = (size_t)Cin * R;
+    // g_ang (N,IR) c64 | g_mag (N,IR) f32 | gx_dst (N,Cin) f32 | partials [waves][O][Cin][2R+1]
+    return (size_t)N * IR * 8 + (size_t)N * IR * 4 + (size_t)N * Cin * 4 + (size_t)fc::kTfGridWaves * O * Cin * (2 * R + 1) * 4 + 256;
+}
+
+int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, const int64_t* slot_to_edge_s, const float* zonal_ang,
+                            const float* zonal_mag, const float* phase, const float* ang, const float* mag, const float* s1sum,
+                            const float* gy, float* gx, float* g_zonal_ang, float* g_zonal_mag, float* g_phase, void* workspace,
+                            size_t workspace_bytes, int32_t N, int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride,
+                            int32_t ftype, void* stream) {
+    if (!by_source || !by_source->rowptr || !zonal_ang || !zonal_mag || !phase || !ang || !mag || !s1sum || !gy || !gx || !g_zonal_ang ||
+        !g_zonal_mag || N <= 0 || E < 0)
+        return FC_ERR_BAD_ARGUMENT;
+    if (ftype != 0 && !g_phase) return FC_ERR_BAD_ARGUMENT;
+    if (E > 0 && (!lift_sten || !by_source->nbr || !slot_to_edge_s)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::tf_supported(Cin, O, R)) return FC_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < fc_trans_field_backward_workspace_bytes(N, Cin, O, R)) return FC_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t IR = (size_t)Cin * R;
+    char* w = static_cast<char*>(workspace);
+    float2* g_ang = reinterpret_cast<float2*>(w);
+    float* g_mag = reinterpret_cast<float*>(w + (size_t)N * IR * 8);
+    float* gx_dst = g_mag + (size_t)N * IR;
+    float* partial = gx_dst + (size_t)N * Cin;
+    if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
+    const fc::TfArgs a{N, E, Cin, O, R, ftype, sten_stride};
+    int waves = (N < fc::kTfGridWaves) ? (N + fc::kTfWaves - 1) / fc::kTfWaves * fc::kTfWaves : fc::kTfGridWaves;
+    hipLaunchKernelGGL(fc::trans_field_backward_vertex_kernel, dim3(waves / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0, s,
+                       reinterpret_cast<const float2*>(ang), mag, reinterpret_cast<const float2*>(s1sum), zonal_ang, zonal_mag, phase,
+                       reinterpret_cast<const float2*>(gy), g_ang, g_mag, gx_dst, partial, a, waves);
+    const int total = O * Cin * (2 * R + 1);
+    hipLaunchKernelGGL(fc::trans_field_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, partial, g_zonal_ang, g_zonal_mag,
+                       g_phase, waves, O, Cin, R, ftype);
+    hipLaunchKernelGGL(fc::trans_field_backward_input_kernel, dim3((N + fc::kTfWaves - 1) / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0,
+                       s, reinterpret_cast<const float2*>(lift_sten), by_source->rowptr, by_source->nbr, slot_to_edge_s, g_ang, g_mag,
+                       gx_dst, gx, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+}  // extern "C"

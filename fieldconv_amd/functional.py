@@ -384,3 +384,72 @@ def echo_descriptors(x, supp_edges, ln, wxp, n_bins):
         raise ValueError('echo_descriptors supports at most 64 channels')
     from .graph import get_edge_csr
     return _EchoFn.apply(x, ln, wxp, get_edge_csr(supp_edges, x.shape[0]), int(n_bins))
+
+
+class _TransFieldFn(torch.autograd.Function):
+    """reference nn/trans_field.py:78-113 (TransField.forward)"""
+
+    @staticmethod
+    def _stencil(lift_sten):
+        # (E,R,2) view of the full stencil (supp_sten[..., B:B+2], reference segmentation.ipynb:204) is read in place
+        E, R, two = lift_sten.shape
+        st = lift_sten.stride()
+        if two == 2 and st[2] == 1 and st[0] == R * st[1] and st[1] >= 2:
+            return lift_sten, int(st[1])
+        return lift_sten.contiguous(), 2
+
+    @staticmethod
+    def forward(ctx, x, lift_sten, zonal_ang, zonal_mag, phase, csr, ftype):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, Cin = x.shape
+        O, _, R = zonal_ang.shape
+        sten, stride = _TransFieldFn._stencil(lift_sten)
+        zonal_ang, zonal_mag, phase = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous()
+        with torch.cuda.device(x.device):
+            y = torch.empty((N, O), dtype=torch.complex64, device=x.device)
+            ang = torch.empty((N, Cin, R), dtype=torch.complex64, device=x.device)
+            mag = torch.empty((N, Cin, R), dtype=torch.float32, device=x.device)
+            s1sum = torch.empty((N, R), dtype=torch.complex64, device=x.device)
+            by_t = _csr(csr.rowptr_t, csr.nbr_t, None)
+            check(lib.fc_trans_field_forward(_p(x), _p(sten), ctypes.byref(by_t), _p(csr.perm_t), _p(zonal_ang), _p(zonal_mag),
+                                             _p(phase), _p(y), _p(ang), _p(mag), _p(s1sum), N, csr.E, Cin, O, R, stride, _stream()),
+                  'fc_trans_field_forward')
+        ctx.save_for_backward(sten, zonal_ang, zonal_mag, phase, ang, mag, s1sum)
+        ctx.csr, ctx.ftype, ctx.stride, ctx.Cin = csr, ftype, stride, Cin
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        sten, zonal_ang, zonal_mag, phase, ang, mag, s1sum = ctx.saved_tensors
+        csr, Cin = ctx.csr, ctx.Cin
+        O, _, R = zonal_ang.shape
+        N = ang.shape[0]
+        gy = gy.contiguous()
+        with torch.cuda.device(gy.device):
+            gx = torch.empty((N, Cin), dtype=torch.float32, device=gy.device)
+            g_za, g_zm = torch.empty_like(zonal_ang), torch.empty_like(zonal_mag)
+            g_ph = torch.empty_like(phase) if ctx.ftype != 0 else None
+            nbytes = lib.fc_trans_field_backward_workspace_bytes(N, Cin, O, R)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+            by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
+            check(lib.fc_trans_field_backward(_p(sten), ctypes.byref(by_s), _p(csr.perm_s), _p(zonal_ang), _p(zonal_mag), _p(phase),
+                                              _p(ang), _p(mag), _p(s1sum), _p(gy), _p(gx), _p(g_za), _p(g_zm),
+                                              _p(g_ph) if g_ph is not None else None, _p(ws), nbytes, N, csr.E, Cin, O, R,
+                                              ctx.stride, ctx.ftype, _stream()), 'fc_trans_field_backward')
+        return gx, None, g_za, g_zm, g_ph, None, None
+
+
+def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
+    """TransField on the device: (N,Cin) real features -> (N,O) complex64 (reference nn/trans_field.py:78-113)."""
+    _require_device(x, 'trans_field')
+    if x.dtype != torch.float32 or x.dim() != 2 or lift_sten.dtype != torch.complex64:
+        raise ValueError('trans_field expects float32 features (N, Cin) and a complex64 stencil (E, R, 2)')
+    O, Cin, R = zonal_ang.shape
+    if x.shape[1] != Cin or lift_sten.shape[1] != R or lift_sten.shape[2] != 2:
+        raise ValueError('trans_field: feature / stencil shapes do not match the zonal filters')
+    if Cin > 4 or R > 8 or O > 64:
+        raise ValueError('trans_field supports Cin <= 4, n_rings <= 8, out_channels <= 64')
+    from .graph import get_edge_csr
+    return _TransFieldFn.apply(x, lift_sten, zonal_ang, zonal_mag, phase, get_edge_csr(supp_edges, x.shape[0]), int(ftype))

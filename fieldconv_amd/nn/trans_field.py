@@ -1,5 +1,6 @@
-"""TransField / learned 'gradient' (reference nn/trans_field.py).  Torch composite for now
-(next to move to HIP); runs once per network with 3 input channels."""
+"""TransField / learned 'gradient' (reference nn/trans_field.py).  On a ROCm device the aggregation, the zonal
+contractions and their gradients are HIP kernels (csrc/fc_trans_field.hip through fc_trans_field_forward / _backward);
+the torch composite below is the host-side restatement the CPU tests check against the reference fixtures."""
 import torch
 import torch.nn as nn
 
@@ -27,6 +28,9 @@ class TransField(nn.Module):
 
     def forward(self, x, supp_edges, lift_sten):
         """x (N,in) real; lift_sten (E,R,2) cfloat = stencil columns m=0,1 -> (N,out) cfloat."""
+        if x.is_cuda:       # device tensors always take the HIP kernels (unsupported shapes raise, no torch fallback there)
+            from ..functional import trans_field
+            return trans_field(x, supp_edges, lift_sten, self.zonalAng, self.zonalMag, self.phase, self.ftype)
         N = x.shape[0]
         src, dst = supp_edges[:, 0], supp_edges[:, 1]
         s0 = lift_sten[:, :, 0]

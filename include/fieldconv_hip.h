@@ -164,6 +164,25 @@ int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const
 int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, const fc_csr* by_source, const float* hist,
                      const float* g_desc, float* gx, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream);
 
+/* ---- TransField (the learned 'gradient' of LiftBlock), reference nn/trans_field.py:78-113, weightContrib* :9-24 ---- *
+ * x (N,Cin) f32 scalar features, Cin <= 4; lift_sten: the stencil columns m = 0, 1 (reference segmentation.ipynb:204)
+ * in ORIGINAL edge order, element (e,r,j) at complex index (e*R + r)*sten_stride + j -- sten_stride = 2 for a packed
+ * (E,R,2) array, 2B+1 for a pointer to column m = 0 of the full (E,R,2B+1) stencil; by_target / by_source: the edges grouped by target / source with
+ * slot_to_edge (E) int64 giving the original edge of every slot; zonal_ang, zonal_mag (O,Cin,R) f32, phase (O,Cin) f32
+ * (zeros for ftype 0); y (N,O) c64, O <= 64.  The forward call also leaves ang (N,Cin,R) c64, mag (N,Cin,R) f32 and
+ * s1sum (N,R) c64 for the backward call, which overwrites gx (N,Cin) f32 and the parameter gradients (g_phase for
+ * ftype != 0 only) using a caller-provided workspace. */
+int fc_trans_field_forward(const float* x, const float* lift_sten, const fc_csr* by_target, const int64_t* slot_to_edge,
+                           const float* zonal_ang, const float* zonal_mag, const float* phase, float* y, float* ang,
+                           float* mag, float* s1sum, int32_t N, int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride,
+                           void* stream);
+size_t fc_trans_field_backward_workspace_bytes(int32_t N, int32_t Cin, int32_t O, int32_t R);
+int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, const int64_t* slot_to_edge_s,
+                            const float* zonal_ang, const float* zonal_mag, const float* phase, const float* ang,
+                            const float* mag, const float* s1sum, const float* gy, float* gx, float* g_zonal_ang,
+                            float* g_zonal_mag, float* g_phase, void* workspace, size_t workspace_bytes, int32_t N,
+                            int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride, int32_t ftype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,8 +185,42 @@ def test_echo_block_and_lift_block_golden(dev):
         xs = D(c['x'], dev).requires_grad_(True)
         y = m(xs, D(c['edges'], dev), D(c['lift_sten'], dev))
         assert rel_err(H(y), c['y']) < 5 * TOL
-        gx, = torch.autograd.grad(y, [xs], grad_outputs=D(c['gy'], dev))
-        assert rel_err(H(gx), c['gx']) < 1e-4
+        params = dict(m.named_parameters())
+        grads = torch.autograd.grad(y, [xs] + list(params.values()), grad_outputs=D(c['gy'], dev))
+        assert rel_err(H(grads[0]), c['gx']) < 1e-4
+        for (name, _), gval in zip(params.items(), grads[1:]):
+            assert rel_err(H(gval), c['g_' + name]) < 1e-4, name
+
+
+@pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1)])
+def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
+    """The TransField kernels against the package's own torch composite run on the CPU in float64 (that composite is
+    pinned to the reference fixtures by the CPU suite): ragged in-degrees, isolated vertices, a strided stencil view."""
+    from fieldconv_amd.nn import TransField
+    g = torch.Generator().manual_seed(N + k)
+    E = N * k
+    dst = torch.randint(0, N, (E,), generator=g)
+    src = torch.randint(0, N, (E,), generator=g)
+    edges = torch.stack((src, dst), dim=1)
+    full = torch.complex(torch.randn(E, R, 5, generator=g), torch.randn(E, R, 5, generator=g)) * 0.2
+    if E:
+        full[::7, 0, 2] = 0           # origin-box stencil entries
+    x = torch.randn(N, Cin, generator=g)
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    m = TransField(Cin, O, n_rings=R, ftype=ftype)
+    ref = TransField(Cin, O, n_rings=R, ftype=ftype).double()
+    ref.load_state_dict({k_: v.double() for k_, v in m.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr, edges, full[..., 2:4].to(torch.complex128))
+    pr = [p for p in ref.parameters()]
+    gr = torch.autograd.grad(yr, [xr] + pr, grad_outputs=gy.to(torch.complex128))
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    yd = m(xd, edges.to(dev), full.to(dev)[..., 2:4])
+    gd = torch.autograd.grad(yd, [xd] + list(m.parameters()), grad_outputs=gy.to(dev))
+    assert rel_err(H(yd), yr.detach().numpy()) < 5 * TOL
+    for a, b in zip(gd, gr):
+        assert rel_err(H(a), b.numpy()) < 1e-4          # d angle(A) ~ 1/|A|: the same bound as the reference-fixture test above
 
 
 @pytest.mark.skipif(REDUCED, reason='eleven layers deep: checks the fp32-grade path')
