@@ -46,7 +46,7 @@ SIGNATURES = {
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
     'fc_echo_hist_dim': (ctypes.c_int, [_c_int32]),
     'fc_echo_forward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
-    'fc_echo_backward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_echo_backward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_trans_field_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_trans_field_backward_workspace_bytes': (_sz, [_c_int32, _c_int32, _c_int32, _c_int32]),
     'fc_trans_field_backward': (ctypes.c_int, [_vp, _CP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),

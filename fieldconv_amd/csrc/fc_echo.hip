@@ -62,25 +62,30 @@ __device__ __forceinline__ float2 echo_frame(float2 x, bool& live) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// `wpv` (1, 2 or 4) wavefronts share one vertex: each takes every wpv-th in-edge into its own histogram, and the
+// histograms are added in wavefront order at the end.  Meshes with few vertices and large supports (the reference's
+// segmentation meshes: ~1k vertices, ~128 neighbours) would otherwise leave most of the chip idle.
 __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
     const float2* __restrict__ x, const float2* __restrict__ ln_t, const float2* __restrict__ wxp_t,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, float2* __restrict__ hist, float* __restrict__ desc,
-    int N, int C, int n, int dS) {
+    int N, int C, int n, int dS, int wpv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const dmap = reinterpret_cast<int*>(smem);                                  // [kEchoMaxCells]
     float* const hl = reinterpret_cast<float*>(smem) + kEchoMaxCells + 3;           // [waves][C][dS][2]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) echo_build_dmap(dmap, n);
-    float* const mine = hl + (size_t)wave * C * dS * 2;
-    for (int idx = lane; idx < C * dS * 2; idx += kWave) mine[idx] = 0.f;
+    const int CS = C * dS;
+    float* const mine = hl + (size_t)wave * CS * 2;
+    for (int idx = lane; idx < CS * 2; idx += kWave) mine[idx] = 0.f;
     __syncthreads();
-    const int v = blockIdx.x * kEchoWaves + wave;
-    if (v >= N) return;
-    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int v = (blockIdx.x * kEchoWaves + wave) / wpv;
+    const int sub = wave % wpv;
+    const bool active = v < N;
+    const int beg = active ? rowptr[v] : 0, end = active ? rowptr[v + 1] : 0;
     const int cl = lane < C ? lane : 0;
     float* const row = mine + (size_t)cl * dS * 2;
-    for (int e = beg; e < end; ++e) {
+    for (int e = beg + sub; e < end; e += wpv) {
         const int src = nbr[e];
         const float2 le = ln_t[e], we = wxp_t[e];
         const float2 xv = x[(size_t)src * C + cl];
@@ -97,56 +102,72 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
             }
         }
     }
-    // the block [C][dS] of this vertex, contiguous in LDS and in the outputs
-    float2* const hout = hist + (size_t)v * C * dS;
-    float* const dout = desc + (size_t)v * C * dS;
-    for (int idx = lane; idx < C * dS; idx += kWave) {
-        const float2 h = make_float2(mine[2 * idx], mine[2 * idx + 1]);
+    if (wpv > 1) __syncthreads();
+    if (!active) return;
+    // the block [C][dS] of this vertex, contiguous in LDS and in the outputs; the vertex's wavefronts share the rows
+    float2* const hout = hist + (size_t)v * CS;
+    float* const dout = desc + (size_t)v * CS;
+    const float* const first = hl + (size_t)(wave - sub) * CS * 2;
+    for (int idx = sub * kWave + lane; idx < CS; idx += wpv * kWave) {
+        float2 h = make_float2(0.f, 0.f);
+        for (int s = 0; s < wpv; ++s) {
+            h.x += first[(size_t)s * CS * 2 + 2 * idx];
+            h.y += first[(size_t)s * CS * 2 + 2 * idx + 1];
+        }
         hout[idx] = h;
         dout[idx] = is_origin(h) ? 0.f : sqrtf(h.x * h.x + h.y * h.y);        // softAbs, reference utils/field.py:29-37
     }
 }
 
 // ------------------------------------------------------------------------------------------ backward
+// gh[n,c,b] = g_desc * hist / |hist| (0 where hist is inside the origin box): the gradient arriving at the histogram
+__global__ void echo_hist_grad_kernel(const float2* __restrict__ hist, const float* __restrict__ g_desc, float2* __restrict__ gh,
+                                      size_t count) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const float2 h = hist[idx];
+    float2 out = make_float2(0.f, 0.f);
+    if (!is_origin(h)) {
+        const float s = g_desc[idx] * __frsqrt_rn(h.x * h.x + h.y * h.y);
+        out = make_float2(h.x * s, h.y * s);
+    }
+    gh[idx] = out;
+}
+
 // gx[j,c] = sum over out-edges e of j: conj(wxp_e) sum_k w_k gh_k      (through the vote's value)
 //         + the angle term: the votes' weights depend on q = n * ln_e * frame, frame = exp(-i angle(x[j,c]))
-// with gh[dst,c,b] = g_desc * hist / |hist| (0 where hist is inside the origin box).
+// `wpv` wavefronts share a source vertex as in the forward kernel; their sums are added in wavefront order.
 __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
     const float2* __restrict__ x, const float2* __restrict__ ln_s, const float2* __restrict__ wxp_s,
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, const float2* __restrict__ hist,
-    const float* __restrict__ g_desc, float2* __restrict__ gx, int N, int C, int n, int dS) {
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, const float2* __restrict__ gh_all,
+    float2* __restrict__ gx, int N, int C, int n, int dS, int wpv) {
     __shared__ int dmap[kEchoMaxCells];
+    __shared__ float4 s_part[kEchoWaves][kWave];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) echo_build_dmap(dmap, n);
     __syncthreads();
-    const int j = blockIdx.x * kEchoWaves + wave;
-    if (j >= N) return;
-    const int beg = rowptr[j], end = rowptr[j + 1];
+    const int j = (blockIdx.x * kEchoWaves + wave) / wpv;
+    const int sub = wave % wpv;
+    const bool active = j < N;
+    const int beg = active ? rowptr[j] : 0, end = active ? rowptr[j + 1] : 0;
     const int cl = lane < C ? lane : 0;
-    const float2 xv = x[(size_t)j * C + cl];
+    const float2 xv = active ? x[(size_t)j * C + cl] : make_float2(1.f, 0.f);
     bool live;
     const float2 fr = echo_frame(xv, live);
     float2 gval = make_float2(0.f, 0.f);        // gradient through the vote values
     float2 gframe = make_float2(0.f, 0.f);      // gradient with respect to frame
-    for (int e = beg; e < end; ++e) {
+    for (int e = beg + sub; e < end; e += wpv) {
         const int dst = nbr[e];
         const float2 le = ln_s[e], we = wxp_s[e];
         const EchoVote vt = echo_rasterize(cmul(le, fr), n);
         const float2 xw = cmul(xv, we);
-        const size_t base = ((size_t)dst * C + cl) * dS;
+        const float2* const ghrow = gh_all + ((size_t)dst * C + cl) * dS;
         float2 acc = make_float2(0.f, 0.f);
         float gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b = dmap[vt.cell[k]];
-            const float2 h = hist[base + b];
-            const float g = g_desc[base + b];
-            float2 gh = make_float2(0.f, 0.f);
-            if (!is_origin(h)) {
-                const float s = g * __frsqrt_rn(h.x * h.x + h.y * h.y);
-                gh = make_float2(h.x * s, h.y * s);
-            }
+            const float2 gh = ghrow[dmap[vt.cell[k]]];
             acc.x += vt.w[k] * gh.x;
             acc.y += vt.w[k] * gh.y;
             const float t = gh.x * xw.x + gh.y * xw.y;          // Re(conj(gh) xw)
@@ -161,6 +182,18 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
         gframe.x += gf.x;
         gframe.y += gf.y;
     }
+    if (wpv > 1) {
+        s_part[wave][lane] = make_float4(gval.x, gval.y, gframe.x, gframe.y);
+        __syncthreads();
+        if (sub != 0) return;
+        gval = make_float2(0.f, 0.f);
+        gframe = gval;
+        for (int s = 0; s < wpv; ++s) {
+            const float4 p = s_part[wave + s][lane];
+            gval.x += p.x; gval.y += p.y; gframe.x += p.z; gframe.y += p.w;
+        }
+    }
+    if (!active) return;
     float2 out = make_float2(0.f, 0.f);
     if (live) {
         // frame = exp(-i theta): dL/dtheta = Im(conj(gframe) frame); theta = angle(x): gx += dL/dtheta * i x / |x|^2
@@ -169,6 +202,14 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
         out = make_float2(gval.x - xv.y * gth * inv2, gval.y + xv.x * gth * inv2);
     }
     if (lane < C) gx[(size_t)j * C + lane] = out;
+}
+
+// wavefronts per vertex: spread large supports over the workgroup when the mesh alone cannot fill the chip
+static int echo_waves_per_vertex(int N, int E) {
+    const long deg = N > 0 ? (long)E / N : 0;
+    if (deg >= 64 && N < 65536) return 4;
+    if (deg >= 32 && N < 131072) return 2;
+    return 1;
 }
 
 }  // namespace fc
@@ -189,22 +230,33 @@ int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return FC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((N + fc::kEchoWaves - 1) / fc::kEchoWaves), dim3(fc::kEchoWaves * fc::kWave), lds,
+    const int wpv = fc::echo_waves_per_vertex(N, E);
+    const int per_wg = fc::kEchoWaves / wpv;
+    hipLaunchKernelGGL(kern, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), lds,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_t),
                        reinterpret_cast<const float2*>(wxp_t), by_target->rowptr, by_target->nbr, reinterpret_cast<float2*>(hist),
-                       desc, N, C, n_bins, dS);
+                       desc, N, C, n_bins, dS, wpv);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, const fc_csr* by_source, const float* hist,
-                     const float* g_desc, float* gx, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream) {
-    if (!x || !by_source || !by_source->rowptr || !hist || !g_desc || !gx || N <= 0 || E < 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
+                     const float* g_desc, float* gx, float* hist_grad_workspace, int32_t N, int32_t E, int32_t C, int32_t n_bins,
+                     void* stream) {
+    if (!x || !by_source || !by_source->rowptr || !hist || !g_desc || !gx || !hist_grad_workspace || N <= 0 || E < 0 || C <= 0)
+        return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!ln_s || !wxp_s || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
     if (C > fc::kWave || n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fc::echo_backward_kernel, dim3((N + fc::kEchoWaves - 1) / fc::kEchoWaves), dim3(fc::kEchoWaves * fc::kWave), 0,
+    const int dS = fc::echo_hist_dim(n_bins);
+    const size_t count = (size_t)N * C * dS;
+    float2* const gh = reinterpret_cast<float2*>(hist_grad_workspace);
+    hipLaunchKernelGGL(fc::echo_hist_grad_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(hist), g_desc, gh, count);
+    const int wpv = fc::echo_waves_per_vertex(N, E);
+    const int per_wg = fc::kEchoWaves / wpv;
+    hipLaunchKernelGGL(fc::echo_backward_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), 0,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_s),
-                       reinterpret_cast<const float2*>(wxp_s), by_source->rowptr, by_source->nbr, reinterpret_cast<const float2*>(hist),
-                       g_desc, reinterpret_cast<float2*>(gx), N, C, n_bins, fc::echo_hist_dim(n_bins));
+                       reinterpret_cast<const float2*>(wxp_s), by_source->rowptr, by_source->nbr, gh, reinterpret_cast<float2*>(gx), N, C,
+                       n_bins, dS, wpv);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

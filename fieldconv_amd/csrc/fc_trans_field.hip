@@ -221,14 +221,25 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_
     }
 }
 
-// fixed-order sum of the per-wavefront partials: one thread per (o, i, slot)
-__global__ void trans_field_reduce_kernel(const float* __restrict__ partial, float* __restrict__ g_zA, float* __restrict__ g_zM,
-                                          float* __restrict__ g_phase, int nparts, int O, int Cin, int R, int ftype) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// fixed-order sum of the per-wavefront partials: 64 outputs (o, i, slot) per workgroup, 16 strided part-sums each, then a
+// fixed-order sum of the 16
+constexpr int kTfReduceWays = 16;
+__global__ __launch_bounds__(kTfReduceWays * kWave) void trans_field_reduce_kernel(
+    const float* __restrict__ partial, float* __restrict__ g_zA, float* __restrict__ g_zM, float* __restrict__ g_phase, int nparts,
+    int O, int Cin, int R, int ftype) {
+    __shared__ float s_part[kTfReduceWays][kWave];
+    const int lane = threadIdx.x & 63, way = threadIdx.x >> 6;
+    const int idx = blockIdx.x * kWave + lane;
     const int per = 2 * R + 1, total = O * Cin * per;
-    if (idx >= total) return;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * total + idx];
+    if (idx < total)
+        for (int p = way; p < nparts; p += kTfReduceWays) s += partial[(size_t)p * total + idx];
+    s_part[way][lane] = s;
+    __syncthreads();
+    if (way != 0 || idx >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < kTfReduceWays; ++q) s += s_part[q][lane];
     const int oi = idx / per, slot = idx - oi * per;
     if (slot < R) g_zA[(size_t)oi * R + slot] = s;
     else if (slot < 2 * R) g_zM[(size_t)oi * R + slot - R] = s;
@@ -323,7 +334,7 @@ int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, con
                        reinterpret_cast<const float2*>(ang), mag, reinterpret_cast<const float2*>(s1sum), zonal_ang, zonal_mag, phase,
                        reinterpret_cast<const float2*>(gy), g_ang, g_mag, gx_dst, partial, a, waves);
     const int total = O * Cin * (2 * R + 1);
-    hipLaunchKernelGGL(fc::trans_field_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, partial, g_zonal_ang, g_zonal_mag,
+    hipLaunchKernelGGL(fc::trans_field_reduce_kernel, dim3((total + fc::kWave - 1) / fc::kWave), dim3(fc::kTfReduceWays * fc::kWave), 0, s, partial, g_zonal_ang, g_zonal_mag,
                        g_phase, waves, O, Cin, R, ftype);
     hipLaunchKernelGGL(fc::trans_field_backward_input_kernel, dim3((N + fc::kTfWaves - 1) / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0,
                        s, reinterpret_cast<const float2*>(lift_sten), by_source->rowptr, by_source->nbr, slot_to_edge_s, g_ang, g_mag,

@@ -369,8 +369,9 @@ class _EchoFn(torch.autograd.Function):
             ln_s = ln.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
             wxp_s = wxp.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
             gx = torch.empty_like(x)
+            gh = torch.empty_like(hist)
             by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
-            check(lib.fc_echo_backward(_p(x), _p(ln_s), _p(wxp_s), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), N, csr.E, C,
+            check(lib.fc_echo_backward(_p(x), _p(ln_s), _p(wxp_s), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), _p(gh), N, csr.E, C,
                                        ctx.n_bins, _stream()), 'fc_echo_backward')
         return gx, None, None, None, None
 

@@ -1,3 +1,5 @@
 from .field import EPS, isZero, isOrigin, softAbs, softAngle, softAbsolute, softSqrt
 
-__all__ = ['EPS', 'isZero', 'isOrigin', 'softAbs', 'softAngle', 'softAbsolute', 'softSqrt']
+from .step_graph import StepGraph
+
+__all__ = ['StepGraph', 'EPS', 'isZero', 'isOrigin', 'softAbs', 'softAngle', 'softAbsolute', 'softSqrt']

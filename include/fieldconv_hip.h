@@ -157,12 +157,13 @@ int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* g
  * descriptor is |hist| (zero-safe).  x (N,C) c64, C <= 64; ln_t / wxp_t (E) c64 in by_target slot order; hist
  * (N,C,dS) c64 and desc (N,C,dS) f32 are overwritten, dS = fc_echo_hist_dim(n_bins), 1 <= n_bins <= 4.
  * Backward: by_source groups the edges by source (nbr = targets), ln_s / wxp_s in that slot order; g_desc (N,C,dS) f32;
- * gx (N,C) c64 is overwritten. */
+ * gx (N,C) c64 is overwritten; hist_grad_workspace: N*C*dS complex64 values of scratch. */
 int fc_echo_hist_dim(int32_t n_bins);
 int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const fc_csr* by_target, float* hist,
                     float* desc, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream);
 int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, const fc_csr* by_source, const float* hist,
-                     const float* g_desc, float* gx, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream);
+                     const float* g_desc, float* gx, float* hist_grad_workspace, int32_t N, int32_t E, int32_t C,
+                     int32_t n_bins, void* stream);
 
 /* ---- TransField (the learned 'gradient' of LiftBlock), reference nn/trans_field.py:78-113, weightContrib* :9-24 ---- *
  * x (N,Cin) f32 scalar features, Cin <= 4; lift_sten: the stencil columns m = 0, 1 (reference segmentation.ipynb:204)

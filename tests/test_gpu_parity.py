@@ -548,3 +548,41 @@ def test_full_size_properties(dev):
     assert torch.equal(torch.view_as_real(y2), torch.view_as_real(y))
     assert torch.equal(torch.view_as_real(gx2), torch.view_as_real(gx))
     assert torch.equal(torch.view_as_real(gW2), torch.view_as_real(gW))
+
+
+def test_step_graph_replays_a_training_step(dev):
+    """A block's forward + loss + backward captured as one HIP graph: the replay is bit-identical to the eager step,
+    and follows in-place updates of the inputs and the parameters (static addresses, fresh values)."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
+    from fieldconv_amd.transforms import FCPrecomp
+    from fieldconv_amd.utils import StepGraph
+    N, k, C, B, R = 300, 24, 16, 2, 6
+    data = sphere_support(N, k).to(dev)
+    edges, sten, ln, wxp = FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(5)
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    labels = torch.randint(0, 4, (N,), generator=g).to(dev)
+    mods = torch.nn.ModuleDict(dict(lift=LiftBlock(3, C, n_rings=R, ftype=1), res=FCResNetBlock(C, C, band_limit=B, n_rings=R),
+                                    echo=ECHOBlock(C, 4, n_des=C, n_bins=2, band_limit=B, n_rings=R))).to(dev)
+    params = list(mods.parameters())
+
+    def step():
+        x = mods['lift'](pos, edges, sten[..., B:B + 2])
+        x = mods['res'](x, edges, sten)
+        logits = mods['echo'](x, edges, sten, ln, wxp)
+        loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
+        return (loss.detach(),) + torch.autograd.grad(loss, params)
+
+    eager = [t.clone() for t in step()]
+    graphed = StepGraph(step)
+    assert all(torch.equal(a, b) for a, b in zip(eager, graphed.replay()))
+    with torch.no_grad():                       # an optimizer step and a new input, in place
+        for p, gp in zip(params, eager[1:]):
+            p.sub_(0.05 * gp)
+        pos.mul_(1.1)
+    replayed = [t.clone() for t in graphed.replay()]
+    fresh = step()
+    assert all(torch.equal(a, b) for a, b in zip(fresh, replayed))
+    assert not torch.equal(replayed[0], eager[0])

@@ -33,9 +33,16 @@ def step():
         x = mods[name](x, edges, sten)
     logits = mods['echo'](x, edges, sten, ln, wxp)
     loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
-    torch.autograd.grad(loss, params)
+    return (loss,) + torch.autograd.grad(loss, params)
 
 
+if os.environ.get('GRAPH', '0') == '1':             # the whole step as one HIP graph
+    from fieldconv_amd.utils import StepGraph
+    eager = [t.detach().clone() for t in step()]
+    graphed = StepGraph(step)
+    step = graphed.replay
+    same = all(torch.equal(a, b) for a, b in zip(eager, step()))
+    print('hipGraph replay bit-identical to eager:', same)
 for _ in range(10):
     step()
 torch.cuda.synchronize()
