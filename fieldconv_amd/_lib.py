@@ -36,9 +36,10 @@ SIGNATURES = {
     'fc_filter_param_grads': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _vp, _vp, _vp, _DP, _vp]),
     'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
     'fc_factored_record_floats': (ctypes.c_int, [_c_int32]),
-    'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
+    'fc_forward_workspace_bytes': (_sz, [_DP]),
+    'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_geometric_record_floats': (ctypes.c_int, []),
-    'fc_forward_geometric': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
+    'fc_forward_geometric': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_workspace_bytes': (_sz, [_DP]),
     'fc_backward_data': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),

@@ -84,27 +84,32 @@ int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!sten || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, sten, by_target, wpk_fwd, y, dims, 0, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, sten, by_target, wpk_fwd, y, dims, 0, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 int fc_factored_record_floats(int32_t band_limit) { return band_limit >= 0 ? fc::factored_record_floats(band_limit) : 0; }
 
+size_t fc_forward_workspace_bytes(const fc_dims* dims) {
+    if (!fc::dims_valid(dims) || !fc::dims_supported(dims)) return 0;
+    return fc::forward_workspace_bytes(dims, 1);
+}
+
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd, float* y,
-                        const fc_dims* dims, void* stream) {
+                        void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!rec_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, 1, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, 1, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int fc_geometric_record_floats(void) { return fc::kGeoRecordFloats; }
 
 int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_target, const float* wpk_fwd, float* y,
-                         const fc_dims* dims, void* stream) {
+                         void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!geo_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t fc_backward_workspace_bytes(const fc_dims* dims) {

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
     float2 xv = make_float2(0.f, 0.f);
     {
-        const int j = blockIdx.x * kTile + wave;
+        const int j = (blockIdx.x >> a.parts_log2) * kTile + wave;
         if (blockIdx.x < a.ntiles && j < a.N && lane < I) xv = gx_[(size_t)j * I + lane];
     }
     int buf = 0;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
             dma_slab(tn, buf ^ 1);
-            const int jn = tn * kTile + wave;
+            const int jn = (tn >> a.parts_log2) * kTile + wave;
             xv = (jn < a.N && lane < I) ? gx_[(size_t)jn * I + lane] : make_float2(0.f, 0.f);
         }
         // the xt stores must be visible to every wavefront; LDS only, the DMA just issued stays in flight
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
     if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
     float2 xv = make_float2(0.f, 0.f);
     {
-        const int j = blockIdx.x * kTile + wave;
+        const int j = (blockIdx.x >> a.parts_log2) * kTile + wave;
         if (blockIdx.x < a.ntiles && j < a.N && lane < I) xv = gx_[(size_t)j * I + lane];
     }
     const int nchunk = KP / 4;                     // chunks of four k entries; a lane converts chunks lane and lane + 64
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
             dma_slab(tn, buf ^ 1);
-            const int jn = tn * kTile + wave;
+            const int jn = (tn >> a.parts_log2) * kTile + wave;
             xv = (jn < a.N && lane < I) ? gx_[(size_t)jn * I + lane] : make_float2(0.f, 0.f);
         } else {
             xv = make_float2(0.f, 0.f);
@@ -350,7 +350,7 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
 
 size_t backward_workspace_bytes(const fc_dims* d) {
     const BwdPlan p = plan_backward(d, split_mode());
-    return p.hdump_bytes + p.gwp_bytes + 256;
+    return p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;
 }
 
 template <int T>

@@ -39,7 +39,10 @@ struct BwdArgs {
     MmaGeom g;           // M = I (rows of gxt), K = R*O in fp32 blocking: layout of the H slabs kept for the filter kernel
     MmaGeom gd;          // the same contraction in the data kernel's MFMA mode (fp32 or split)
     uint32_t wpk_bytes;  // size of the packed backward filter image
-    int ntiles;
+    int ntiles;          // VIRTUAL tiles: (N/16 vertex tiles) << parts_log2, one set of H slabs each
+    int parts_log2;      // 2^parts_log2 workgroups share a vertex tile, each with that share of every source's edges (see
+                         // FwdArgs); virtual tile vt covers the vertices of tile vt >> parts_log2
+    uint32_t part_stride;   // complex numbers between the parts' partial gx arrays
     int ngw;             // KST * NMT 16x16 gW tiles per frequency
     int KD;              // row stride (floats) of the H slabs kept for the filter kernel, one row of interleaved
                          // (re, im) pairs per vertex: 2*KP + 8, so that the filter kernel's 8-byte A-fragment reads
@@ -105,19 +108,31 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
     };
 
-    int beg = 0, end = 0, ro[R];      // ro: ring-run offsets of my source (factored), see fc_forward.hip
+    // slots of my source in virtual tile vt: part p of 2^pl takes [n p / parts, n (p+1) / parts) of the source's n slots,
+    // with the ring-run offsets clipped to that range (see fc_forward_kernels.hpp)
+    const int pl = a.parts_log2;
+    auto slot_range = [&](const int vt, int& b, int& e, int (&run)[R]) {
+        b = 0;
+        e = 0;
 #pragma unroll
-    for (int q = 0; q < R; ++q) ro[q] = 0;
-    {
-        const int j0 = first_tile_of_block() * kTile + wave;
-        if (first_tile_of_block() < a.ntiles && j0 < a.N) {
-            beg = growptr[j0];
-            end = growptr[j0 + 1];
+        for (int q = 0; q < R; ++q) run[q] = 0;
+        const int j = (vt >> pl) * kTile + wave;
+        if (vt < a.ntiles && j < a.N) {
+            const int rb = growptr[j];
+            const int n = growptr[j + 1] - rb;
+            const int part = vt & ((1 << pl) - 1);
+            const int s0 = (n * part) >> pl, s1 = (n * (part + 1)) >> pl;
+            b = rb + s0;
+            e = rb + s1;
             if (FACTORED) {
 #pragma unroll
-                for (int q = 0; q < R; ++q) ro[q] = gnbr[(size_t)j0 * kRunStride + q];
+                for (int q = 0; q < R; ++q) run[q] = min(max(gnbr[(size_t)j * kRunStride + q], s0), s1) - s0;
             }
         }
+    };
+    int beg = 0, end = 0, ro[R];      // ro: ring-run offsets of my source (factored), see fc_forward.hip
+    {
+        slot_range(first_tile_of_block(), beg, end, ro);
         if (FACTORED) {
             const int nch = (end - beg + CR - 1) >> LOG_CR;
             for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
@@ -126,23 +141,11 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 
     for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
         int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
-#pragma unroll
-        for (int q = 0; q < R; ++q) nro[q] = 0;
-        {
-            const int jn = (tile + gridDim.x) * kTile + wave;
-            if (tile + gridDim.x < a.ntiles && jn < a.N) {
-                nbeg = growptr[jn];
-                nend = growptr[jn + 1];
-                if (FACTORED) {
-#pragma unroll
-                    for (int q = 0; q < R; ++q) nro[q] = gnbr[(size_t)jn * kRunStride + q];
-                }
-            }
-        }
+        slot_range(tile + gridDim.x, nbeg, nend, nro);
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
         // my (vertex, channel) entry of x for the gx epilogue: issued now, consumed after the first slab
-        const int ejn = tile * kTile + ev;
+        const int ejn = (tile >> pl) * kTile + ev;
         float2 exs = make_float2(0.f, 0.f);
         if (e_active && ejn < a.N) exs = gx_[(size_t)ejn * I + ei];
         float2 gxacc = make_float2(0.f, 0.f);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             }
             if constexpr (SPLIT) vs = (vs == vscale) ? vscale + 2 * kTile : vscale;   // the next group writes the other buffer
         }
-        if (e_active && ejn < a.N) ggx[(size_t)ejn * I + ei] = gxacc;
+        if (e_active && ejn < a.N) ggx[(size_t)(tile & ((1 << pl) - 1)) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
         beg = nbeg;
         end = nend;
 #pragma unroll
@@ -389,8 +392,8 @@ __host__ __device__ inline int filter_image_stride(int KP) { return round_up(4 *
 
 struct BwdPlan {
     MmaGeom g, gd;
-    int IP, KP, KD, ntiles, ngw, P, F, slab_floats, slab_stride, fhalf;
-    size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes;
+    int IP, KP, KD, ntiles, parts_log2, ngw, P, F, slab_floats, slab_stride, fhalf;
+    size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes, gxp_bytes, gx_part_stride;
     bool ok, ok_factored;
 };
 
@@ -401,7 +404,10 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.gd = make_mma_geom(d->I, d->R, d->O, halves);
     p.IP = p.g.MP;
     p.KP = p.g.KP;
-    p.ntiles = (d->N + kTile - 1) / kTile;
+    p.parts_log2 = edge_parts_log2(d);
+    p.ntiles = ((d->N + kTile - 1) / kTile) << p.parts_log2;       // virtual tiles
+    p.gx_part_stride = part_stride((size_t)d->N * d->I);
+    p.gxp_bytes = p.parts_log2 ? (p.gx_part_stride << p.parts_log2) * sizeof(float2) : 0;
     p.ngw = p.g.KST * p.g.NMT;
     int P = kNumCUs / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
     if (P < 1) P = 1;
@@ -432,6 +438,8 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.gd = p.gd;
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R, d->O, p.F, p.gd.split) * sizeof(float));
     a.ntiles = p.ntiles;
+    a.parts_log2 = p.parts_log2;
+    a.part_stride = (uint32_t)p.gx_part_stride;
     a.ngw = p.ngw;
     a.KD = p.KD;
     a.slab_floats = p.slab_floats;
@@ -462,20 +470,25 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
                             void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
     const BwdPlan p = plan_backward(d, SPLIT ? split_mode() : 0);
     if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
+    if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes + p.gxp_bytes) return FC_ERR_WORKSPACE;
     const BwdArgs a = make_args(d, p);
     float* hdump = reinterpret_cast<float*>(ws);
+    // with an edge split the parts write partial gx arrays behind the slabs and the filter partials
+    float* gxp = reinterpret_cast<float*>(static_cast<char*>(ws) + p.hdump_bytes + p.gwp_bytes);
+    float2* gx2 = reinterpret_cast<float2*>(p.parts_log2 ? gxp : gx);
+    int rc = FC_ERR_UNSUPPORTED;
 #define FC_CASE(RR, BB)                                                                                                \
     if (d->R == RR && d->B == BB)                                                                                      \
-        return factored ? launch_backward_data<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x),                       \
-                                                             reinterpret_cast<const float2*>(gy), sten, g, wpk,        \
-                                                             reinterpret_cast<float2*>(gx), hdump, a, p, stream)       \
-                        : launch_backward_data<RR, BB, false, SPLIT>(reinterpret_cast<const float2*>(x),                      \
-                                                              reinterpret_cast<const float2*>(gy), sten, g, wpk,       \
-                                                              reinterpret_cast<float2*>(gx), hdump, a, p, stream);
+        rc = factored ? launch_backward_data<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x),                  \
+                                                           reinterpret_cast<const float2*>(gy), sten, g, wpk, gx2,     \
+                                                           hdump, a, p, stream)                                        \
+                      : launch_backward_data<RR, BB, false, SPLIT>(reinterpret_cast<const float2*>(x),                 \
+                                                            reinterpret_cast<const float2*>(gy), sten, g, wpk, gx2,    \
+                                                            hdump, a, p, stream);
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
-    return FC_ERR_UNSUPPORTED;
+    if (rc != FC_OK || p.parts_log2 == 0) return rc;
+    return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, 1 << p.parts_log2, stream);
 }
 
 

@@ -35,6 +35,10 @@ struct FwdArgs {
     int N, I, O;
     MmaGeom g;          // M = O, K = R*I
     int ntiles;
+    int parts_log2;     // factored kernels: every tile is processed by 2^parts_log2 workgroups, each taking that share of
+                        // every target's slots and writing its own partial output (y + part * part_stride); 0 = whole tiles.
+                        // Meshes with few vertices and wide supports would otherwise occupy ntiles of the 256 CUs.
+    uint32_t part_stride;   // complex numbers between the partial outputs: N*O rounded up to a multiple of 2
     int ring_chunks;    // factored: 1 KiB chunks per wavefront in the LDS record ring
     int slabs;          // slab buffers in LDS: 2 = consecutive frequencies alternate buffers and need one barrier each;
                         // the k-partials of the epilogue then live in whichever buffer is idle
@@ -315,17 +319,30 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     };
 
     // ro[q] = first slot (relative to beg) whose ring index is >= q: the slots of ring q are [ro[q], ro[q+1])
-    int beg = 0, end = 0, ro[R];
+    // A workgroup walks VIRTUAL tiles vt = (tile << parts_log2) + part: part p of 2^parts_log2 takes the slots
+    // [n p / parts, n (p+1) / parts) of each of the tile's targets, with the ring-run offsets clipped to that range.
+    const int pl = a.parts_log2;
+    const int nvt = a.ntiles << pl;
+    auto slot_range = [&](const int vt, int& b, int& e, int (&run)[R]) {
+        b = 0;
+        e = 0;
 #pragma unroll
-    for (int q = 0; q < R; ++q) ro[q] = 0;
-    {
-        const int t0 = first_tile_of_block() * kTile + wave;
-        if (first_tile_of_block() < a.ntiles && t0 < a.N) {
-            beg = growptr[t0];
-            end = growptr[t0 + 1];
+        for (int q = 0; q < R; ++q) run[q] = 0;
+        const int t = (vt >> pl) * kTile + wave;
+        if (vt < nvt && t < a.N) {
+            const int rb = growptr[t];
+            const int n = growptr[t + 1] - rb;
+            const int part = vt & ((1 << pl) - 1);
+            const int s0 = (n * part) >> pl, s1 = (n * (part + 1)) >> pl;
+            b = rb + s0;
+            e = rb + s1;
 #pragma unroll
-            for (int q = 0; q < R; ++q) ro[q] = gruns[(size_t)t0 * kRunStride + q];
+            for (int q = 0; q < R; ++q) run[q] = min(max(gruns[(size_t)t * kRunStride + q], s0), s1) - s0;
         }
+    };
+    int beg = 0, end = 0, ro[R];
+    {
+        slot_range(first_tile_of_block(), beg, end, ro);
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
     }
@@ -347,23 +364,13 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
 
     float* vs = l.vscale;
     int buf = 0;
-    for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
+    for (int vt = first_tile_of_block(); vt < nvt; vt += gridDim.x) {
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
 
         // next tile's slot range for this wavefront (its first chunks are DMA'd during phase B)
         int nbeg = 0, nend = 0, nro[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) nro[q] = 0;
-        {
-            const int tn = (tile + gridDim.x) * kTile + wave;
-            if (tile + gridDim.x < a.ntiles && tn < a.N) {
-                nbeg = growptr[tn];
-                nend = growptr[tn + 1];
-#pragma unroll
-                for (int q = 0; q < R; ++q) nro[q] = gruns[(size_t)tn * kRunStride + q];
-            }
-        }
+        slot_range(vt + gridDim.x, nbeg, nend, nro);
 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -466,8 +473,8 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
         first_rows(nend - nbeg, pxa, pxb);       // the next tile's first source rows fly during the epilogue
-        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, tile, wave, lane, acc_re,
-                                acc_im, gy_);
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, vt >> pl, wave, lane, acc_re,
+                                acc_im, gy_ + (size_t)(vt & ((1 << pl) - 1)) * a.part_stride);
         buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
         beg = nbeg;
@@ -491,14 +498,26 @@ static int launch_forward(const float2* x, const float* sten, const fc_csr* g, c
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
+// Edge split for small meshes: how many workgroups share a tile (log2).  Only when the tiles alone leave CUs idle and
+// every part still gets a few slots per target.
+inline int forward_parts_log2(const fc_dims* d, int kind) { return kind == 0 ? 0 : edge_parts_log2(d); }
+inline size_t forward_part_stride(const fc_dims* d) { return part_stride((size_t)d->N * d->O); }
+inline size_t forward_workspace_bytes_impl(const fc_dims* d, int kind) {
+    const int pl = forward_parts_log2(d, kind);
+    return pl ? (forward_part_stride(d) << pl) * sizeof(float2) : 0;
+}
+
 template <bool SPLIT>
 int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                      const fc_dims* d, int kind, hipStream_t stream) {
+                      const fc_dims* d, int kind, void* ws, size_t ws_bytes, hipStream_t stream) {
     const bool factored = kind != 0;
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
     a.g = make_mma_geom(d->O, d->R, d->I, SPLIT ? split_mode() : 0);
     a.ntiles = (d->N + kTile - 1) / kTile;
+    // without a workspace the tiles are not split (same result, fewer workgroups)
+    a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
+    a.part_stride = (uint32_t)forward_part_stride(d);
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, a.g.split) * sizeof(float));
     { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.ring_chunks = factored ? kRingChunks : 0;
@@ -508,18 +527,21 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
-    const int grid = factored ? (a.ntiles < kNumCUs ? a.ntiles : kNumCUs) : a.ntiles;
+    const int nvt = a.ntiles << a.parts_log2;
+    const int grid = factored ? (nvt < kNumCUs ? nvt : kNumCUs) : a.ntiles;
+    int rc = FC_ERR_UNSUPPORTED;
 #define FC_CASE(RR, BB)                                                                                              \
     if (d->R == RR && d->B == BB) {                                                                                  \
         const float2* x2 = reinterpret_cast<const float2*>(x);                                                       \
-        float2* y2 = reinterpret_cast<float2*>(y);                                                                   \
-        if (kind == 2) return launch_forward<RR, BB, 2, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);          \
-        if (kind == 1) return launch_forward<RR, BB, 1, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);          \
-        return launch_forward<RR, BB, 0, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);                         \
+        float2* y2 = reinterpret_cast<float2*>(a.parts_log2 ? static_cast<float*>(ws) : y);                          \
+        if (kind == 2) rc = launch_forward<RR, BB, 2, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);            \
+        else if (kind == 1) rc = launch_forward<RR, BB, 1, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);       \
+        else rc = launch_forward<RR, BB, 0, SPLIT>(x2, sten, g, wpk, y2, a, lds, grid, stream);                      \
     }
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
-    return FC_ERR_UNSUPPORTED;
+    if (rc != FC_OK || a.parts_log2 == 0) return rc;
+    return sum_parts(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, stream);
 }
 
 }  // namespace fc

@@ -18,8 +18,10 @@ constexpr int kNumCUs = 256;         // MI355X: 8 XCDs x 32 CUs; persistent grid
 constexpr int kMaxChannels = 64;     // one channel per lane in the gather phases
 
 // kind: 0 dense stencil rows, 1 factored records, 2 geometric-phase records
+// ws: optional scratch of forward_workspace_bytes(d, kind) bytes that lets several workgroups share a tile on small meshes
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                 const fc_dims* d, int kind, hipStream_t stream);
+                 const fc_dims* d, int kind, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t forward_workspace_bytes(const fc_dims* d, int kind);
 size_t backward_workspace_bytes(const fc_dims* d);
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);

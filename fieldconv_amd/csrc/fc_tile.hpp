@@ -2,7 +2,9 @@
 // hand-off between the per-wavefront gather phase and the MFMA contraction, the contraction
 // itself, and the fixed-order combination of the k-partials.
 #pragma once
+#include <stdlib.h>
 #include "fc_common.hpp"
+#include "fc_kernels.hpp"
 
 namespace fc {
 
@@ -266,6 +268,47 @@ __device__ __forceinline__ float2 sum_partials(const float* part, const MmaGeom&
         im += p.y;
     }
     return make_float2(re, im);
+}
+
+// ---- edge split for small meshes (forward and backward data kernels) ----
+// dst[idx] = sum over parts of part[p][idx], in part order (float4 per thread; the parts are part_stride complex numbers
+// apart, a multiple of 2)
+static __global__ void fc_sum_parts_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dst, size_t count4, size_t stride4, int parts,
+                                    size_t tail_floats) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count4) return;
+    f32x4 s = part[idx];
+    for (int p = 1; p < parts; ++p) s += part[(size_t)p * stride4 + idx];
+    if (idx + 1 < count4 || tail_floats == 0) dst[idx] = s;
+    else {
+        float* d = reinterpret_cast<float*>(dst + idx);
+        for (size_t k = 0; k < tail_floats; ++k) d[k] = s[k];
+    }
+}
+
+
+// complex numbers between the partial outputs of the parts: `count` rounded up to a multiple of 2 (16-byte rows)
+inline size_t part_stride(size_t count) { return ((count + 1) / 2) * 2; }
+
+// dst (count complex numbers) = fixed-order sum of `parts` partial arrays
+inline int sum_parts(const float* part, float* dst, size_t count, size_t stride, int parts, hipStream_t stream) {
+    const size_t floats = count * 2, count4 = (floats + 3) / 4;
+    hipLaunchKernelGGL(fc_sum_parts_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dst), count4, stride / 2, parts, floats % 4);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+// How many workgroups share a tile of 16 vertices (log2): only when the tiles alone leave CUs idle and every part still
+// gets a few edges per vertex.  FC_EDGE_PARTS_MAX (development) caps it.
+inline int edge_parts_log2(const fc_dims* d) {
+    if (d->N <= 0) return 0;
+    const int ntiles = (d->N + kTile - 1) / kTile;
+    const long deg = (long)d->E / d->N;
+    int cap = 3;
+    if (const char* e = getenv("FC_EDGE_PARTS_MAX")) cap = atoi(e);
+    int pl = 0;
+    while (pl < cap && (ntiles << (pl + 1)) <= kNumCUs && (deg >> (pl + 1)) >= 8) ++pl;
+    return pl;
 }
 
 }  // namespace fc

@@ -4,6 +4,7 @@ The tensors are plain torch device buffers; only raw pointers, sizes and the cur
 cross into libfieldconv_hip.so (include/fieldconv_hip.h).
 """
 import ctypes
+import os
 
 import torch
 
@@ -132,13 +133,19 @@ class _FieldConvFn(torch.autograd.Function):
 def _launch_forward(lib, x, graph, wpk_f, dims, O, st):
     y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
     csr = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
+    ws, nbytes = None, 0
+    if graph.factored and os.environ.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1':
+        nbytes = lib.fc_forward_workspace_bytes(ctypes.byref(dims))      # non-zero on small meshes with wide supports
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    wsp = _p(ws) if ws is not None else None
     with _timed('fc_forward'):
         if graph.geo_t is not None:
-            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                  'fc_forward_geometric')
+            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), ctypes.byref(csr), _p(wpk_f), _p(y), wsp, nbytes,
+                                           ctypes.byref(dims), st), 'fc_forward_geometric')
         elif graph.factored:
-            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                  'fc_forward_factored')
+            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), wsp, nbytes,
+                                          ctypes.byref(dims), st), 'fc_forward_factored')
         else:
             check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
                   'fc_forward')

@@ -96,10 +96,15 @@ int fc_forward(const float* x, const float* sten_t, const fc_csr* by_target, con
  * the caller has verified that structure it may pass, instead of the dense rows, one record of
  * fc_factored_record_floats(B) floats per edge (in by_target slot order and, inside every target's
  * slot range, sorted by q; followed by at least 1 KiB of readable padding):  [0] q as int32 bits, [1] w[q], [2] w[q+1],
- * [3] the slot's other endpoint (= by_target->nbr[slot]) as int32 bits, [4+2f], [5+2f] = Re, Im ph[f].  Same result as fc_forward up to fp32 rounding. */
+ * [3] the slot's other endpoint (= by_target->nbr[slot]) as int32 bits, [4+2f], [5+2f] = Re, Im ph[f].  Same result as fc_forward up to fp32 rounding.
+ * workspace (optional, may be NULL / 0): fc_forward_workspace_bytes(dims) bytes of scratch.  On meshes whose N/16 vertex
+ * tiles cannot occupy the 256 CUs (the reference's segmentation meshes: ~1k vertices with ~128 neighbours) it lets up
+ * to 8 workgroups share a tile, each taking a share of every target's edges; their partial outputs are added in a
+ * fixed order.  fc_forward_workspace_bytes returns 0 when the split does not apply. */
 int fc_factored_record_floats(int32_t band_limit);
+size_t fc_forward_workspace_bytes(const fc_dims* dims);
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd,
-                        float* y, const fc_dims* dims, void* stream);
+                        float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
 
 /* ---- geometric-phase records (forward only) ---------------------------------------------- *
  * FCPrecomp's phases are geometric in the frequency: ph[e,f] = c[e] * g[e]^(f-B) with |g| = 1
@@ -109,7 +114,7 @@ int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_tar
  * bits, [4],[5] = Re, Im c, [6],[7] = Re, Im g.  Same result as fc_forward up to fp32 rounding. */
 int fc_geometric_record_floats(void);
 int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_target, const float* wpk_fwd,
-                         float* y, const fc_dims* dims, void* stream);
+                         float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
 
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
  * Three calls on the same stream, sharing `workspace` (fc_backward_workspace_bytes(dims) bytes,

@@ -586,3 +586,46 @@ def test_step_graph_replays_a_training_step(dev):
     fresh = step()
     assert all(torch.equal(a, b) for a, b in zip(fresh, replayed))
     assert not torch.equal(replayed[0], eager[0])
+
+
+@pytest.mark.parametrize('N,k', [(200, 96), (1024, 128), (48, 40), (33, 32)])
+def test_edge_split_on_small_meshes(dev, monkeypatch, N, k):
+    """Meshes whose N/16 tiles cannot fill the chip: several workgroups share a tile, each with a share of every
+    vertex's edges (ragged degrees here: a random third of the edges is dropped).  Against the oracle, and against the
+    unsplit kernels on the same inputs."""
+    from fieldconv_amd import _lib
+    from fieldconv_amd._lib import FcDims
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from fieldconv_amd.transforms import FCPrecomp
+    import ctypes
+    I, O, B, R = 24, 20, 2, 6
+    data = sphere_support(N, k, seed=N)
+    edges, sten, _, _ = FCPrecomp(B, R, float(data.logMag.max()) * 1.0001)(data)
+    g = torch.Generator().manual_seed(N + k)
+    keep = torch.rand(edges.shape[0], generator=g) > 0.33
+    edges, sten = edges[keep].contiguous(), sten[keep].contiguous()
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    dims = FcDims(N, int(edges.shape[0]), I, O, R, B)
+    assert _lib.load().fc_forward_workspace_bytes(ctypes.byref(dims)) > 0            # the split applies to this shape
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    out = {}
+    for split in ('1', '0'):
+        for no_geo in ('0', '1'):
+            monkeypatch.setenv('FIELDCONV_NO_EDGE_SPLIT', '0' if split == '1' else '1')
+            monkeypatch.setenv('FIELDCONV_NO_GEO', no_geo)
+            graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+            assert graph.factored
+            xd = x.to(dev).requires_grad_(True)
+            Wd = W.to(dev).requires_grad_(True)
+            y = field_conv(xd, Wd, graph)
+            gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+            assert rel_err(H(y), y_ref) < TOL
+            assert rel_err(H(gx), gx_ref) < TOL
+            assert rel_err(H(gW), gW_ref) < TOL
+            out[split, no_geo] = H(y)
+    assert rel_err(out['1', '0'], out['0', '0']) < TOL and rel_err(out['1', '1'], out['0', '1']) < TOL
