@@ -93,7 +93,8 @@ def main():
     print(f'rank {rank}: n_owned={n_owned} halo={plan.n_halo} send={plan.send_counts} recv={plan.recv_counts} '
           f'err y={e_y:.2e} gx={e_gx:.2e} gW={e_gw:.2e}', flush=True)
     assert plan.n_halo > 0
-    assert e_y < 1e-5 and e_gx < 1e-5 and e_gw < 1e-5
+    tol = 5e-3 if (on_gpu and os.environ.get('FC_MFMA') == 'f16') else 1e-5      # f16: the opt-in reduced-precision mode
+    assert e_y < tol and e_gx < tol and e_gw < tol
     dist.destroy_process_group()
 
 
