@@ -1,0 +1,286 @@
+// Support-graph build for the kernels of this library: from the operator's inputs
+//   supp_edges (E,2) int64 (col 0 = source, col 1 = target; reference nn/field_conv.py:104-121) and
+//   supp_sten (E,R,F) complex64 (reference transforms/fc_precomp.py:95)
+// to the edges grouped by target and by source (rowptr / nbr / ring-run offsets, include/fieldconv_hip.h: fc_csr), the
+// factored per-edge records in slot order and the geometric-phase records of the forward pass.
+// The torch version of this (fieldconv_amd/graph.py) is ~100 small launches and two host synchronisations, 1.5-2.5 ms
+// per mesh -- as long as a whole training step of the segmentation network, and paid on every step of an epoch over
+// different meshes.  Here: one analysis kernel per edge (factorisation + verification + keys + bucket counts), one
+// kernel per vertex (ring-run offsets, degrees), two scans and two radix sorts (rocPRIM through hipCUB: plumbing), and
+// one placement kernel per side.  Slots are ordered by (vertex, lower ring q, original edge index): the sorts are
+// stable, the counts are integer atomics, so the result is deterministic.
+#include <hipcub/hipcub.hpp>
+#include "fc_common.hpp"
+#include "fc_kernels.hpp"
+
+namespace fc {
+
+constexpr int kGraphMaxR = 8;
+constexpr int kGraphMaxF = 7;
+constexpr float kGraphTol = 2e-6f;          // same acceptance threshold as graph.py: factor_stencil / geometric_phases
+
+struct GraphArgs {
+    int N, E, R, F, recf;
+};
+
+__device__ __forceinline__ float cabs2(float2 z) { return z.x * z.x + z.y * z.y; }
+
+// ---- per edge: factorisation of the stencil row, its verification, sort keys and bucket counts
+__global__ __launch_bounds__(256) void graph_analyze_kernel(
+    const int64_t* __restrict__ edges, const float2* __restrict__ sten, float* __restrict__ rec, float* __restrict__ geo,
+    uint32_t* __restrict__ key_t, uint32_t* __restrict__ key_s, uint32_t* __restrict__ val, int32_t* __restrict__ cnt_t,
+    int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags, const GraphArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.E) return;
+    const int R = a.R, F = a.F, B = (F - 1) / 2;
+    int64_t src = edges[2 * (size_t)e], dst = edges[2 * (size_t)e + 1];
+    if (src < 0 || src >= a.N || dst < 0 || dst >= a.N) {
+        atomicOr(flags, 4);
+        src = min(max(src, (int64_t)0), (int64_t)a.N - 1);
+        dst = min(max(dst, (int64_t)0), (int64_t)a.N - 1);
+    }
+    int q = 0;
+    if (sten) {
+        const float2* row = sten + (size_t)e * R * F;
+        // ring magnitudes: first non-zero ring, nothing outside {q, q+1}
+        float mag[kGraphMaxR];
+        float scale = 0.f;
+#pragma unroll
+        for (int r = 0; r < kGraphMaxR; ++r) {
+            mag[r] = 0.f;
+            if (r < R) {
+                float m2 = 0.f;
+                for (int f = 0; f < F; ++f) m2 = fmaxf(m2, cabs2(row[r * F + f]));
+                mag[r] = m2;
+                scale = fmaxf(scale, m2);
+            }
+        }
+        scale = sqrtf(scale);
+        int first = 0;
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < kGraphMaxR; ++r)
+            if (r < R && !found && mag[r] > 0.f) { first = r; found = true; }
+        q = min(first, R - 2);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < kGraphMaxR; ++r)
+            if (r < R && mag[r] > 0.f && (r < q || r > q + 1)) bad = true;
+        float2 s0[kGraphMaxF], s1[kGraphMaxF], ph[kGraphMaxF];
+        float den = 0.f, n0 = 0.f, n1 = 0.f;
+#pragma unroll
+        for (int f = 0; f < kGraphMaxF; ++f)
+            if (f < F) {
+                s0[f] = row[q * F + f];
+                s1[f] = row[(q + 1) * F + f];
+                ph[f] = make_float2(s0[f].x + s1[f].x, s0[f].y + s1[f].y);       // = phase * (w_q + w_{q+1})
+                den += cabs2(ph[f]);
+                n0 += s0[f].x * ph[f].x + s0[f].y * ph[f].y;                      // Re(s0 conj(ph))
+                n1 += s1[f].x * ph[f].x + s1[f].y * ph[f].y;
+            }
+        const float w0 = den > 0.f ? n0 / den : 0.f, w1 = den > 0.f ? n1 / den : 0.f;
+        float err2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < kGraphMaxF; ++f)
+            if (f < F) {
+                err2 = fmaxf(err2, cabs2(make_float2(s0[f].x - w0 * ph[f].x, s0[f].y - w0 * ph[f].y)));
+                err2 = fmaxf(err2, cabs2(make_float2(s1[f].x - w1 * ph[f].x, s1[f].y - w1 * ph[f].y)));
+            }
+        if (bad || sqrtf(err2) > kGraphTol * scale) atomicOr(flags, 1);
+        float* rp = rec + (size_t)e * a.recf;
+        rp[0] = __int_as_float(q);
+        rp[1] = w0;
+        rp[2] = w1;
+        rp[3] = 0.f;
+#pragma unroll
+        for (int f = 0; f < kGraphMaxF; ++f)
+            if (f < F) { rp[4 + 2 * f] = ph[f].x; rp[5 + 2 * f] = ph[f].y; }
+        for (int k = 4 + 2 * F; k < a.recf; ++k) rp[k] = 0.f;
+        // geometric phases: ph[f] = c g^(f-B), |g| = 1
+        if (geo) {
+            bool badgeo = B < 1;
+            float2 c = make_float2(0.f, 0.f), g = make_float2(1.f, 0.f);
+            if (B >= 1) {
+                c = ph[B];
+                const float cm2 = cabs2(c);
+                const bool live = cm2 > 0.f;
+                if (live) {
+                    const float2 n = ph[B + 1];
+                    g = make_float2((n.x * c.x + n.y * c.y) / cm2, (n.y * c.x - n.x * c.y) / cm2);      // ph[B+1] / c
+                }
+                float pscale = 0.f;
+#pragma unroll
+                for (int f = 0; f < kGraphMaxF; ++f)
+                    if (f < F) pscale = fmaxf(pscale, cabs2(ph[f]));
+                pscale = sqrtf(pscale);
+                float err = fabsf(sqrtf(cabs2(g)) - 1.f) * sqrtf(cm2);
+                float2 p = c, pc = c;
+#pragma unroll
+                for (int m = 1; m <= (kGraphMaxF - 1) / 2; ++m)
+                    if (m <= B) {
+                        p = cmul(p, g);
+                        pc = cmul_conj(pc, g);
+                        const float2 up = ph[B + m], dn = ph[B - m];
+                        err = fmaxf(err, sqrtf(cabs2(make_float2(up.x - p.x, up.y - p.y))));
+                        err = fmaxf(err, sqrtf(cabs2(make_float2(dn.x - pc.x, dn.y - pc.y))));
+                    }
+                badgeo = err > kGraphTol * pscale || (!live && pscale > 0.f);
+            }
+            if (badgeo) atomicOr(flags, 2);
+            float4* gp = reinterpret_cast<float4*>(geo + (size_t)e * 8);
+            gp[0] = make_float4(__int_as_float(q), w0, w1, 0.f);
+            gp[1] = make_float4(c.x, c.y, g.x, g.y);
+        }
+    }
+    const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
+    key_t[e] = kt;
+    key_s[e] = ks;
+    val[e] = (uint32_t)e;
+    atomicAdd(cnt_t + kt, 1);
+    atomicAdd(cnt_s + ks, 1);
+}
+
+// ---- per vertex: ring-run offsets (exclusive over q) and the degree, both sides
+__global__ void graph_runs_kernel(const int32_t* __restrict__ cnt_t, const int32_t* __restrict__ cnt_s, int32_t* __restrict__ runs_t,
+                                  int32_t* __restrict__ runs_s, int32_t* __restrict__ deg_t, int32_t* __restrict__ deg_s, int N) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > N) return;
+    if (v == N) { deg_t[N] = 0; deg_s[N] = 0; return; }         // the scans run over N+1 entries: rowptr[N] = E
+    int at = 0, as = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ct = cnt_t[(size_t)v * 8 + q], cs = cnt_s[(size_t)v * 8 + q];
+        runs_t[(size_t)v * 8 + q] = at;
+        runs_s[(size_t)v * 8 + q] = as;
+        at += ct;
+        as += cs;
+    }
+    deg_t[v] = at;
+    deg_s[v] = as;
+}
+
+// ---- per slot: the other endpoint, the slot -> edge permutation and the records in slot order
+__global__ __launch_bounds__(256) void graph_place_kernel(
+    const uint32_t* __restrict__ sorted_val, const int64_t* __restrict__ edges, int other_col, const float* __restrict__ rec,
+    const float* __restrict__ geo, int32_t* __restrict__ nbr, int64_t* __restrict__ perm, float* __restrict__ rec_out,
+    float* __restrict__ geo_out, const GraphArgs a) {
+    const int pieces = a.recf / 4;                  // float4 pieces of a record
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t slot = idx / pieces;
+    const int piece = (int)(idx - slot * pieces);
+    if (slot >= (size_t)a.E) return;
+    const uint32_t e = sorted_val[slot];
+    int64_t o = edges[2 * (size_t)e + other_col];
+    o = min(max(o, (int64_t)0), (int64_t)a.N - 1);
+    if (piece == 0) {
+        nbr[slot] = (int32_t)o;
+        perm[slot] = (int64_t)e;
+    }
+    if (rec_out) {
+        float4 v = *reinterpret_cast<const float4*>(rec + (size_t)e * a.recf + 4 * piece);
+        if (piece == 0) v.w = __int_as_float((int32_t)o);
+        *reinterpret_cast<float4*>(rec_out + slot * a.recf + 4 * piece) = v;
+    }
+    if (geo_out && piece < 2) {
+        float4 v = *reinterpret_cast<const float4*>(geo + (size_t)e * 8 + 4 * piece);
+        if (piece == 0) v.w = __int_as_float((int32_t)o);
+        *reinterpret_cast<float4*>(geo_out + slot * 8 + 4 * piece) = v;
+    }
+}
+
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+struct GraphPlan {
+    size_t cnt, deg, keys, vals, rec, geo, cub, total;
+    size_t cub_bytes;
+    int bits;
+};
+
+static GraphPlan plan_graph(int N, int E, int recf, bool with_sten) {
+    GraphPlan p;
+    p.bits = 3;
+    while (p.bits < 32 && ((uint64_t)1 << p.bits) < (uint64_t)N * 8) ++p.bits;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, E, 0, p.bits);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1);
+    p.cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    size_t off = 0;
+    p.cnt = off;  off += align256((size_t)N * 8 * 4 * 2);             // cnt_t | cnt_s
+    p.deg = off;  off += align256((size_t)(N + 1) * 4 * 2);           // deg_t | deg_s
+    p.keys = off; off += align256((size_t)E * 4) * 3;                 // key_t | key_s | sorted keys (scratch)
+    p.vals = off; off += align256((size_t)E * 4) * 2;                 // val | sorted val
+    p.rec = off;  off += with_sten ? align256((size_t)E * recf * 4) : 0;
+    p.geo = off;  off += with_sten ? align256((size_t)E * 8 * 4) : 0;
+    p.cub = off;  off += align256(p.cub_bytes);
+    p.total = off + 256;
+    return p;
+}
+
+}  // namespace fc
+
+extern "C" {
+
+size_t fc_graph_workspace_bytes(int32_t N, int32_t E, int32_t R, int32_t F, int32_t with_stencil) {
+    if (N <= 0 || E < 0) return 0;
+    const int recf = (4 + 2 * F + 3) / 4 * 4;
+    return fc::plan_graph(N, E, recf, with_stencil != 0).total;
+}
+
+int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N, int32_t E, int32_t R, int32_t F,
+                   int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s, int32_t* nbr_s,
+                   int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    if (N <= 0 || E < 0 || !rowptr_t || !rowptr_s || !runs_t || !runs_s || !flags || !workspace) return FC_ERR_BAD_ARGUMENT;
+    if (E > 0 && (!supp_edges || !nbr_t || !nbr_s || !perm_t || !perm_s)) return FC_ERR_BAD_ARGUMENT;
+    if ((uint64_t)N * 8 >= ((uint64_t)1 << 32)) return FC_ERR_UNSUPPORTED;
+    const bool with_sten = supp_sten != nullptr;
+    if (with_sten && (R < 2 || R > fc::kGraphMaxR || F < 1 || F > fc::kGraphMaxF || (F & 1) == 0 || !rec_t || !rec_s)) return FC_ERR_UNSUPPORTED;
+    const int recf = (4 + 2 * F + 3) / 4 * 4;
+    const fc::GraphPlan p = fc::plan_graph(N, E, recf, with_sten);
+    if (workspace_bytes < p.total) return FC_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(workspace);
+    int32_t* cnt_t = reinterpret_cast<int32_t*>(w + p.cnt);
+    int32_t* cnt_s = cnt_t + (size_t)N * 8;
+    int32_t* deg_t = reinterpret_cast<int32_t*>(w + p.deg);
+    int32_t* deg_s = deg_t + (N + 1);
+    const size_t ke = (((size_t)E * 4 + 255) / 256 * 256) / 4;
+    uint32_t* key_t = reinterpret_cast<uint32_t*>(w + p.keys);
+    uint32_t* key_s = key_t + ke;
+    uint32_t* key_sorted = key_s + ke;
+    uint32_t* val = reinterpret_cast<uint32_t*>(w + p.vals);
+    uint32_t* val_sorted = val + ke;
+    float* rec = with_sten ? reinterpret_cast<float*>(w + p.rec) : nullptr;
+    float* geo = (with_sten && geo_t) ? reinterpret_cast<float*>(w + p.geo) : nullptr;
+    void* cub = w + p.cub;
+    size_t cub_bytes = p.cub_bytes;
+    const fc::GraphArgs a{N, E, R, F, recf};
+
+    if (hipMemsetAsync(cnt_t, 0, (size_t)N * 8 * 4 * 2, s) != hipSuccess) return FC_ERR_LAUNCH;
+    if (hipMemsetAsync(flags, 0, 4, s) != hipSuccess) return FC_ERR_LAUNCH;
+    if (E > 0)
+        hipLaunchKernelGGL(fc::graph_analyze_kernel, dim3((E + 255) / 256), dim3(256), 0, s, supp_edges,
+                           reinterpret_cast<const float2*>(supp_sten), rec, geo, key_t, key_s, val, cnt_t, cnt_s, flags, a);
+    hipLaunchKernelGGL(fc::graph_runs_kernel, dim3((N + 1 + 255) / 256), dim3(256), 0, s, cnt_t, cnt_s, runs_t, runs_s, deg_t, deg_s, N);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, deg_t, rowptr_t, N + 1, s) != hipSuccess) return FC_ERR_LAUNCH;
+    cub_bytes = p.cub_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, deg_s, rowptr_s, N + 1, s) != hipSuccess) return FC_ERR_LAUNCH;
+    if (E > 0) {
+        const size_t threads = (size_t)E * (recf / 4);
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        cub_bytes = p.cub_bytes;
+        if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, key_t, key_sorted, val, val_sorted, E, 0, p.bits, s) != hipSuccess)
+            return FC_ERR_LAUNCH;
+        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, val_sorted, supp_edges, 0, rec, geo, nbr_t, perm_t,
+                           with_sten ? rec_t : nullptr, geo ? geo_t : nullptr, a);
+        cub_bytes = p.cub_bytes;
+        if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, key_s, key_sorted, val, val_sorted, E, 0, p.bits, s) != hipSuccess)
+            return FC_ERR_LAUNCH;
+        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, val_sorted, supp_edges, 1, rec, nullptr, nbr_s, perm_s,
+                           with_sten ? rec_s : nullptr, nullptr, a);
+    }
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -12,8 +12,10 @@ rows in slot order, so this module builds, once per (supp_edges, supp_sten) pair
 
 Every FieldConv in a network receives the same pair (reference segmentation.ipynb:205), so the
 result is cached and the cost is amortised over all convolutions of a forward+backward.
-Everything runs on the device with torch ops (sort / bincount / cumsum / gather): plumbing, no
-host synchronisation.
+Device tensors are processed by the library's own build (csrc/fc_graph.hip through fc_graph_build: one analysis
+kernel, two radix sorts, two scans, two placement kernels, one host synchronisation for the verdict); the torch
+version below (sort / bincount / cumsum / gather, ~100 launches) is what CPU tensors take and what the tests compare
+the native build against.
 """
 import collections
 import os
@@ -100,9 +102,9 @@ def geometric_phases(rec, F, tol=2e-6):
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', '_keep')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep')
 
-    def __init__(self, supp_edges, supp_sten, N, allow_factored=True):
+    def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
             raise ValueError('supp_edges must have shape (E, 2)')
         if supp_sten.dim() != 3 or supp_sten.shape[0] != supp_edges.shape[0]:
@@ -138,6 +140,12 @@ class SupportGraph:
         self._keep = (supp_edges, supp_sten)      # pins the storages the cache key refers to
         self.factored = False
         self.rec_t = self.rec_s = self.sten_t = self.sten_s = self.runs_t = self.runs_s = self.geo_t = None
+        self.perm_t = self.perm_s = None
+        if native is None:
+            native = sten.is_cuda and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1'
+        if native and E > 0 and 2 <= self.R <= 8 and self.F <= 7 and self.F % 2 == 1:
+            self._build_native(supp_edges, sten, allow_factored)
+            return
         # factored fast path: FCPrecomp's stencil is w[e,r] * ph[e,f] with two adjacent non-zero rings
         rec = None
         if allow_factored and E > 0 and self.R >= 2 and os.environ.get('FIELDCONV_DENSE', '0') != '1':
@@ -149,6 +157,7 @@ class SupportGraph:
             pad = torch.zeros((1024 // (rec.shape[1] * 4) + 16, rec.shape[1]), dtype=rec.dtype, device=dev)
             self.rowptr_t, self.nbr_t, perm_t = group(dst, src, q)
             self.rowptr_s, self.nbr_s, perm_s = group(src, dst, q)
+            self.perm_t, self.perm_s = perm_t, perm_s
             rt = rec.index_select(0, perm_t)
             rt[:, 3] = self.nbr_t.view(torch.float32)
             rs = rec.index_select(0, perm_s)
@@ -173,6 +182,7 @@ class SupportGraph:
         else:
             self.rowptr_t, self.nbr_t, perm_t = group(dst, src)
             self.rowptr_s, self.nbr_s, perm_s = group(src, dst)
+            self.perm_t, self.perm_s = perm_t, perm_s
             if E == 0:
                 self.sten_t = self.sten_s = sten
             else:
@@ -181,6 +191,52 @@ class SupportGraph:
                 # identity permutation and the stencil needs no second copy (one host sync per build)
                 by_source = bool((src[1:] >= src[:-1]).all()) if E > 1 else True
                 self.sten_s = sten if by_source else sten.index_select(0, perm_s)
+
+    def _build_native(self, supp_edges, sten, allow_factored):
+        """csrc/fc_graph.hip: everything above in ~12 launches.  The factored / geometric verdicts come back in one
+        flags word (the one host synchronisation of the build)."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev, N, E, R, F = sten.device, self.N, self.E, self.R, self.F
+        edges = supp_edges.to(torch.int64).contiguous()
+        want_rec = allow_factored and os.environ.get('FIELDCONV_DENSE', '0') != '1'
+        want_geo = want_rec and os.environ.get('FIELDCONV_NO_GEO', '0') != '1' and F >= 3
+        recf = (4 + 2 * F + 3) // 4 * 4
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            self.rowptr_t = torch.empty(N + 1, **i32)
+            self.rowptr_s = torch.empty(N + 1, **i32)
+            self.nbr_t = torch.empty(E, **i32)
+            self.nbr_s = torch.empty(E, **i32)
+            runs_t = torch.empty((N, 8), **i32)
+            runs_s = torch.empty((N, 8), **i32)
+            self.perm_t = torch.empty(E, dtype=torch.int64, device=dev)
+            self.perm_s = torch.empty(E, dtype=torch.int64, device=dev)
+            rec_t = rec_s = geo_t = None
+            if want_rec:        # zeroed: the kernels stream up to 1 KiB past the last record
+                rec_t = torch.zeros((E + 1024 // (recf * 4) + 16, recf), dtype=torch.float32, device=dev)
+                rec_s = torch.zeros_like(rec_t)
+                if want_geo:
+                    geo_t = torch.zeros((E + 1024 // 32 + 16, 8), dtype=torch.float32, device=dev)
+            flags = torch.empty(1, **i32)
+            nbytes = lib.fc_graph_workspace_bytes(N, E, R, F, 1 if want_rec else 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+            _lib.check(lib.fc_graph_build(p(edges), p(sten) if want_rec else None, N, E, R, F, p(self.rowptr_t), p(self.nbr_t),
+                                          p(runs_t), p(self.perm_t), p(self.rowptr_s), p(self.nbr_s), p(runs_s), p(self.perm_s),
+                                          p(rec_t), p(rec_s), p(geo_t), p(flags), p(ws), nbytes,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'fc_graph_build')
+            verdict = int(flags.item())
+        if verdict & 4:
+            raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+        if want_rec and not (verdict & 1):
+            self.factored = True
+            self.rec_t, self.rec_s, self.runs_t, self.runs_s = rec_t, rec_s, runs_t, runs_s
+            self.geo_t = geo_t if (want_geo and not (verdict & 2)) else None
+        else:                   # dense kernels: stencil rows in slot order (any order inside a vertex is fine)
+            self.sten_t = sten.index_select(0, self.perm_t)
+            self.sten_s = sten.index_select(0, self.perm_s)
 
     def check_indices(self):
         """Debug helper: host-synchronising range check of the edge list."""
@@ -231,8 +287,44 @@ class EdgeCSR:
             rowptr = torch.zeros(self.N + 1, dtype=torch.int32, device=dev)
             rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
             return rowptr, other[perm].to(torch.int32).contiguous(), perm
+        if supp_edges.is_cuda and self.E > 0 and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1':
+            self._native(supp_edges)
+            return
         self.rowptr_t, self.nbr_t, self.perm_t = group(dst, src)
         self.rowptr_s, self.nbr_s, self.perm_s = group(src, dst)
+
+    def _native(self, supp_edges):
+        """edge grouping only (fc_graph_build without a stencil)"""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev, N, E = supp_edges.device, self.N, self.E
+        edges = supp_edges.to(torch.int64).contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            self.rowptr_t, self.rowptr_s = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+            self.nbr_t, self.nbr_s = torch.empty(E, **i32), torch.empty(E, **i32)
+            runs_t, runs_s = torch.empty((N, 8), **i32), torch.empty((N, 8), **i32)
+            self.perm_t = torch.empty(E, dtype=torch.int64, device=dev)
+            self.perm_s = torch.empty(E, dtype=torch.int64, device=dev)
+            flags = torch.empty(1, **i32)
+            nbytes = lib.fc_graph_workspace_bytes(N, E, 2, 1, 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+            _lib.check(lib.fc_graph_build(p(edges), None, N, E, 2, 1, p(self.rowptr_t), p(self.nbr_t), p(runs_t), p(self.perm_t),
+                                          p(self.rowptr_s), p(self.nbr_s), p(runs_s), p(self.perm_s), None, None, None, p(flags),
+                                          p(ws), nbytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       'fc_graph_build')
+            if int(flags.item()) & 4:
+                raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+
+    @classmethod
+    def from_support_graph(cls, sg, supp_edges):
+        g = cls.__new__(cls)
+        g.N, g.E, g._keep = sg.N, sg.E, supp_edges
+        g.rowptr_t, g.nbr_t, g.perm_t = sg.rowptr_t, sg.nbr_t, sg.perm_t
+        g.rowptr_s, g.nbr_s, g.perm_s = sg.rowptr_s, sg.nbr_s, sg.perm_s
+        return g
 
 
 _edge_cache = collections.OrderedDict()
@@ -244,7 +336,13 @@ def get_edge_csr(supp_edges, N):
     if g is not None:
         _edge_cache.move_to_end(key)
         return g
-    g = EdgeCSR(supp_edges, N)
+    # the FieldConvs of the same network already grouped these edges (any order inside a vertex serves)
+    for (ek, _, n), sg in reversed(_cache.items()):
+        if ek == key[0] and n == key[1] and sg.perm_t is not None:
+            g = EdgeCSR.from_support_graph(sg, supp_edges)
+            break
+    else:
+        g = EdgeCSR(supp_edges, N)
     _edge_cache[key] = g
     while len(_edge_cache) > _CACHE_SIZE:
         _edge_cache.popitem(last=False)

@@ -189,6 +189,23 @@ int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, con
                             float* g_zonal_mag, float* g_phase, void* workspace, size_t workspace_bytes, int32_t N,
                             int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride, int32_t ftype, void* stream);
 
+/* ---- support-graph build (what every FieldConv needs before its first launch on a mesh) ---------------------------- *
+ * From the operator's own inputs (reference nn/field_conv.py:104-121): supp_edges (E,2) int64, col 0 = source, col 1 =
+ * target; supp_sten (E,R,F) c64 contiguous, F = 2B+1 (NULL: edge grouping only, for the ECHO / TransField entry points)
+ * to the two fc_csr groupings and the per-edge records of fc_forward_factored / fc_forward_geometric /
+ * fc_backward_data_factored.  Slots are ordered by (vertex, lower ring q, original edge index); perm_* (E) int64 give the
+ * original edge of every slot; runs_* are (N,8) int32; rec_* hold E rows of fc_factored_record_floats(B) floats, geo_t E
+ * rows of 8 floats -- the caller allocates and zeroes the >= 1 KiB of padding behind them.  flags (one device int32):
+ * bit 0 the stencil is NOT of the rank-1 / two-adjacent-rings form (every row is reconstructed and compared, relative
+ * tolerance 2e-6): rec_* / geo_t must not be used, use the dense entry points with supp_sten[perm]; bit 1 the phases are
+ * not geometric in the frequency: geo_t must not be used; bit 2 an edge refers to a vertex outside [0, N).
+ * No host synchronisation inside; reading `flags` is the caller's one synchronisation per mesh. */
+size_t fc_graph_workspace_bytes(int32_t N, int32_t E, int32_t R, int32_t F, int32_t with_stencil);
+int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N, int32_t E, int32_t R, int32_t F,
+                   int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
+                   int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t,
+                   int32_t* flags, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

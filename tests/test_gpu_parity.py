@@ -629,3 +629,47 @@ def test_edge_split_on_small_meshes(dev, monkeypatch, N, k):
             assert rel_err(H(gW), gW_ref) < TOL
             out[split, no_geo] = H(y)
     assert rel_err(out['1', '0'], out['0', '0']) < TOL and rel_err(out['1', '1'], out['0', '1']) < TOL
+
+
+@pytest.mark.parametrize('N,k,B,R', [(300, 20, 2, 6), (1024, 128, 2, 6), (77, 9, 1, 3), (150, 12, 3, 8)])
+def test_native_graph_build_matches_torch_build(dev, N, k, B, R):
+    """fc_graph_build (csrc/fc_graph.hip) against the torch build of the same SupportGraph: identical grouping, slot
+    order, permutations and ring-run offsets; records equal up to the rounding of the two weight quotients; a dense
+    (non-factorable) stencil is detected and takes the dense kernels."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.graph import EdgeCSR, SupportGraph
+    from fieldconv_amd.transforms import FCPrecomp
+    data = sphere_support(N, k, seed=N)
+    edges, sten, _, _ = FCPrecomp(B, R, float(data.logMag.max()) * 1.0001)(data)
+    g = torch.Generator().manual_seed(N)
+    order = torch.randperm(edges.shape[0], generator=g)             # no particular input order
+    edges, sten = edges[order].contiguous().to(dev), sten[order].contiguous().to(dev)
+    a = SupportGraph(edges, sten, N, native=True)
+    b = SupportGraph(edges, sten, N, native=False)
+    assert a.factored and b.factored and (a.geo_t is not None) and (b.geo_t is not None)
+    for name in ('rowptr_t', 'nbr_t', 'runs_t', 'perm_t', 'rowptr_s', 'nbr_s', 'runs_s', 'perm_s'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for name in ('rec_t', 'rec_s', 'geo_t'):
+        ra, rb = getattr(a, name), getattr(b, name)
+        assert ra.shape == rb.shape, name
+        assert torch.equal(ra[:, 0].view(torch.int32), rb[:, 0].view(torch.int32)) and torch.equal(ra[:, 3].view(torch.int32), rb[:, 3].view(torch.int32))
+        keep = [c for c in range(ra.shape[1]) if c not in (0, 3)]
+        assert rel_err(H(ra[:, keep]), H(rb[:, keep])) < 1e-6, name
+    e = EdgeCSR(edges, N)
+    for name in ('rowptr_t', 'rowptr_s'):
+        assert torch.equal(getattr(e, name), getattr(a, name))
+    assert torch.equal(torch.sort(e.nbr_t.view(-1))[0], torch.sort(a.nbr_t)[0])
+    assert torch.equal(edges[e.perm_t, 0].to(torch.int32), e.nbr_t) and torch.equal(edges[e.perm_s, 1].to(torch.int32), e.nbr_s)
+    # a random dense stencil is not factorable: both builds must say so
+    dense = torch.complex(torch.randn(sten.shape, generator=g), torch.randn(sten.shape, generator=g)).to(dev)
+    c = SupportGraph(edges, dense, N, native=True)
+    assert not c.factored and torch.equal(c.sten_t, dense[c.perm_t]) and torch.equal(c.sten_s, dense[c.perm_s])
+    # rank-1 but not geometric phases: factored records without the geometric form
+    twisted = sten.clone()
+    twisted[:, :, 0] *= 1.5
+    d = SupportGraph(edges, twisted, N, native=True)
+    assert d.factored and d.geo_t is None
+    with pytest.raises(IndexError):
+        bad = edges.clone()
+        bad[3, 0] = N + 5
+        SupportGraph(bad, sten, N, native=True)
