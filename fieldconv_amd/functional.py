@@ -72,8 +72,34 @@ def _require_device(t, what):
                            'there is no CPU fallback')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw pointer.  torch.cuda.current_stream() costs ~10 us of
+    Python per call -- with ~25 launches per network forward that was a quarter of the host's enqueue time."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for the launches below; free when `device` already is the current one (the usual case)."""
+    if _cur_device is not None and device.index is not None and _cur_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def _p(t):
@@ -102,17 +128,14 @@ class _FieldConvFn(torch.autograd.Function):
         w_eff = w_eff.contiguous()
         O, I, R, F = w_eff.shape
         B = (F - 1) // 2
-        dims = make_dims(graph, I, O, B)
-        if not lib.fc_supported(ctypes.byref(dims)):
-            raise _lib.FieldConvNativeError(
-                f'FieldConv(in={I}, out={O}, n_rings={R}, band_limit={B}) is outside the compiled HIP kernels '
-                '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
-        with torch.cuda.device(x.device):
+        plan = _conv_plan(lib, graph, I, O, B)
+        dims = plan.dims
+        with _on(x.device):
             st = _stream()
-            wpk_f = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
-            wpk_b = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
+            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
             check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), st), 'fc_pack_filter')
-            y = _launch_forward(lib, x, graph, wpk_f, dims, O, st)
+            y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
         ctx.wshape = (O, I, R, F)
@@ -123,50 +146,75 @@ class _FieldConvFn(torch.autograd.Function):
         lib = _lib.load()
         x, wpk_b = ctx.saved_tensors
         O, I, R, F = ctx.wshape
-        dims = make_dims(ctx.graph, I, O, (F - 1) // 2)
+        plan = _conv_plan(lib, ctx.graph, I, O, (F - 1) // 2)
         gy = gy.contiguous()
-        with torch.cuda.device(x.device):
-            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, dims, ctx.wshape, _stream())
+        with _on(x.device):
+            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, _stream())
         return gx, gw, None
 
 
-def _launch_forward(lib, x, graph, wpk_f, dims, O, st):
-    y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
-    csr = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
-    ws, nbytes = None, 0
+class _ConvPlan:
+    """What every launch of one (graph, in, out, band limit) combination needs and never changes: the dims struct, the
+    grouping structs, buffer sizes.  Cached on the graph: ~15 ctypes calls per convolution otherwise."""
+    __slots__ = ('dims', 'dref', 'n_fwd', 'n_bwd', 'ws_fwd', 'ws_bwd', 'csr_t', 'csr_s', 'cref_t', 'cref_s')
+
+
+def _conv_plan(lib, graph, I, O, B):
+    key = (int(I), int(O), int(B))
+    plan = graph._plans.get(key)
+    if plan is not None:
+        return plan
+    plan = _ConvPlan()
+    plan.dims = make_dims(graph, I, O, B)
+    plan.dref = ctypes.byref(plan.dims)
+    if not lib.fc_supported(plan.dref):
+        raise _lib.FieldConvNativeError(
+            f'FieldConv(in={I}, out={O}, n_rings={graph.R}, band_limit={B}) is outside the compiled HIP kernels '
+            '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
+    plan.n_fwd = lib.fc_packed_filter_floats_fwd(plan.dref)
+    plan.n_bwd = lib.fc_packed_filter_floats_bwd(plan.dref)
+    plan.ws_bwd = lib.fc_backward_workspace_bytes(plan.dref)
+    plan.ws_fwd = 0
     if graph.factored and os.environ.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1':
-        nbytes = lib.fc_forward_workspace_bytes(ctypes.byref(dims))      # non-zero on small meshes with wide supports
-        if nbytes:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        plan.ws_fwd = lib.fc_forward_workspace_bytes(plan.dref)      # non-zero on small meshes with wide supports
+    plan.csr_t = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
+    plan.csr_s = _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
+    plan.cref_t, plan.cref_s = ctypes.byref(plan.csr_t), ctypes.byref(plan.csr_s)
+    graph._plans[key] = plan
+    return plan
+
+
+def _launch_forward(lib, x, graph, wpk_f, plan, O, st):
+    y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
+    nbytes = plan.ws_fwd
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     wsp = _p(ws) if ws is not None else None
     with _timed('fc_forward'):
         if graph.geo_t is not None:
-            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), ctypes.byref(csr), _p(wpk_f), _p(y), wsp, nbytes,
-                                           ctypes.byref(dims), st), 'fc_forward_geometric')
+            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, st),
+                  'fc_forward_geometric')
         elif graph.factored:
-            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(csr), _p(wpk_f), _p(y), wsp, nbytes,
-                                          ctypes.byref(dims), st), 'fc_forward_factored')
+            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, st),
+                  'fc_forward_factored')
         else:
-            check(lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(csr), _p(wpk_f), _p(y), ctypes.byref(dims), st),
-                  'fc_forward')
+            check(lib.fc_forward(_p(x), _p(graph.sten_t), plan.cref_t, _p(wpk_f), _p(y), plan.dref, st), 'fc_forward')
     return y
 
 
-def _launch_backward(lib, x, gy, graph, wpk_b, dims, wshape, st):
+def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
     O, I, R, F = wshape
     gx = torch.empty_like(x)
     gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
-    nbytes = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
+    nbytes = plan.ws_bwd
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    csr = _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
     sten = graph.rec_s if graph.factored else graph.sten_s
     fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
+    wsp = _p(ws)
     with _timed('fc_backward_data'):
-        check(fn(_p(x), _p(gy), _p(sten), ctypes.byref(csr), _p(wpk_b), _p(gx), _p(ws), nbytes, ctypes.byref(dims), st),
-              'fc_backward_data')
+        check(fn(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_data')
     with _timed('fc_backward_filter'):
-        check(lib.fc_backward_filter(_p(x), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_filter')
-    check(lib.fc_backward_finish(_p(gw), _p(ws), nbytes, ctypes.byref(dims), st), 'fc_backward_finish')
+        check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, st), 'fc_backward_filter')
+    check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, st), 'fc_backward_finish')
     return gx, gw
 
 
@@ -182,18 +230,15 @@ class _FieldConvParamFn(torch.autograd.Function):
         zonal, spherical, phase = zonal.contiguous(), spherical.contiguous(), phase.contiguous()
         O, I, R = zonal.shape[0], zonal.shape[1], zonal.shape[2]
         F = 2 * B + 1
-        dims = make_dims(graph, I, O, B)
-        if not lib.fc_supported(ctypes.byref(dims)):
-            raise _lib.FieldConvNativeError(
-                f'FieldConv(in={I}, out={O}, n_rings={R}, band_limit={B}) is outside the compiled HIP kernels '
-                '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
-        with torch.cuda.device(x.device):
+        plan = _conv_plan(lib, graph, I, O, B)
+        dims = plan.dims
+        with _on(x.device):
             st = _stream()
-            wpk_f = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
-            wpk_b = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), dtype=torch.float32, device=x.device)
+            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
+            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
             check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), ctypes.byref(dims),
                                             st), 'fc_pack_filter_params')
-            y = _launch_forward(lib, x, graph, wpk_f, dims, O, st)
+            y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
         ctx.graph, ctx.ftype, ctx.wshape = graph, ftype, (O, I, R, F)
         return y
@@ -203,11 +248,12 @@ class _FieldConvParamFn(torch.autograd.Function):
         lib = _lib.load()
         x, wpk_b, zonal, spherical, phase = ctx.saved_tensors
         O, I, R, F = ctx.wshape
-        dims = make_dims(ctx.graph, I, O, (F - 1) // 2)
+        plan = _conv_plan(lib, ctx.graph, I, O, (F - 1) // 2)
+        dims = plan.dims
         gy = gy.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             st = _stream()
-            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, dims, ctx.wshape, st)
+            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, st)
             g_z = torch.empty_like(zonal)
             g_s = torch.empty_like(spherical)
             g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
@@ -269,7 +315,7 @@ class _TangentLinFn(torch.autograd.Function):
         im_w = im_w.contiguous()
         O, I = re_w.shape
         N = x.shape[0]
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             y = torch.empty((N, O), dtype=torch.complex64, device=x.device)
             check(lib.fc_tangent_lin_forward(_p(x), _p(re_w), _p(im_w), _p(y), N, I, O, _stream()), 'fc_tangent_lin_forward')
         ctx.save_for_backward(x, re_w, im_w)
@@ -282,7 +328,7 @@ class _TangentLinFn(torch.autograd.Function):
         O, I = re_w.shape
         N = x.shape[0]
         gy = gy.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             gx = torch.empty_like(x)
             g_re = torch.empty_like(re_w)
             g_im = torch.empty_like(im_w)
@@ -311,7 +357,7 @@ class _TangentNonLinFn(torch.autograd.Function):
         x = x.contiguous()
         b = bias.contiguous()
         N, C = x.shape
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             y = torch.empty_like(x)
             check(lib.fc_tangent_nonlin_forward(_p(x), _p(b), _p(y), N, C, _stream()), 'fc_tangent_nonlin_forward')
         ctx.save_for_backward(x, b)
@@ -323,7 +369,7 @@ class _TangentNonLinFn(torch.autograd.Function):
         x, b = ctx.saved_tensors
         N, C = x.shape
         gy = gy.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             gx = torch.empty_like(x)
             gb = torch.empty_like(b)
             nbytes = lib.fc_tangent_nonlin_backward_workspace_bytes(N, C)
@@ -353,7 +399,7 @@ class _EchoFn(torch.autograd.Function):
         dS = lib.fc_echo_hist_dim(n_bins)
         if dS == 0:
             raise ValueError(f'ECHO: n_bins must be in 1..4, got {n_bins}')
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             ln_t = ln.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
             wxp_t = wxp.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
             hist = torch.empty((N, C, dS), dtype=torch.complex64, device=x.device)
@@ -372,7 +418,7 @@ class _EchoFn(torch.autograd.Function):
         csr = ctx.csr
         N, C = x.shape
         g_desc = g_desc.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             ln_s = ln.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
             wxp_s = wxp.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
             gx = torch.empty_like(x)
@@ -414,7 +460,7 @@ class _TransFieldFn(torch.autograd.Function):
         O, _, R = zonal_ang.shape
         sten, stride = _TransFieldFn._stencil(lift_sten)
         zonal_ang, zonal_mag, phase = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             y = torch.empty((N, O), dtype=torch.complex64, device=x.device)
             ang = torch.empty((N, Cin, R), dtype=torch.complex64, device=x.device)
             mag = torch.empty((N, Cin, R), dtype=torch.float32, device=x.device)
@@ -435,7 +481,7 @@ class _TransFieldFn(torch.autograd.Function):
         O, _, R = zonal_ang.shape
         N = ang.shape[0]
         gy = gy.contiguous()
-        with torch.cuda.device(gy.device):
+        with _on(gy.device):
             gx = torch.empty((N, Cin), dtype=torch.float32, device=gy.device)
             g_za, g_zm = torch.empty_like(zonal_ang), torch.empty_like(zonal_mag)
             g_ph = torch.empty_like(phase) if ctx.ftype != 0 else None
