@@ -673,3 +673,32 @@ def test_native_graph_build_matches_torch_build(dev, N, k, B, R):
         bad = edges.clone()
         bad[3, 0] = N + 5
         SupportGraph(bad, sten, N, native=True)
+
+
+@pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4)])
+def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
+    """ECHO descriptor kernels against the package's torch composite run on the CPU in float64 (pinned to the reference
+    fixtures by the CPU suite), on supports wide enough that 2 or 4 wavefronts share a vertex, with ragged degrees and
+    zero features."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import ECHO
+    from fieldconv_amd.transforms import FCPrecomp
+    data = sphere_support(N, k, seed=N)
+    edges, _, ln, wxp = FCPrecomp(1, 3, float(data.logMag.max()) * 1.0001)(data)
+    g = torch.Generator().manual_seed(N + C)
+    keep = torch.rand(edges.shape[0], generator=g) > 0.2
+    edges, ln, wxp = edges[keep].contiguous(), ln[keep].contiguous(), wxp[keep].contiguous()
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
+    x[torch.rand(N, C, generator=g) < 0.05] = 0
+    m = ECHO(C, n_bins)
+    xr = x.to(torch.complex128).requires_grad_(True)
+    dr = m(xr, edges, ln.to(torch.complex128) * 0.999, wxp.to(torch.complex128))
+    gd = torch.randn(dr.shape, generator=g)
+    gr, = torch.autograd.grad(dr, [xr], grad_outputs=gd.double())
+    xd = x.to(dev).requires_grad_(True)
+    dd = m.to(dev)(xd, edges.to(dev), (ln * 0.999).to(dev), wxp.to(dev))
+    gg, = torch.autograd.grad(dd, [xd], grad_outputs=gd.to(dev))
+    # votes are piecewise linear in the rotated point (an fp32 floor/ceil flip moves a vanishing vote to the neighbouring
+    # cell); ln is scaled by 0.999 so that no point sits exactly on the raster's rim
+    assert rel_err(H(dd), dr.detach().numpy()) < 5e-6             # measured 1-3e-7
+    assert rel_err(H(gg), gr.numpy()) < 5e-5                      # measured 1-3e-6
