@@ -34,9 +34,10 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
     const float* __restrict__ x, const float2* __restrict__ lsten, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ nbr, const int64_t* __restrict__ perm, const float* __restrict__ zA, const float* __restrict__ zM,
     const float* __restrict__ phase, float2* __restrict__ y, float2* __restrict__ ang_out, float* __restrict__ mag_out,
-    float2* __restrict__ s1sum_out, const TfArgs a) {
+    float2* __restrict__ s1sum_out, const TfArgs a, const int wpv) {
     __shared__ float2 s_ang[kTfWaves][kTfMaxIn * kTfMaxR];
     __shared__ float s_mag[kTfWaves][kTfMaxIn * kTfMaxR];
+    __shared__ float2 s_s1[kTfWaves][kTfMaxIn * kTfMaxR];
     __shared__ float2 s_cs[kWave * kTfMaxIn];              // (cos, sin) of phase[o][i]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -47,15 +48,18 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
         s_cs[idx] = make_float2(c, s);
     }
     __syncthreads();
-    const int n = blockIdx.x * kTfWaves + wave;
-    if (n >= a.N) return;
+    // `wpv` (1, 2 or 4) wavefronts share a vertex, each with every wpv-th in-edge (meshes with few vertices and wide
+    // supports, see fc_echo.hip); their sums are added in wavefront order
+    const int n = (blockIdx.x * kTfWaves + wave) / wpv;
+    const int sub = wave % wpv;
+    const bool active = n < a.N;
     // ---- aggregation: lane = (i, r)
     const int li = lane < IR ? lane / R : 0, lr = lane < IR ? lane - (lane / R) * R : 0;
     float2 ang = make_float2(0.f, 0.f), s1sum = ang;
     float mag = 0.f;
-    const float xd = x[(size_t)n * Cin + li];
-    const int beg = rowptr[n], end = rowptr[n + 1];
-    for (int e = beg; e < end; ++e) {
+    const float xd = active ? x[(size_t)n * Cin + li] : 0.f;
+    const int beg = active ? rowptr[n] : 0, end = active ? rowptr[n + 1] : 0;
+    for (int e = beg + sub; e < end; e += wpv) {
         const int src = nbr[e];
         const int edge = (int)perm[e];
         float2 s0, s1;
@@ -69,6 +73,20 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
         s1sum.y += s1.y;
     }
     ang = make_float2(-ang.x, -ang.y);
+    if (wpv > 1) {
+        if (lane < IR) { s_ang[wave][lane] = ang; s_mag[wave][lane] = mag; s_s1[wave][lane] = s1sum; }
+        __syncthreads();
+        if (sub != 0 || !active) return;
+        if (lane < IR)
+            for (int s = 1; s < wpv; ++s) {
+                const float2 pa = s_ang[wave + s][lane], ps = s_s1[wave + s][lane];
+                ang.x += pa.x; ang.y += pa.y;
+                mag += s_mag[wave + s][lane];
+                s1sum.x += ps.x; s1sum.y += ps.y;
+            }
+    } else if (!active) {
+        return;
+    }
     if (lane < IR) {
         s_ang[wave][lane] = ang;
         s_mag[wave][lane] = mag;
@@ -251,18 +269,19 @@ __global__ __launch_bounds__(kTfReduceWays * kWave) void trans_field_reduce_kern
 __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_input_kernel(
     const float2* __restrict__ lsten, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr,
     const int64_t* __restrict__ perm, const float2* __restrict__ g_ang, const float* __restrict__ g_mag,
-    const float* __restrict__ gx_dst, float* __restrict__ gx, const TfArgs a) {
+    const float* __restrict__ gx_dst, float* __restrict__ gx, const TfArgs a, const int wpv) {
     __shared__ float s_t[kTfWaves][kTfMaxIn * kTfMaxR];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Cin = a.Cin, R = a.R, IR = Cin * R;
-    const int j = blockIdx.x * kTfWaves + wave;
-    if (j >= a.N) return;
+    const int j = (blockIdx.x * kTfWaves + wave) / wpv;
+    const int sub = wave % wpv;
+    const bool active = j < a.N;
     const int lr = lane < IR ? lane - (lane / R) * R : 0;
     const int lc = lane < IR ? lane : 0;
     float acc = 0.f;
-    const int beg = rowptr[j], end = rowptr[j + 1];
-    for (int e = beg; e < end; ++e) {
+    const int beg = active ? rowptr[j] : 0, end = active ? rowptr[j + 1] : 0;
+    for (int e = beg + sub; e < end; e += wpv) {
         const int dst = nbr[e];
         const int edge = (int)perm[e];
         float2 s0, s1;
@@ -272,11 +291,21 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_input_k
         acc += gm * soft_abs(s0) - (ga.x * s1.x + ga.y * s1.y);
     }
     if (lane < IR) s_t[wave][lane] = acc;
+    if (wpv > 1) __syncthreads();
+    if (sub != 0 || !active) return;
     if (lane < Cin) {
         float s = gx_dst[(size_t)j * Cin + lane];
-        for (int r = 0; r < R; ++r) s += s_t[wave][lane * R + r];
+        for (int w = 0; w < wpv; ++w)
+            for (int r = 0; r < R; ++r) s += s_t[wave + w][lane * R + r];
         gx[(size_t)j * Cin + lane] = s;
     }
+}
+
+static int tf_waves_per_vertex(int N, int E) {
+    const long deg = N > 0 ? (long)E / N : 0;
+    if (deg >= 64 && N < 65536) return 4;
+    if (deg >= 32 && N < 131072) return 2;
+    return 1;
 }
 
 static bool tf_supported(int Cin, int O, int R) { return Cin >= 1 && Cin <= kTfMaxIn && R >= 1 && R <= kTfMaxR && O >= 1 && O <= kWave; }
@@ -294,10 +323,11 @@ int fc_trans_field_forward(const float* x, const float* lift_sten, const fc_csr*
     if (!fc::tf_supported(Cin, O, R)) return FC_ERR_UNSUPPORTED;
     if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
     const fc::TfArgs a{N, E, Cin, O, R, 1, sten_stride};
-    hipLaunchKernelGGL(fc::trans_field_forward_kernel, dim3((N + fc::kTfWaves - 1) / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0,
+    const int wpv = fc::tf_waves_per_vertex(N, E), per_wg = fc::kTfWaves / wpv;
+    hipLaunchKernelGGL(fc::trans_field_forward_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kTfWaves * fc::kWave), 0,
                        static_cast<hipStream_t>(stream), x, reinterpret_cast<const float2*>(lift_sten), by_target->rowptr, by_target->nbr,
                        slot_to_edge, zonal_ang, zonal_mag, phase, reinterpret_cast<float2*>(y), reinterpret_cast<float2*>(ang), mag,
-                       reinterpret_cast<float2*>(s1sum), a);
+                       reinterpret_cast<float2*>(s1sum), a, wpv);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -329,16 +359,18 @@ int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, con
     float* partial = gx_dst + (size_t)N * Cin;
     if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
     const fc::TfArgs a{N, E, Cin, O, R, ftype, sten_stride};
-    int waves = (N < fc::kTfGridWaves) ? (N + fc::kTfWaves - 1) / fc::kTfWaves * fc::kTfWaves : fc::kTfGridWaves;
+    // persistent wavefronts = parameter-gradient partials: a quarter of the vertices on small meshes
+    int waves = (N < 4 * fc::kTfGridWaves) ? ((N + 3) / 4 + fc::kTfWaves - 1) / fc::kTfWaves * fc::kTfWaves : fc::kTfGridWaves;
     hipLaunchKernelGGL(fc::trans_field_backward_vertex_kernel, dim3(waves / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0, s,
                        reinterpret_cast<const float2*>(ang), mag, reinterpret_cast<const float2*>(s1sum), zonal_ang, zonal_mag, phase,
                        reinterpret_cast<const float2*>(gy), g_ang, g_mag, gx_dst, partial, a, waves);
     const int total = O * Cin * (2 * R + 1);
     hipLaunchKernelGGL(fc::trans_field_reduce_kernel, dim3((total + fc::kWave - 1) / fc::kWave), dim3(fc::kTfReduceWays * fc::kWave), 0, s, partial, g_zonal_ang, g_zonal_mag,
                        g_phase, waves, O, Cin, R, ftype);
-    hipLaunchKernelGGL(fc::trans_field_backward_input_kernel, dim3((N + fc::kTfWaves - 1) / fc::kTfWaves), dim3(fc::kTfWaves * fc::kWave), 0,
+    const int wpv = fc::tf_waves_per_vertex(N, E), per_wg = fc::kTfWaves / wpv;
+    hipLaunchKernelGGL(fc::trans_field_backward_input_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kTfWaves * fc::kWave), 0,
                        s, reinterpret_cast<const float2*>(lift_sten), by_source->rowptr, by_source->nbr, slot_to_edge_s, g_ang, g_mag,
-                       gx_dst, gx, a);
+                       gx_dst, gx, a, wpv);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -192,7 +192,8 @@ def test_echo_block_and_lift_block_golden(dev):
             assert rel_err(H(gval), c['g_' + name]) < 1e-4, name
 
 
-@pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1)])
+@pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1),
+                                             (100, 80, 3, 48, 6, 1), (90, 40, 2, 16, 4, 1)])      # the last two: 4 / 2 wavefronts per vertex
 def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
     """The TransField kernels against the package's own torch composite run on the CPU in float64 (that composite is
     pinned to the reference fixtures by the CPU suite): ragged in-degrees, isolated vertices, a strided stencil view."""
