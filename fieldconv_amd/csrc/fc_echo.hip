@@ -10,6 +10,7 @@
 namespace fc {
 
 constexpr int kEchoWaves = 4;                 // vertices per workgroup
+constexpr int kEchoAhead = 4;                 // edges whose gathers are in flight together
 constexpr int kEchoMaxBins = 4;               // n_bins <= 4: (2*4+1)^2 = 81 raster cells
 constexpr int kEchoMaxCells = (2 * kEchoMaxBins + 1) * (2 * kEchoMaxBins + 1);
 
@@ -85,20 +86,46 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
     const int beg = active ? rowptr[v] : 0, end = active ? rowptr[v + 1] : 0;
     const int cl = lane < C ? lane : 0;
     float* const row = mine + (size_t)cl * dS * 2;
-    for (int e = beg + sub; e < end; e += wpv) {
-        const int src = nbr[e];
-        const float2 le = ln_t[e], we = wxp_t[e];
-        const float2 xv = x[(size_t)src * C + cl];
-        bool live;
-        const float2 fr = echo_frame(xv, live);
-        const EchoVote vt = echo_rasterize(cmul(le, fr), n);
-        const float2 xw = live ? cmul(xv, we) : make_float2(0.f, 0.f);
-        if (lane < C) {
+    // The per-edge chain (edge -> source row -> vote) is latency bound: the source rows of kEchoAhead edges are
+    // requested together, then consumed.
+    for (int e0 = beg + sub; e0 < end; e0 += kEchoAhead * wpv) {
+        float2 xs[kEchoAhead], les[kEchoAhead], wes[kEchoAhead];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float* cellp = row + 2 * dmap[vt.cell[k]];
-                cellp[0] += xw.x * vt.w[k];          // lane-private row: plain read-modify-write, in program order
-                cellp[1] += xw.y * vt.w[k];
+        for (int u = 0; u < kEchoAhead; ++u) {
+            const int e = min(e0 + u * wpv, end - 1);
+            les[u] = ln_t[e];
+            wes[u] = wxp_t[e];
+            xs[u] = x[(size_t)nbr[e] * C + cl];
+        }
+#pragma unroll
+        for (int u = 0; u < kEchoAhead; ++u) {
+            if (e0 + u * wpv >= end) break;
+            const float2 xv = xs[u];
+            bool live;
+            const float2 fr = echo_frame(xv, live);
+            const EchoVote vt = echo_rasterize(cmul(les[u], fr), n);
+            const float2 xw = live ? cmul(xv, wes[u]) : make_float2(0.f, 0.f);
+            if (lane < C) {
+                // lane-private row, plain read-modify-write.  The four bins are read together, updated and written
+                // together (one LDS round trip instead of four dependent ones).  Votes that fall into the same bin (a
+                // coordinate on a raster line or clamped at the rim) first pool their weights, so every write of a
+                // shared bin carries the full sum.
+                int b[4];
+                float2 h[4];
+                float w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] = dmap[vt.cell[k]];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const float2*>(row + 2 * b[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w[k] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[k] += (b[j] == b[k]) ? vt.w[j] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float2*>(row + 2 * b[k]) = make_float2(h[k].x + xw.x * w[k], h[k].y + xw.y * w[k]);
             }
         }
     }
@@ -157,6 +184,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
     const float2 fr = echo_frame(xv, live);
     float2 gval = make_float2(0.f, 0.f);        // gradient through the vote values
     float2 gframe = make_float2(0.f, 0.f);      // gradient with respect to frame
+    // (bound by the L1 line rate: every edge touches four scattered entries per channel of the target's block)
     for (int e = beg + sub; e < end; e += wpv) {
         const int dst = nbr[e];
         const float2 le = ln_s[e], we = wxp_s[e];
