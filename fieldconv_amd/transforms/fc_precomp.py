@@ -1,4 +1,9 @@
-"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97)."""
+"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97).  Device tensors go through
+the library (csrc/fc_precomp.hip: three launches); the torch code below is what CPU tensors take and what the CPU suite pins
+to the reference fixtures."""
+import ctypes
+import os
+
 import torch
 
 
@@ -50,6 +55,38 @@ class FCPrecomp(object):
         return out
 
     def _compute(self, r, theta, w, supp_edges, xp):
+        if (r.is_cuda and os.environ.get('FIELDCONV_TORCH_PRECOMP', '0') != '1' and r.dtype == torch.float32
+                and theta.dtype == torch.float32 and w.dtype == torch.float32 and xp.dtype == torch.complex64
+                and 2 <= self.R <= 8 and 2 * self.B + 1 <= 7 and r.numel() > 0):
+            return self._compute_native(r, theta, w, supp_edges, xp)
+        return self._compute_torch(r, theta, w, supp_edges, xp)
+
+    def _compute_native(self, r, theta, w, supp_edges, xp):
+        from .. import _lib
+        lib = _lib.load()
+        dev = r.device
+        E, N, R, F = int(r.numel()), int(w.shape[0]), self.R, 2 * self.B + 1
+        r, theta, xp = r.contiguous(), theta.contiguous(), xp.contiguous()
+        wv = w.reshape(-1).contiguous()
+        edges = supp_edges.to(torch.int64).contiguous()
+        eps = float(self.max_r)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            nbytes = lib.fc_precomp_workspace_bytes(N, E)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.fc_precomp_mark(p(r), eps, N, E, p(ws), nbytes, st), 'fc_precomp_mark')
+            off = lib.fc_precomp_kept_count_ptr(p(ws), E) - ws.data_ptr()
+            kept = int(ws[off:off + 4].view(torch.int32).item())          # the one synchronisation (the reference's `nonzero`)
+            edges_out = torch.empty((kept, 2), dtype=torch.int64, device=dev)
+            sten = torch.empty((kept, R, F), dtype=torch.complex64, device=dev)
+            ln = torch.empty(kept, dtype=torch.complex64, device=dev)
+            wxp = torch.empty(kept, dtype=torch.complex64, device=dev)
+            _lib.check(lib.fc_precomp_build(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, R, F, p(edges_out), p(sten), p(ln),
+                                            p(wxp), p(ws), nbytes, st), 'fc_precomp_build')
+        return edges_out.to(supp_edges.dtype), sten, ln, wxp
+
+    def _compute_torch(self, r, theta, w, supp_edges, xp):
         B, R = self.B, self.R
         r = r / self.max_r
         keep = torch.nonzero(r <= 1.0).squeeze(-1)

@@ -206,6 +206,21 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
                    int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t,
                    int32_t* flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- FCPrecomp (stencil assembly), reference transforms/fc_precomp.py:53-97 ------------------------------------------ *
+ * Inputs as the reference's data object holds them: log_mag (E) f32, log_ang (E) f32, xp (E) c64, w (N) f32 (vertex
+ * areas), supp_edges (E,2) int64, epsilon (support radius).  Two steps because the number of kept edges E' (those with
+ * log_mag / epsilon <= 1) sizes the outputs: fc_precomp_mark enqueues the selection; the int32 at
+ * fc_precomp_kept_count_ptr() then holds E' (device memory: the caller's one synchronisation); fc_precomp_build, with the
+ * same workspace, writes supp_edges_out (E',2) int64, supp_sten (E',R,F) c64, ln (E') c64 and wxp (E') c64 in the
+ * original edge order. */
+size_t fc_precomp_workspace_bytes(int32_t N, int32_t E);
+int fc_precomp_mark(const float* log_mag, float epsilon, int32_t N, int32_t E, void* workspace, size_t workspace_bytes,
+                    void* stream);
+const int32_t* fc_precomp_kept_count_ptr(const void* workspace, int32_t E);
+int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
+                     float epsilon, int32_t N, int32_t E, int32_t R, int32_t F, int64_t* supp_edges_out, float* supp_sten,
+                     float* ln, float* wxp, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -703,3 +703,25 @@ def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     # cell); ln is scaled by 0.999 so that no point sits exactly on the raster's rim
     assert rel_err(H(dd), dr.detach().numpy()) < 5e-6             # measured 1-3e-7
     assert rel_err(H(gg), gr.numpy()) < 5e-5                      # measured 1-3e-6
+
+
+@pytest.mark.parametrize('N,k,B,R,shrink', [(300, 20, 2, 6, 1.0), (1024, 128, 2, 6, 0.8), (77, 9, 1, 3, 0.5), (150, 12, 3, 8, 1.0)])
+def test_native_fc_precomp_matches_torch(dev, N, k, B, R, shrink):
+    """fc_precomp_mark / fc_precomp_build (csrc/fc_precomp.hip) against the torch FCPrecomp (pinned to the reference
+    fixtures by the CPU suite) on the same device inputs: the same edges are kept, in the same order, and stencil, ln
+    and wxp agree to fp32 rounding (the area sums are float atomics in both)."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.transforms import FCPrecomp
+    data = sphere_support(N, k, seed=N).to(dev)
+    pre = FCPrecomp(B, R, float(data.logMag.max()) * shrink)             # shrink < 1: part of the edges falls outside the radius
+    args = (data.logMag, data.logAng, data.w, data.supp_edges, data.xp)
+    e1, s1, l1, w1 = pre._compute_native(*args)
+    e2, s2, l2, w2 = pre._compute_torch(*args)
+    assert e1.shape[0] > 0 and (shrink == 1.0 or e1.shape[0] < data.supp_edges.shape[0])
+    assert torch.equal(e1, e2) and e1.dtype == e2.dtype
+    assert s1.shape == s2.shape and s1.dtype == s2.dtype
+    assert rel_err(H(s1), H(s2)) < 2e-6 and rel_err(H(l1), H(l2)) < 2e-6 and rel_err(H(w1), H(w2)) < 2e-6
+    # the same two rings carry the weight (torch divides by epsilon through its reciprocal, the kernel divides: an edge
+    # within one ulp of a knot may get a 1e-7 weight on the neighbouring ring in one of the two)
+    tiny = 1e-5 * float(s2.abs().max())
+    assert torch.equal(s1.abs() > tiny, s2.abs() > tiny)
