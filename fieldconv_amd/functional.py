@@ -434,10 +434,12 @@ def echo_descriptors(x, supp_edges, ln, wxp, n_bins):
     _require_device(x, 'echo_descriptors')
     if x.dtype != torch.complex64 or x.dim() != 2:
         raise ValueError('echo_descriptors expects complex64 features of shape (N, C)')
-    if x.shape[1] > 64:
-        raise ValueError('echo_descriptors supports at most 64 channels')
     from .graph import get_edge_csr
-    return _EchoFn.apply(x, ln, wxp, get_edge_csr(supp_edges, x.shape[0]), int(n_bins))
+    csr = get_edge_csr(supp_edges, x.shape[0])
+    if x.shape[1] > MAX_CHANNELS:          # the channels are independent: blocks of 64 (one channel per lane)
+        return torch.cat([_EchoFn.apply(x[:, c0:c0 + MAX_CHANNELS], ln, wxp, csr, int(n_bins))
+                          for c0 in range(0, x.shape[1], MAX_CHANNELS)], dim=1)
+    return _EchoFn.apply(x, ln, wxp, csr, int(n_bins))
 
 
 class _TransFieldFn(torch.autograd.Function):
@@ -503,7 +505,12 @@ def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
     O, Cin, R = zonal_ang.shape
     if x.shape[1] != Cin or lift_sten.shape[1] != R or lift_sten.shape[2] != 2:
         raise ValueError('trans_field: feature / stencil shapes do not match the zonal filters')
-    if Cin > 4 or R > 8 or O > 64:
-        raise ValueError('trans_field supports Cin <= 4, n_rings <= 8, out_channels <= 64')
+    if Cin > 4 or R > 8:
+        raise ValueError('trans_field supports at most 4 scalar input channels and 8 rings')
     from .graph import get_edge_csr
-    return _TransFieldFn.apply(x, lift_sten, zonal_ang, zonal_mag, phase, get_edge_csr(supp_edges, x.shape[0]), int(ftype))
+    csr = get_edge_csr(supp_edges, x.shape[0])
+    if O > MAX_CHANNELS:                   # the output channels are independent: blocks of 64 (one per lane)
+        return torch.cat([_TransFieldFn.apply(x, lift_sten, zonal_ang[o0:o0 + MAX_CHANNELS], zonal_mag[o0:o0 + MAX_CHANNELS],
+                                              phase[o0:o0 + MAX_CHANNELS], csr, int(ftype))
+                          for o0 in range(0, O, MAX_CHANNELS)], dim=1)
+    return _TransFieldFn.apply(x, lift_sten, zonal_ang, zonal_mag, phase, csr, int(ftype))

@@ -193,7 +193,8 @@ def test_echo_block_and_lift_block_golden(dev):
 
 
 @pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1),
-                                             (100, 80, 3, 48, 6, 1), (90, 40, 2, 16, 4, 1)])      # the last two: 4 / 2 wavefronts per vertex
+                                             (100, 80, 3, 48, 6, 1), (90, 40, 2, 16, 4, 1),      # 4 / 2 wavefronts per vertex
+                                             (120, 7, 3, 150, 6, 1)])                             # output channels in blocks of 64
 def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
     """The TransField kernels against the package's own torch composite run on the CPU in float64 (that composite is
     pinned to the reference fixtures by the CPU suite): ragged in-degrees, isolated vertices, a strided stencil view."""
@@ -676,7 +677,7 @@ def test_native_graph_build_matches_torch_build(dev, N, k, B, R):
         SupportGraph(bad, sten, N, native=True)
 
 
-@pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4)])
+@pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4), (60, 10, 130, 2)])
 def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     """ECHO descriptor kernels against the package's torch composite run on the CPU in float64 (pinned to the reference
     fixtures by the CPU suite), on supports wide enough that 2 or 4 wavefronts share a vertex, with ragged degrees and
