@@ -100,6 +100,45 @@ def geometric_phases(rec, F, tol=2e-6):
     return geo
 
 
+def _native_build(supp_edges, sten, N, R, F, want_rec, want_geo):
+    """fc_graph_build (csrc/fc_graph.hip) on device tensors: both edge groupings, ring-run offsets, slot -> edge
+    permutations and -- with a stencil -- the factored / geometric records, plus the verdict flags (the one host
+    synchronisation).  Returns a dict of tensors and 'flags' (int)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev, E = supp_edges.device, int(supp_edges.shape[0])
+    edges = supp_edges.to(torch.int64).contiguous()
+    recf = (4 + 2 * F + 3) // 4 * 4
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = {}
+    with torch.cuda.device(dev):
+        for side in ('t', 's'):
+            out['rowptr_' + side] = torch.empty(N + 1, **i32)
+            out['nbr_' + side] = torch.empty(E, **i32)
+            out['runs_' + side] = torch.empty((N, 8), **i32)
+            out['perm_' + side] = torch.empty(E, dtype=torch.int64, device=dev)
+        out['rec_t'] = out['rec_s'] = out['geo_t'] = None
+        if want_rec:            # zeroed: the kernels stream up to 1 KiB past the last record
+            out['rec_t'] = torch.zeros((E + 1024 // (recf * 4) + 16, recf), dtype=torch.float32, device=dev)
+            out['rec_s'] = torch.zeros_like(out['rec_t'])
+            if want_geo:
+                out['geo_t'] = torch.zeros((E + 1024 // 32 + 16, 8), dtype=torch.float32, device=dev)
+        flags = torch.empty(1, **i32)
+        nbytes = lib.fc_graph_workspace_bytes(N, E, R, F, 1 if want_rec else 0)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(lib.fc_graph_build(p(edges), p(sten) if want_rec else None, N, E, R, F, p(out['rowptr_t']), p(out['nbr_t']),
+                                      p(out['runs_t']), p(out['perm_t']), p(out['rowptr_s']), p(out['nbr_s']), p(out['runs_s']),
+                                      p(out['perm_s']), p(out['rec_t']), p(out['rec_s']), p(out['geo_t']), p(flags), p(ws), nbytes,
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'fc_graph_build')
+        out['flags'] = int(flags.item())
+    if out['flags'] & 4:
+        raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+    return out
+
+
+
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
                  'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans')
@@ -194,47 +233,16 @@ class SupportGraph:
                 self.sten_s = sten if by_source else sten.index_select(0, perm_s)
 
     def _build_native(self, supp_edges, sten, allow_factored):
-        """csrc/fc_graph.hip: everything above in ~12 launches.  The factored / geometric verdicts come back in one
-        flags word (the one host synchronisation of the build)."""
-        import ctypes
-        from . import _lib
-        lib = _lib.load()
-        dev, N, E, R, F = sten.device, self.N, self.E, self.R, self.F
-        edges = supp_edges.to(torch.int64).contiguous()
+        """csrc/fc_graph.hip: everything the torch code above does, in ~12 launches."""
         want_rec = allow_factored and os.environ.get('FIELDCONV_DENSE', '0') != '1'
-        want_geo = want_rec and os.environ.get('FIELDCONV_NO_GEO', '0') != '1' and F >= 3
-        recf = (4 + 2 * F + 3) // 4 * 4
-        i32 = dict(dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            self.rowptr_t = torch.empty(N + 1, **i32)
-            self.rowptr_s = torch.empty(N + 1, **i32)
-            self.nbr_t = torch.empty(E, **i32)
-            self.nbr_s = torch.empty(E, **i32)
-            runs_t = torch.empty((N, 8), **i32)
-            runs_s = torch.empty((N, 8), **i32)
-            self.perm_t = torch.empty(E, dtype=torch.int64, device=dev)
-            self.perm_s = torch.empty(E, dtype=torch.int64, device=dev)
-            rec_t = rec_s = geo_t = None
-            if want_rec:        # zeroed: the kernels stream up to 1 KiB past the last record
-                rec_t = torch.zeros((E + 1024 // (recf * 4) + 16, recf), dtype=torch.float32, device=dev)
-                rec_s = torch.zeros_like(rec_t)
-                if want_geo:
-                    geo_t = torch.zeros((E + 1024 // 32 + 16, 8), dtype=torch.float32, device=dev)
-            flags = torch.empty(1, **i32)
-            nbytes = lib.fc_graph_workspace_bytes(N, E, R, F, 1 if want_rec else 0)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-            _lib.check(lib.fc_graph_build(p(edges), p(sten) if want_rec else None, N, E, R, F, p(self.rowptr_t), p(self.nbr_t),
-                                          p(runs_t), p(self.perm_t), p(self.rowptr_s), p(self.nbr_s), p(runs_s), p(self.perm_s),
-                                          p(rec_t), p(rec_s), p(geo_t), p(flags), p(ws), nbytes,
-                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'fc_graph_build')
-            verdict = int(flags.item())
-        if verdict & 4:
-            raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
-        if want_rec and not (verdict & 1):
+        want_geo = want_rec and os.environ.get('FIELDCONV_NO_GEO', '0') != '1' and self.F >= 3
+        g = _native_build(supp_edges, sten, self.N, self.R, self.F, want_rec, want_geo)
+        for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s'):
+            setattr(self, name, g[name])
+        if want_rec and not (g['flags'] & 1):
             self.factored = True
-            self.rec_t, self.rec_s, self.runs_t, self.runs_s = rec_t, rec_s, runs_t, runs_s
-            self.geo_t = geo_t if (want_geo and not (verdict & 2)) else None
+            self.rec_t, self.rec_s, self.runs_t, self.runs_s = g['rec_t'], g['rec_s'], g['runs_t'], g['runs_s']
+            self.geo_t = g['geo_t'] if (want_geo and not (g['flags'] & 2)) else None
         else:                   # dense kernels: stencil rows in slot order (any order inside a vertex is fine)
             self.sten_t = sten.index_select(0, self.perm_t)
             self.sten_s = sten.index_select(0, self.perm_s)
@@ -296,28 +304,9 @@ class EdgeCSR:
 
     def _native(self, supp_edges):
         """edge grouping only (fc_graph_build without a stencil)"""
-        import ctypes
-        from . import _lib
-        lib = _lib.load()
-        dev, N, E = supp_edges.device, self.N, self.E
-        edges = supp_edges.to(torch.int64).contiguous()
-        i32 = dict(dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            self.rowptr_t, self.rowptr_s = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
-            self.nbr_t, self.nbr_s = torch.empty(E, **i32), torch.empty(E, **i32)
-            runs_t, runs_s = torch.empty((N, 8), **i32), torch.empty((N, 8), **i32)
-            self.perm_t = torch.empty(E, dtype=torch.int64, device=dev)
-            self.perm_s = torch.empty(E, dtype=torch.int64, device=dev)
-            flags = torch.empty(1, **i32)
-            nbytes = lib.fc_graph_workspace_bytes(N, E, 2, 1, 0)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-            _lib.check(lib.fc_graph_build(p(edges), None, N, E, 2, 1, p(self.rowptr_t), p(self.nbr_t), p(runs_t), p(self.perm_t),
-                                          p(self.rowptr_s), p(self.nbr_s), p(runs_s), p(self.perm_s), None, None, None, p(flags),
-                                          p(ws), nbytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                       'fc_graph_build')
-            if int(flags.item()) & 4:
-                raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+        g = _native_build(supp_edges, None, self.N, 2, 1, False, False)
+        for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s'):
+            setattr(self, name, g[name])
 
     @classmethod
     def from_support_graph(cls, sg, supp_edges):
