@@ -6,3 +6,4 @@ mirrors `from nn import ...` of the reference (reference nn/__init__.py:1-12).
 __version__ = '0.1.0'
 
 from . import nn, transforms, utils  # noqa: F401,E402
+from . import optim  # noqa: F401,E402

@@ -503,8 +503,10 @@ def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
     if x.dtype != torch.float32 or x.dim() != 2 or lift_sten.dtype != torch.complex64:
         raise ValueError('trans_field expects float32 features (N, Cin) and a complex64 stencil (E, R, 2)')
     O, Cin, R = zonal_ang.shape
-    if x.shape[1] != Cin or lift_sten.shape[1] != R or lift_sten.shape[2] != 2:
+    if x.shape[1] != Cin or lift_sten.dim() != 3 or lift_sten.shape[1] != R or lift_sten.shape[2] < 2:
         raise ValueError('trans_field: feature / stencil shapes do not match the zonal filters')
+    if lift_sten.shape[2] > 2:          # the reference reads columns 0 and 1 of whatever it is given (classification.ipynb:195
+        lift_sten = lift_sten[..., :2]  # passes the full stencil); a strided view, read in place
     if Cin > 4 or R > 8:
         raise ValueError('trans_field supports at most 4 scalar input channels and 8 rings')
     from .graph import get_edge_csr

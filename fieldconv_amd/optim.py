@@ -1,0 +1,66 @@
+"""Fused Adam for the networks built from this package.
+
+All parameters live in one flat float32 buffer (each `p.data` becomes a view of it, each `p.grad` a view of one flat
+gradient buffer), so that an optimizer step is one elementwise HIP kernel (csrc/fc_optim.hip through fc_adam_step) and
+`zero_grad` one fill.  The step counter lives on the device: the update is capturable in a HIP graph together with the
+forward and backward passes (fieldconv_amd.utils.StepGraph).  Arithmetic of torch.optim.Adam (L2 weight decay, no amsgrad).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = [p for p in params]
+        if not params:
+            raise ValueError('FusedAdam needs at least one parameter')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedAdam keeps one flat buffer: one parameter group')
+        ps = self.param_groups[0]['params']
+        dev = ps[0].device
+        for p in ps:
+            if p.dtype != torch.float32 or p.device != dev or not p.is_cuda:
+                raise ValueError('FusedAdam: float32 parameters on one ROCm device (complex filters are stored as real pairs '
+                                 'by the modules of this package)')
+        sizes = [p.numel() for p in ps]
+        offs, total = [], 0
+        for n in sizes:                     # every tensor starts on a 16-byte boundary
+            offs.append(total)
+            total += (n + 3) // 4 * 4
+        self._n = total
+        self._flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, n in zip(ps, offs, sizes):
+                view = self._flat[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self._grad[o:o + n].view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        """One fill; the gradient views stay in place (set_to_none would detach them from the flat buffer)."""
+        self._grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        for p in g['params']:               # autograd must have accumulated into the views, not replaced them
+            if p.grad is None or p.grad.data_ptr() < self._grad.data_ptr() or p.grad.data_ptr() >= self._grad.data_ptr() + 4 * self._n:
+                raise RuntimeError('FusedAdam: a parameter\'s .grad no longer points into the flat gradient buffer '
+                                   '(use optimizer.zero_grad(), not set_to_none)')
+        lib = _lib.load()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(self._flat.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.fc_adam_step(p(self._flat), p(self._grad), p(self._m), p(self._v), p(self._step), self._n, float(g['lr']),
+                                        float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), st),
+                       'fc_adam_step')
+        return loss

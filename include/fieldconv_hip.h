@@ -221,6 +221,12 @@ int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp
                      float epsilon, int32_t N, int32_t E, int32_t R, int32_t F, int64_t* supp_edges_out, float* supp_sten,
                      float* ln, float* wxp, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused Adam over a flat float32 parameter buffer (torch.optim.Adam arithmetic, L2 weight decay, no amsgrad) -------- *
+ * params, grads, exp_avg, exp_avg_sq: n floats each, n a multiple of 4, 16-byte aligned; step: one device float holding
+ * the number of steps taken so far (incremented on the device, so the call is capturable in a HIP graph). */
+int fc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step, size_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

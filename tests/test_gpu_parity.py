@@ -219,6 +219,8 @@ def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
     m = m.to(dev)
     xd = x.to(dev).requires_grad_(True)
     yd = m(xd, edges.to(dev), full.to(dev)[..., 2:4])
+    # the full stencil in place of the two-column slice: columns 0 and 1 are used (reference classification.ipynb:195)
+    assert torch.equal(m(xd, edges.to(dev), full.to(dev)[..., 2:]), yd)
     gd = torch.autograd.grad(yd, [xd] + list(m.parameters()), grad_outputs=gy.to(dev))
     assert rel_err(H(yd), yr.detach().numpy()) < 5 * TOL
     for a, b in zip(gd, gr):
@@ -726,3 +728,46 @@ def test_native_fc_precomp_matches_torch(dev, N, k, B, R, shrink):
     # within one ulp of a knot may get a 1e-7 weight on the neighbouring ring in one of the two)
     tiny = 1e-5 * float(s2.abs().max())
     assert torch.equal(s1.abs() > tiny, s2.abs() > tiny)
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """FusedAdam (one flat buffer, fc_adam_step) against torch.optim.Adam on the same block over several steps, with
+    weight decay; also as part of a captured HIP graph (device-side step counter)."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import FCResNetBlock
+    from fieldconv_amd.optim import FusedAdam
+    from fieldconv_amd.transforms import FCPrecomp
+    from fieldconv_amd.utils import StepGraph
+    import copy
+    N, k, C, B, R = 200, 12, 8, 1, 4
+    data = sphere_support(N, k).to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
+    ma = FCResNetBlock(C, C, band_limit=B, n_rings=R).to(dev)
+    mb = copy.deepcopy(ma)
+    mc = copy.deepcopy(ma)
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    oa = torch.optim.Adam(ma.parameters(), **kw)
+    ob = FusedAdam(mb.parameters(), **kw)
+    oc = FusedAdam(mc.parameters(), **kw)
+
+    def train_step(m, o):
+        o.zero_grad()
+        loss = m(x, edges, sten).abs().square().mean()
+        loss.backward()
+        o.step()
+        return loss.detach()
+    graphed = StepGraph(lambda: train_step(mc, oc), warmup=2)         # 2 warm-up steps are taken; the capture only records
+    for _ in range(2):
+        la = train_step(ma, oa)
+        lb = train_step(mb, ob)
+    for _ in range(4):
+        la = train_step(ma, oa)
+        lb = train_step(mb, ob)
+        lc = graphed.replay().clone()
+    assert abs(float(la) - float(lb)) < 1e-5 * abs(float(la)) and abs(float(la) - float(lc)) < 1e-5 * abs(float(la))
+    for (name, pa), pb, pc in zip(ma.named_parameters(), mb.parameters(), mc.parameters()):
+        assert rel_err(H(pb), H(pa)) < 2e-5, name
+        assert rel_err(H(pc), H(pa)) < 2e-5, name

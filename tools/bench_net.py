@@ -26,6 +26,16 @@ pos = torch.randn(N, 3, generator=g).to(dev)
 labels = torch.randint(0, n_classes, (N,), generator=g).to(dev)
 
 
+OPT = os.environ.get('OPT', '0') in ('1', 'fused')            # 1: torch.optim.Adam (capturable), fused: fieldconv_amd.optim.FusedAdam
+if os.environ.get('OPT') == 'fused':
+    from fieldconv_amd.optim import FusedAdam
+    opt = FusedAdam(params, lr=1e-3)
+elif OPT:
+    opt = torch.optim.Adam(params, lr=1e-3, capturable=True, foreach=True)
+    for p_ in params:
+        p_.grad = torch.zeros_like(p_)
+
+
 def step():
     edges, sten, ln, wxp = pre(data)                       # runs every forward in the reference, too
     x = mods['lift'](pos, edges, sten[..., B:B + 2])
@@ -33,6 +43,11 @@ def step():
         x = mods[name](x, edges, sten)
     logits = mods['echo'](x, edges, sten, ln, wxp)
     loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
+    if OPT:                                             # a complete training step: gradients into .grad, Adam update
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return (loss.detach(),)
     return (loss,) + torch.autograd.grad(loss, params)
 
 
@@ -41,8 +56,9 @@ if os.environ.get('GRAPH', '0') == '1':             # the whole step as one HIP 
     eager = [t.detach().clone() for t in step()]
     graphed = StepGraph(step)
     step = graphed.replay
-    same = all(torch.equal(a, b) for a, b in zip(eager, step()))
-    print('hipGraph replay bit-identical to eager:', same)
+    if not OPT:             # (with the optimizer in the graph every replay starts from different parameters)
+        same = all(torch.equal(a, b) for a, b in zip(eager, step()))
+        print('hipGraph replay bit-identical to eager:', same)
 for _ in range(10):
     step()
 torch.cuda.synchronize()
