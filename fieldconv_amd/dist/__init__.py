@@ -1,3 +1,3 @@
-from .halo import HaloPlan, halo_exchange
+from .halo import HaloPlan, halo_exchange, overlap_backward
 
-__all__ = ['HaloPlan', 'halo_exchange']
+__all__ = ['HaloPlan', 'halo_exchange', 'overlap_backward']

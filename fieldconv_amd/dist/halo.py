@@ -42,6 +42,7 @@ class HaloPlan:
         self.send_idx = (asked - lo).contiguous()              # local owned rows to ship, grouped by peer
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_owned):
             raise ValueError('a peer asked for a vertex this rank does not own')
+        self._early = {}           # gradient exchanges started by overlap_backward's hook: data_ptr -> (work, send, recv)
 
 
 class _HaloExchange(torch.autograd.Function):
@@ -57,16 +58,24 @@ class _HaloExchange(torch.autograd.Function):
     def backward(ctx, g_local):
         plan = ctx.plan
         g_owned = g_local[: plan.n_owned].clone()
-        send = g_local[plan.n_owned:].contiguous()
-        recv = torch.empty((plan.send_idx.numel(),) + tuple(g_local.shape[1:]), dtype=g_local.dtype, device=g_local.device)
-        _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group)
+        early = plan._early.pop(g_local.data_ptr(), None)
+        plan._early.clear()
+        if early is not None and early[2].shape[1:] == g_local.shape[1:]:
+            work, _, recv = early                       # started between the convolution's two backward kernels
+            if work is not None:
+                work.wait()
+        else:
+            send = g_local[plan.n_owned:].contiguous()
+            recv = torch.empty((plan.send_idx.numel(),) + tuple(g_local.shape[1:]), dtype=g_local.dtype, device=g_local.device)
+            _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group)
         g_owned.index_add_(0, plan.send_idx, recv)
         return g_owned, None
 
 
-def _all_to_all(recv, send, recv_counts, send_counts, group):
+def _all_to_all(recv, send, recv_counts, send_counts, group, async_op=False):
     """all_to_all_single; device tensors are staged through the host when the group's backend is gloo (used to
-    run several ranks on ONE GPU in tests -- RCCL refuses two ranks per device; production runs use "nccl")."""
+    run several ranks on ONE GPU in tests -- RCCL refuses two ranks per device; production runs use "nccl").
+    async_op: returns the Work handle (None on the host-staged path, which completes here)."""
     kw = {}
     if recv_counts is not None:
         kw = dict(output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
@@ -74,14 +83,31 @@ def _all_to_all(recv, send, recv_counts, send_counts, group):
         r = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(r, send.cpu(), group=group, **kw)
         recv.copy_(r)
-    else:
-        dist.all_to_all_single(recv, send, group=group, **kw)
+        return None
+    return dist.all_to_all_single(recv, send, group=group, async_op=async_op, **kw)
 
 
-def _a2a(recv, send, recv_counts, send_counts, group):
+def _a2a(recv, send, recv_counts, send_counts, group, async_op=False):
     r = torch.view_as_real(recv) if recv.is_complex() else recv
     s = torch.view_as_real(send) if send.is_complex() else send
-    _all_to_all(r, s, recv_counts, send_counts, group)
+    return _all_to_all(r, s, recv_counts, send_counts, group, async_op=async_op)
+
+
+def overlap_backward(graph, plan):
+    """Hide the gradient halo exchange under the filter-gradient kernel.  The backward pass of a convolution is two
+    kernels: the first completes gx (including the rows of the halo vertices, which belong to their owners), the second
+    only reads the slabs the first left behind.  With this hook on the mesh's SupportGraph the transposed exchange of
+    the halo rows is enqueued between the two (asynchronously, on RCCL's stream) and halo_exchange's backward node later
+    only waits for it.  Per mesh, after get_graph(...) and HaloPlan(...)."""
+    def on_gx(gx):
+        if gx.shape[0] != plan.n_owned + plan.n_halo:
+            return
+        send = gx[plan.n_owned:]                                   # contiguous rows of a contiguous tensor
+        recv = torch.empty((plan.send_idx.numel(),) + tuple(gx.shape[1:]), dtype=gx.dtype, device=gx.device)
+        work = _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group, async_op=True)
+        plan._early.clear()
+        plan._early[gx.data_ptr()] = (work, send, recv)
+    graph.on_gx = on_gx
 
 
 def halo_exchange(x_owned, plan):

@@ -212,6 +212,8 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
     wsp = _p(ws)
     with _timed('fc_backward_data'):
         check(fn(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_data')
+    if graph.on_gx is not None:         # gx is complete (in stream order): a partitioned mesh starts returning its halo rows
+        graph.on_gx(gx)                 # now, under the filter-gradient kernel
     with _timed('fc_backward_filter'):
         check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, st), 'fc_backward_filter')
     check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, st), 'fc_backward_finish')

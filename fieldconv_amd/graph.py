@@ -141,7 +141,7 @@ def _native_build(supp_edges, sten, N, R, F, want_rec, want_geo):
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -181,6 +181,7 @@ class SupportGraph:
         self.rec_t = self.rec_s = self.sten_t = self.sten_s = self.runs_t = self.runs_s = self.geo_t = None
         self.perm_t = self.perm_s = None
         self._plans = {}           # launch plans per (in, out, band limit): functional._conv_plan
+        self.on_gx = None          # optional callback(gx) between the data and filter kernels of a backward pass (dist/halo.py)
         if native is None:
             native = sten.is_cuda and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1'
         if native and E > 0 and 2 <= self.R <= 8 and self.F <= 7 and self.F % 2 == 1:

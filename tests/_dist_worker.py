@@ -62,6 +62,9 @@ def main():
         from fieldconv_amd.graph import SupportGraph
         Wd = W.detach().to(dev).requires_grad_(True)
         graph = SupportGraph(edges.to(dev), sten.to(dev), x_local.shape[0])
+        if os.environ.get('FC_DIST_OVERLAP', '1') == '1':
+            from fieldconv_amd.dist import overlap_backward
+            overlap_backward(graph, plan)           # the gradient exchange starts inside the convolution's backward pass
         y_owned = field_conv(x_local, Wd, graph)[:n_owned]
         gx, gW = torch.autograd.grad(y_owned, [x_owned, Wd], grad_outputs=gy_all[lo:lo + n_owned].to(dev))
         y_owned, gx, gW = y_owned.cpu(), gx.cpu(), gW.cpu()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Host enqueue time vs wall time of the partitioned step with a single rank (RCCL path, empty halo): is the multi-GPU
+step bound by the host's launch rate?   BENCH_FORCE_DIST-style set-up without the bench's reporting."""
+import os
+import sys
+import time
+import torch
+import torch.distributed as dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29533')
+os.environ.setdefault('RANK', '0')
+os.environ.setdefault('WORLD_SIZE', '1')
+from fieldconv_amd.data import sphere_partition
+from fieldconv_amd.dist import HaloPlan, halo_exchange, overlap_backward
+from fieldconv_amd.graph import get_graph
+from fieldconv_amd.nn import FieldConv
+from fieldconv_amd.transforms import FCPrecomp
+
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=dev)
+B, R, C, k, n = 2, 6, 48, 32, 20000
+data, n_owned, halo_global, bounds = sphere_partition(n, 1, 0, k=k, seed=0)
+data = data.to(dev)
+edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+plan = HaloPlan(n_owned, halo_global, bounds, device=dev)
+conv = FieldConv(C, C, band_limit=B, n_rings=R).to(dev)
+params = list(conv.parameters())
+g = torch.Generator().manual_seed(1)
+x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev).requires_grad_(True)
+gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
+overlap_backward(get_graph(edges, sten, data.num_nodes), plan)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'dist'
+
+
+def step():
+    xl = halo_exchange(x, plan) if mode != 'plain' else x
+    y = conv(xl, edges, sten)[:n_owned]
+    grads = torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+    if mode != 'plain':
+        flat = torch.cat([t.reshape(-1) for t in grads[1:]])
+        dist.all_reduce(flat)
+    return grads
+
+
+for _ in range(30):
+    step()
+torch.cuda.synchronize()
+n_steps = 200
+t0 = time.perf_counter()
+for _ in range(n_steps):
+    step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'{mode}: host enqueue {(t1 - t0) / n_steps * 1e6:.0f} us/step, wall {(t2 - t0) / n_steps * 1e6:.0f} us/step')
+dist.destroy_process_group()
