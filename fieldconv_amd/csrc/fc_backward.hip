@@ -317,6 +317,181 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
     }
 }
 
+template <int T>
+__global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
+    const float2* __restrict__ gx_, const float* __restrict__ hdump, float2* __restrict__ ggwp /* [P][F][KP][IP] */,
+    const BwdArgs a, const int F, const int B, const int KV /* valid k entries, R*O */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MmaGeom& mg = a.g;
+    const int KD = a.KD, KP = mg.KP, IP = mg.MP, I = a.I;
+    const int KSI = filter_image_stride(KP);
+    const int xplane = IP * kXbStride;
+    // Two images and two second-operand blocks: the rows of slab t+1 are converted (straight from registers, loaded from
+    // memory one slab ahead) while slower wavefronts still run the MFMAs of slab t -- one barrier per slab, no fp32 copy
+    // of H in LDS.
+    lds_f16* const img0 = (lds_f16*)smem;                              // [2][16 vertices][re_hi, re_lo, im_hi, im_lo][KP] halves, row stride KSI
+    lds_f16* const xb0 = img0 + 2 * kTile * KSI;                       // [2][c_hi, c_lo, d_hi, d_lo, -d_hi, -d_lo][IP][kXbStride] halves
+    lds_f16* const zeros = xb0 + 2 * 6 * IP * kXbStride;               // 16 bytes of zeros: the lower half of the [lo; 0] fragments
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y;
+    const int m = f - B;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int idx = tid; idx < (2 * kTile * KSI + 2 * 6 * xplane) / 2 + 4; idx += kThreads) reinterpret_cast<float*>(smem)[idx] = 0.f;
+    __syncthreads();
+
+    // my gW tiles all lie in ONE column tile (i0 = 16 * (wave % NMT)), so the second-operand fragments are read once per
+    // tile; the row tiles of that column are dealt round-robin to the wavefronts that share it
+    const int my_ct = wave % mg.NMT, my_idx = wave / mg.NMT;
+    const int ct_waves = (kWaves - my_ct + mg.NMT - 1) / mg.NMT;
+    const int i0 = my_ct * 16;
+    int gw_h[T];                // first k of my row tiles; -1: unused slot
+#pragma unroll
+    for (int n = 0; n < T; ++n) {
+        const int rt = my_idx + n * ct_waves;
+        gw_h[n] = (rt * 16 < KP) ? rt * 16 : -1;
+    }
+    // The MFMA's 32 k entries are the 16 vertices' hi halves followed by their lo halves (first operand) against
+    // [hi; hi] and [lo; 0] of the second: (A_hi | A_lo)(B_hi; B_hi) + (A_hi | A_lo)(B_lo; 0) = hi*hi + lo*hi + hi*lo, two
+    // full-rate v_mfma_f32_16x16x32_f16 per real product.  Lane groups 0/1 carry vertices 0-7 / 8-15 of the hi planes,
+    // groups 2/3 the same vertices of the lo planes.
+    // A fragment: lane 4q+p of a lane group addresses vertex (vb + q), entries k0+4p .. +3 of its plane, and receives entry
+    // k0 + lane%16 of the vertices vb .. vb+3; two reads (vb = 8*(g&1), +4) make the group's eight k entries.
+    const int a_lane = (8 * (fq & 1) + ((lane & 15) >> 2)) * KSI + 4 * (lane & 3) + (fq >= 2 ? KP : 0);
+    const int b_lane = fr * kXbStride + 8 * (fq & 1);    // B fragment: plane[i = i0 + fr][vertices 8*(g&1) .. +7]
+    const bool upper = fq >= 2;
+
+    f32x4 gre[T], gim[T];
+#pragma unroll
+    for (int n = 0; n < T; ++n) { gre[n] = f32x4{0.f, 0.f, 0.f, 0.f}; gim[n] = gre[n]; }
+
+    const int nchunk = KP / 4;                     // chunks of four k entries; a lane holds chunks lane and lane + 64 of its vertex's row
+    // registers one slab ahead: my vertex's row of H (fp32) and the scales behind the slab
+    float4 pv[2][2];
+    float ps = 1.f, pinv = 1.f, pt = 1.f, pit = 1.f;
+    float2 xv = make_float2(0.f, 0.f);
+    auto prefetch = [&](const int tile) {
+        const float* sl = hdump + ((size_t)tile * F + f) * a.slab_stride;
+        const float* row = sl + wave * KD;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = lane + 64 * cc;
+            if (c < nchunk) {
+                pv[cc][0] = *reinterpret_cast<const float4*>(row + 8 * c);          // (re, im) of k = 4c, 4c+1
+                pv[cc][1] = *reinterpret_cast<const float4*>(row + 8 * c + 4);      // k = 4c+2, 4c+3
+            }
+        }
+        const float* tail = sl + a.slab_floats;             // [16] s_v, [16] 1/s_v, [IP] t, [IP] 1/t
+        ps = tail[wave];
+        pinv = tail[kTile + wave];
+        pt = lane < IP ? tail[2 * kTile + lane] : 1.f;
+        pit = tail[2 * kTile + IP + i0 + fr];
+        const int j = (tile >> a.parts_log2) * kTile + wave;
+        xv = (j < a.N && lane < I) ? gx_[(size_t)j * I + lane] : make_float2(0.f, 0.f);
+    };
+    if (blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        lds_f16* const img = img0 + buf * kTile * KSI;
+        lds_f16* const xb = xb0 + buf * 6 * xplane;
+        const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));     // rotated feature of my source row
+        const float it = pit;
+        {   // ---- my vertex's row of H: scale, split, store plane-major
+            const float s = ps;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c < nchunk) {
+                    float4 v0 = pv[cc][0], v1 = pv[cc][1];
+                    // entries past the R*O valid ones were never written by the data kernel
+                    if (4 * c + 0 >= KV) { v0.x = 0.f; v0.y = 0.f; }
+                    if (4 * c + 1 >= KV) { v0.z = 0.f; v0.w = 0.f; }
+                    if (4 * c + 2 >= KV) { v1.x = 0.f; v1.y = 0.f; }
+                    if (4 * c + 3 >= KV) { v1.z = 0.f; v1.w = 0.f; }
+                    f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+                    split_halves2(f32x2{v0.x, v0.y}, s, h0, l0);
+                    split_halves2(f32x2{v0.z, v0.w}, s, h1, l1);
+                    split_halves2(f32x2{v1.x, v1.y}, s, h2, l2);
+                    split_halves2(f32x2{v1.z, v1.w}, s, h3, l3);
+                    lds_f16* p = img + wave * KSI + 4 * c;
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) h4 lds_h4;
+                    *(lds_h4*)(p) = h4{h0.x, h1.x, h2.x, h3.x};                 // re_hi
+                    *(lds_h4*)(p + KP) = h4{l0.x, l1.x, l2.x, l3.x};            // re_lo
+                    *(lds_h4*)(p + 2 * KP) = h4{h0.y, h1.y, h2.y, h3.y};        // im_hi
+                    *(lds_h4*)(p + 3 * KP) = h4{l0.y, l1.y, l2.y, l3.y};        // im_lo
+                }
+            }
+        }
+        if (lane < IP) {   // ---- second operand: xt / s_v * t[i], halves, planes [i][vertex]
+            f16x2 hi, lo;
+            split_halves2(f32x2{xt.x, xt.y}, pinv * pt, hi, lo);
+            lds_f16* p = xb + lane * kXbStride + wave;
+            p[0] = hi.x;
+            p[xplane] = lo.x;
+            p[2 * xplane] = hi.y;
+            p[3 * xplane] = lo.y;
+            p[4 * xplane] = -hi.y;
+            p[5 * xplane] = -lo.y;
+        }
+        if (tile + gridDim.x < a.ntiles) prefetch(tile + gridDim.x);      // the next slab's rows fly during the MFMAs below
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        if (!(a.dbg & 4)) {
+            // second operand, once per tile: [hi; hi] from the hi planes in every lane group, [lo; 0] from the lo planes in
+            // groups 0/1 and from the zero block in groups 2/3
+            const lds_f16* bp = xb + i0 * kXbStride + b_lane;
+            const lds_f16* bl = upper ? zeros : bp + xplane;
+            const int lstep = upper ? 0 : 2 * xplane;
+            const u32x4 c_hh = *reinterpret_cast<lds_u32x4*>(bp), c_l0 = *reinterpret_cast<lds_u32x4*>(bl);
+            const u32x4 d_hh = *reinterpret_cast<lds_u32x4*>(bp + 2 * xplane), d_l0 = *reinterpret_cast<lds_u32x4*>(bl + lstep);
+            const u32x4 nd_hh = *reinterpret_cast<lds_u32x4*>(bp + 4 * xplane), nd_l0 = *reinterpret_cast<lds_u32x4*>(bl + 2 * lstep);
+#pragma unroll
+            for (int n = 0; n < T; ++n) {
+                if (gw_h[n] >= 0) {
+                    // first operand: (hi | lo) of the real and of the imaginary part of H^T
+                    const lds_f16* ap = img + a_lane + gw_h[n];
+                    u32x4 are, aim;
+                    {
+                        const u32x2 r0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap)));
+                        const u32x2 r1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * KSI)));
+                        const u32x2 i0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP)));
+                        const u32x2 i1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP + 4 * KSI)));
+                        are = u32x4{r0.x, r0.y, r1.x, r1.y};
+                        aim = u32x4{i0_.x, i0_.y, i1_.x, i1_.y};
+                    }
+                    // H conj(X), H = a + ib, X = c + id:  re = a c + b d,  im = b c - a d
+                    f32x4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
+                    re = mfma32h(are, c_l0, re);  re = mfma32h(are, c_hh, re);
+                    re = mfma32h(aim, d_l0, re);  re = mfma32h(aim, d_hh, re);
+                    im = mfma32h(aim, c_l0, im);  im = mfma32h(aim, c_hh, im);
+                    im = mfma32h(are, nd_l0, im); im = mfma32h(are, nd_hh, im);
+                    gre[n] += re * it;
+                    gim[n] += im * it;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // flush my gW partial
+#pragma unroll
+    for (int n = 0; n < T; ++n) {
+        if (gw_h[n] >= 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = gw_h[n] + 4 * fq + jj;
+                const int i = i0 + fr;
+                ggwp[(((size_t)blockIdx.x * F + f) * KP + k) * IP + i] = make_float2(gre[n][jj], gim[n][jj]);
+            }
+        }
+    }
+}
+
 // gw_eff[o][i][r][f] = 1/F sum_p gwp[p][f][r*O+o][i]
 __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __restrict__ gw, int P, int F, int R,
                                     int O, int I, int KP, int IP) {
@@ -361,7 +536,15 @@ static int launch_backward_filter(const float2* x, const float* hdump, float2* g
                                  : reinterpret_cast<const void*>(fc_backward_filter_kernel<T>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_filter) != hipSuccess) return FC_ERR_LAUNCH;
     }
-    if (p.fhalf)
+    static const bool half2 = !(getenv("FC_FILTER2") && atoi(getenv("FC_FILTER2")) == 0);      // FC_FILTER2=0: the LDS-staged kernel (development)
+    if (p.fhalf && half2) {
+        const size_t lds2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
+        if (lds2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return FC_ERR_LAUNCH;
+        hipLaunchKernelGGL(fc_backward_filter_half2_kernel<T>, dim3(p.P, p.F), dim3(kThreads), lds2, stream, x, hdump, gwp, a, p.F, d->B,
+                           d->R * d->O);
+    } else if (p.fhalf)
         hipLaunchKernelGGL(fc_backward_filter_half_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a,
                            p.F, d->B, d->R * d->O);
     else

@@ -43,3 +43,11 @@ def golden():
             cache[fname] = load_golden(fname)
         return cache[fname]
     return get
+
+
+def free_port():
+    """A TCP port nobody listens on right now (a fixed rendezvous port can still be in TIME_WAIT from the previous run)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]

@@ -4,13 +4,13 @@ import os
 import subprocess
 import sys
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 
 def test_partitioned_fieldconv_two_ranks_gloo():
     env = dict(os.environ, OMP_NUM_THREADS='2', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'tests', '_dist_worker.py')]
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count('err y=') == 2, res.stdout[-3000:]

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_partitioned_fieldconv_two_ranks_one_gpu():
     env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29534', os.path.join(ROOT, 'tests', '_dist_worker.py')]
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count('err y=') == 2, res.stdout[-3000:]
