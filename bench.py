@@ -48,9 +48,9 @@ def algorithmic_flops(N, E, I, O, R, F):
 def cpu_baseline(B, R, C, k, threads):
     """Reference algorithm (oracle/reference_port_torch.py) on the host cores, bounded sample."""
     from fieldconv_amd.data import sphere_support
-    from fieldconv_amd.transforms import FCPrecomp
     from fieldconv_amd.nn import FieldConv
     from oracle import reference_port_torch as port
+    from oracle.torch_composites import FCPrecomp              # the CPU leg's stencil comes from the oracle as well
     n_s = 2500
     torch.set_num_threads(threads)
     data = sphere_support(n_s, k=k, seed=1)

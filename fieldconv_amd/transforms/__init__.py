@@ -1,3 +1,3 @@
-from .fc_precomp import FCPrecomp, radialInterpolant
+from .fc_precomp import FCPrecomp
 
-__all__ = ['FCPrecomp', 'radialInterpolant']
+__all__ = ['FCPrecomp']

@@ -1,26 +1,8 @@
-"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97).  Device tensors go through
-the library (csrc/fc_precomp.hip: three launches); the torch code below is what CPU tensors take and what the CPU suite pins
-to the reference fixtures."""
+"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97): three launches of
+csrc/fc_precomp.hip (fc_precomp_mark / fc_precomp_build).  Device tensors only, like every operator of this package."""
 import ctypes
-import os
 
 import torch
-
-
-def radialInterpolant(r, n_rings):
-    """(E,R) linear-interpolation weights on the equal-area knots sqrt(q/(R-1)); exactly two
-    non-zeros per row (reference transforms/fc_precomp.py:10-27).  The upper knot is the first
-    knot >= r, never knot 0."""
-    knots = torch.sqrt(torch.arange(n_rings, device=r.device) / (n_rings - 1))
-    gap = knots[None, :] - r[:, None]
-    gap = torch.where(gap < 0, torch.full_like(gap, 1e8), gap)
-    hi = torch.argmin(gap, dim=1).clamp_min(1)
-    lo = hi - 1
-    w_hi = (r - knots[lo]) / (knots[hi] - knots[lo])
-    w = torch.zeros(r.shape[0], n_rings, device=r.device, dtype=torch.float32)
-    w.scatter_(1, hi[:, None], w_hi[:, None].float())
-    w.scatter_(1, lo[:, None], (1 - w_hi)[:, None].float())
-    return w
 
 
 class FCPrecomp(object):
@@ -55,11 +37,19 @@ class FCPrecomp(object):
         return out
 
     def _compute(self, r, theta, w, supp_edges, xp):
-        if (r.is_cuda and os.environ.get('FIELDCONV_TORCH_PRECOMP', '0') != '1' and r.dtype == torch.float32
-                and theta.dtype == torch.float32 and w.dtype == torch.float32 and xp.dtype == torch.complex64
-                and 2 <= self.R <= 8 and 2 * self.B + 1 <= 7 and r.numel() > 0):
-            return self._compute_native(r, theta, w, supp_edges, xp)
-        return self._compute_torch(r, theta, w, supp_edges, xp)
+        if not r.is_cuda:
+            raise RuntimeError(f'FCPrecomp: fieldconv_amd runs on a ROCm device only (got {r.device} tensors); there is no '
+                               'CPU fallback')
+        if (r.dtype != torch.float32 or theta.dtype != torch.float32 or w.dtype != torch.float32
+                or xp.dtype != torch.complex64):
+            raise ValueError('FCPrecomp expects float32 logMag / logAng / w and complex64 xp')
+        if not (2 <= self.R <= 8 and 1 <= 2 * self.B + 1 <= 7):
+            raise ValueError('FCPrecomp supports n_rings 2..8 and band limits 0..3')
+        if r.numel() == 0:
+            F = 2 * self.B + 1
+            return (supp_edges[:0], torch.zeros((0, self.R, F), dtype=torch.complex64, device=r.device),
+                    torch.zeros(0, dtype=torch.complex64, device=r.device), torch.zeros(0, dtype=torch.complex64, device=r.device))
+        return self._compute_native(r, theta, w, supp_edges, xp)
 
     def _compute_native(self, r, theta, w, supp_edges, xp):
         from .. import _lib
@@ -85,23 +75,6 @@ class FCPrecomp(object):
             _lib.check(lib.fc_precomp_build(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, R, F, p(edges_out), p(sten), p(ln),
                                             p(wxp), p(ws), nbytes, st), 'fc_precomp_build')
         return edges_out.to(supp_edges.dtype), sten, ln, wxp
-
-    def _compute_torch(self, r, theta, w, supp_edges, xp):
-        B, R = self.B, self.R
-        r = r / self.max_r
-        keep = torch.nonzero(r <= 1.0).squeeze(-1)
-        r, theta, supp_edges, xp = r[keep], theta[keep], supp_edges[keep, :], xp[keep]
-        ln = torch.polar(r, theta)
-        ring = radialInterpolant(r, R)
-        m = torch.arange(-B, B + 1, device=theta.device)
-        ang = m[None, :] * theta[:, None]
-        freq = torch.polar(torch.ones_like(ang), ang)
-        src, dst = supp_edges[:, 0], supp_edges[:, 1]
-        ws = w[src, 0]
-        total = torch.zeros(w.shape[0], dtype=ws.dtype, device=ws.device).index_add(0, dst, ws)
-        wxp = (ws / (1e-12 + total[dst])) * xp
-        supp_sten = ring[:, :, None] * freq[:, None, :] * wxp[:, None, None]
-        return supp_edges, supp_sten, ln, wxp
 
     def __repr__(self):
         return '{}(n_rings={}, epsilon={})'.format(self.__class__.__name__, self.R, self.max_r)

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 from fieldconv_amd.data import sphere_partition                     # noqa: E402
 from fieldconv_amd.dist import HaloPlan, halo_exchange              # noqa: E402
-from fieldconv_amd.transforms import FCPrecomp                      # noqa: E402
+from oracle.torch_composites import FCPrecomp                       # noqa: E402  (CPU stencils; the package's FCPrecomp is device-only)
 from oracle import fieldconv_oracle as orc                          # noqa: E402
 
 

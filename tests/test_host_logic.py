@@ -1,6 +1,6 @@
-"""CPU tests of the host-side logic of fieldconv_amd: module/state_dict layout, filter assembly,
-stencil assembly, graph preprocessing, torch-composite blocks, and the C-ABI surface (symbols only:
-no kernel launches without a GPU)."""
+"""CPU tests of the host-side logic of fieldconv_amd (module/state_dict layout, filter assembly, graph preprocessing, the
+C-ABI surface: symbols only, no kernel launches without a GPU) and of the oracle's torch restatements of FCPrecomp, ECHO
+and TransField against the reference fixtures."""
 import ctypes
 import os
 import re
@@ -17,8 +17,9 @@ from fieldconv_amd import _lib
 from fieldconv_amd.graph import SupportGraph, get_graph
 from fieldconv_amd.nn import ECHO, ECHOBlock, FCResNetBlock, FieldConv, LiftBlock, TangentLin, TangentNonLin, TransField
 from fieldconv_amd.nn.field_conv import effective_filter
-from fieldconv_amd.transforms import FCPrecomp
 from fieldconv_amd.utils import isOrigin, softAbs, softAngle
+from oracle import torch_composites as tc
+from oracle.torch_composites import FCPrecomp        # stencils for the CPU tests (the package's FCPrecomp is device-only)
 
 
 def T(a):
@@ -65,6 +66,14 @@ def test_product_path_refuses_cpu_tensors():
         TangentLin(4, 4)(x)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         TangentNonLin(4)(x)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ECHO(4, 2)(x, edges, torch.zeros(3, dtype=torch.cfloat), torch.zeros(3, dtype=torch.cfloat))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        TransField(3, 4, n_rings=3)(torch.zeros(5, 3), edges, sten[..., :2])
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.transforms import FCPrecomp as DeviceFCPrecomp
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        DeviceFCPrecomp(1, 3, 1.0)(sphere_support(20, 4))
 
 
 def test_package_never_imports_the_oracle():
@@ -203,13 +212,13 @@ def test_support_graph_groups_edges_both_ways():
     assert empty.rowptr_t.tolist() == [0] * 5
 
 
-# ------------------------------------------------------------------ torch-composite "next" rows
+# ------------------------------------------------------------------ the oracle's torch restatements of the "next" rows
 def test_echo_descriptor_matches_reference():
     c = load_golden('echo_lift.npz')['echo']
     m = ECHO(c['x'].shape[1], int(c['n_bins']))
-    assert torch.equal(m.dMap, T(c['dMap']))
+    assert torch.equal(m.dMap, T(c['dMap'])) and torch.equal(tc.disk_map(int(c['n_bins']))[0], T(c['dMap']))
     x = T(c['x']).requires_grad_(True)
-    y = m(x, T(c['edges']), T(c['ln']), T(c['wxp']))
+    y = tc.echo_descriptors(x, T(c['edges']), T(c['ln']), T(c['wxp']), int(c['n_bins']))
     assert rel_err(y.detach().numpy(), c['y']) < 5e-6
     gx, = torch.autograd.grad(y, x, grad_outputs=T(c['gy']))
     assert rel_err(gx.numpy(), c['gx']) < 5e-5
@@ -219,8 +228,8 @@ def test_echo_descriptor_matches_reference():
 def test_trans_field_matches_reference(ftype):
     c = load_golden('echo_lift.npz')[f'lift_block_t{ftype}']
     m = TransField(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ftype)
-    m.load_state_dict({k[len('p_field.'):]: T(v) for k, v in c.items() if k.startswith('p_field.')})
-    y = m(T(c['x']), T(c['edges']), T(c['lift_sten']))
+    m.load_state_dict({k[len('p_field.'):]: T(v) for k, v in c.items() if k.startswith('p_field.')})      # the reference's layout loads
+    y = tc.trans_field(T(c['x']), T(c['edges']), T(c['lift_sten']), m.zonalAng, m.zonalMag, m.phase, ftype)
     # LiftBlock output = modReLU(TransField); check through the oracle's modReLU
     out = orc.tangent_nonlin_forward(y.detach().numpy(), c['p_nonlin.bias'])
     assert rel_err(out, c['y']) < 5e-6
@@ -231,7 +240,6 @@ def test_factored_and_geometric_records_reconstruct_the_stencil():
     kernels read must reproduce every stencil entry; stencils without that structure are refused."""
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.graph import factor_stencil, geometric_phases
-    from fieldconv_amd.transforms import FCPrecomp
     for B, R in ((1, 3), (2, 6), (3, 5)):
         data = sphere_support(300, 9, seed=B)
         edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
