@@ -66,14 +66,14 @@ def cpu_baseline(B, R, C, k, threads):
         torch.autograd.grad(y, [x] + params, grad_outputs=gy)
     step()
     best = float('inf')
-    for _ in range(2):
+    for _ in range(4):                     # ~2 s per step on 128 cores: ~10 s of CPU work in all
         t0 = time.perf_counter()
         step()
         best = min(best, time.perf_counter() - t0)
     E = edges.shape[0]
     return {'value': E / best / 1e6, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
             'sample': f'reference-structured torch CPU port (oracle/reference_port_torch.py), one FieldConv fwd+bwd on a '
-                      f'{n_s}-vertex sphere mesh, k={k}, C={C}, B={B}, R={R} (E={E}); best of 2 after 1 warm-up, '
+                      f'{n_s}-vertex sphere mesh, k={k}, C={C}, B={B}, R={R} (E={E}); best of 4 after 1 warm-up, '
                       f'{best:.2f} s per step'}
 
 
