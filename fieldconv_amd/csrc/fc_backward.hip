@@ -135,6 +135,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
 //                   split into halves, planes [i][vertex].
 // All scales arrive with the slab (BwdArgs::tails), so the conversion has no reduction and no extra barrier.
 // The tile's products start from zero and are added to the fp32 running sums with the factor 1/t[i].
+// Two variants: fc_backward_filter_half_kernel stages the fp32 slabs in LDS (LDS-DMA, double-buffered; one image, two
+// barriers per slab; FC_FILTER2=0), fc_backward_filter_half2_kernel (default, below it) converts straight from registers
+// loaded one slab ahead into one of two images, with one barrier per slab.
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

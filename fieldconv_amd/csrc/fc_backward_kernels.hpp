@@ -14,10 +14,11 @@
 //  fc_forward.hip), drops one LDS slab per frequency, the workgroup contracts it with the packed
 //  conjugated filter on MFMA, and every thread folds its (vertex, channel) entry of gxt_f into a
 //  running gx.  Each slab is also copied to HBM (`hdump`, 2*16*KS floats per tile and frequency).
-//  fc_backward_filter_kernel needs every tile's H for one frequency and 553 KB of accumulators in
-//  total -- more than a CU's register file -- so blockIdx.y = f: a persistent workgroup keeps
-//  gW[:,:,:,f] (KP x IP complex, spread over its wavefronts' MFMA accumulators) in registers,
-//  streams the dumped slabs of its frequency back with LDS-DMA (double-buffered, no gather at all)
+//  The filter-gradient kernels (fc_backward.hip) need every tile's H for one frequency and 553 KB of
+//  accumulators in total -- more than a CU's register file -- so blockIdx.y = f: a persistent workgroup
+//  keeps gW[:,:,:,f] (KP x IP complex, spread over its wavefronts' MFMA accumulators) in registers,
+//  streams the dumped slabs of its frequency back (no gather at all: the default kernel loads every
+//  wavefront's vertex row into registers one slab ahead, the fp32 one uses double-buffered LDS-DMA)
 //  and writes one partial at the end; fc_backward_finish sums the partials in a fixed order.
 //  The 2 x 237 MB of slab traffic at config 2 replace a five-fold repetition of the gather.
 #pragma once
