@@ -665,6 +665,13 @@ def test_native_graph_build_matches_torch_build(dev, N, k, B, R):
         assert torch.equal(getattr(e, name), getattr(a, name))
     assert torch.equal(torch.sort(e.nbr_t.view(-1))[0], torch.sort(a.nbr_t)[0])
     assert torch.equal(edges[e.perm_t, 0].to(torch.int32), e.nbr_t) and torch.equal(edges[e.perm_s, 1].to(torch.int32), e.nbr_s)
+    # the reference hands over a transposed view of a (2,E) tensor (transforms/support_graph.py:59), and int32 works too
+    view = edges.t().contiguous().t()
+    assert not view.is_contiguous()
+    v = SupportGraph(view, sten, N, native=True)
+    w32 = SupportGraph(edges.to(torch.int32), sten, N, native=True)
+    for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s'):
+        assert torch.equal(getattr(v, name), getattr(a, name)) and torch.equal(getattr(w32, name), getattr(a, name)), name
     # a random dense stencil is not factorable: both builds must say so
     dense = torch.complex(torch.randn(sten.shape, generator=g), torch.randn(sten.shape, generator=g)).to(dev)
     c = SupportGraph(edges, dense, N, native=True)
