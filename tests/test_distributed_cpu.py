@@ -1,5 +1,6 @@
-"""world_size-2 gloo test of the vertex-partitioned path (halo exchange forward, transposed exchange
-backward, filter-gradient all-reduce) against the unpartitioned single-process answer."""
+"""world_size-2 gloo tests: the vertex-partitioned path (halo exchange forward, transposed exchange backward,
+filter-gradient all-reduce) against the unpartitioned single-process answer, and the data-parallel path (one mesh per
+rank, one all-reduce of the parameter gradients; BASELINE config 5) against the sum over the meshes."""
 import os
 import subprocess
 import sys
@@ -14,3 +15,12 @@ def test_partitioned_fieldconv_two_ranks_gloo():
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count('err y=') == 2, res.stdout[-3000:]
+
+
+def test_data_parallel_meshes_two_ranks_gloo():
+    env = dict(os.environ, OMP_NUM_THREADS='2', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dp_worker.py')]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count('dp err gparams=') == 2, res.stdout[-3000:]

@@ -20,3 +20,13 @@ def test_partitioned_fieldconv_two_ranks_one_gpu():
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count('err y=') == 2, res.stdout[-3000:]
+
+
+def test_data_parallel_meshes_two_ranks_one_gpu():
+    """BASELINE config 5 in miniature: one mesh per rank through the FieldConv module, parameter gradients all-reduced."""
+    env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dp_worker.py')]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count('dp err gparams=') == 2, res.stdout[-3000:]
