@@ -20,7 +20,9 @@ static bool dims_supported(const fc_dims* d) {
     if (!dims_valid(d)) return false;
     if (!shape_compiled(d->R, d->B)) return false;
     if (d->I > kMaxChannels || d->O > kMaxChannels) return false;
-    return true;
+    // slab, partial sums and record ring must fit the CU's LDS (e.g. 8 rings x 57..64 channels do not in split mode:
+    // the callers run such layers in narrower channel blocks, which the operator's linearity allows)
+    return forward_fits(d) && backward_fits(d);
 }
 
 // The factored kernels address feature rows with 32-bit byte offsets: N * C * 8 must stay below 4 GiB

@@ -526,6 +526,8 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
     gw[(((size_t)o * I + i) * R + r) * F + f] = make_float2(s.x * sc, s.y * sc);
 }
 
+bool backward_fits(const fc_dims* d) { return plan_backward(d, split_mode()).ok_factored; }
+
 size_t backward_workspace_bytes(const fc_dims* d) {
     const BwdPlan p = plan_backward(d, split_mode());
     return p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;

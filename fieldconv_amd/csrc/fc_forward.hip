@@ -16,4 +16,9 @@ int forward_impl(const float* x, const float* sten, const fc_csr* g, const float
 
 size_t forward_workspace_bytes(const fc_dims* d, int kind) { return forward_workspace_bytes_impl(d, kind); }
 
+bool forward_fits(const fc_dims* d) {
+    const MmaGeom g = make_mma_geom(d->O, d->R, d->I, split_mode());
+    return forward_lds_floats(g, 1) * sizeof(float) + (size_t)kWaves * kRingChunks * 1024 <= kMaxLds;
+}
+
 }  // namespace fc

@@ -34,5 +34,8 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
+// LDS budget of the factored kernels in the current MFMA mode (the dense kernels need less)
+bool forward_fits(const fc_dims* d);
+bool backward_fits(const fc_dims* d);
 
 }  // namespace fc

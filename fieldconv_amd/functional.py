@@ -267,19 +267,34 @@ class _FieldConvParamFn(torch.autograd.Function):
 MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)
 
 
+def _channel_block(graph, I, O, B):
+    """Widest channel block (<= 64) the compiled kernels take for this stencil shape: 64 in general, less when slab,
+    partial sums and record ring would not fit the CU's LDS (e.g. 8 rings with more than 56 channels)."""
+    cached = graph._plans.get(('block', B))
+    if cached is not None:
+        return cached
+    lib = _lib.load()
+    blk = MAX_CHANNELS
+    while blk > 8 and not lib.fc_supported(ctypes.byref(FcDims(graph.N, graph.E, blk, blk, graph.R, int(B)))):
+        blk -= 8
+    graph._plans[('block', B)] = blk
+    return blk
+
+
 def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
-    """FieldConv from the raw module parameters (see FieldConv.forward).  Layers wider than 64 channels
-    run as blocks of <= 64 input x <= 64 output channels: the operator is linear in the input channels
-    (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
+    """FieldConv from the raw module parameters (see FieldConv.forward).  Layers wider than the kernels' channel block
+    (64, fewer for the largest ring counts) run as blocks of input x output channels: the operator is linear in the
+    input channels (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
-    if I > MAX_CHANNELS or O > MAX_CHANNELS:
+    blk = _channel_block(graph, I, O, band_limit)
+    if I > blk or O > blk:
         outs = []
-        for o0 in range(0, O, MAX_CHANNELS):
-            osl = slice(o0, min(o0 + MAX_CHANNELS, O))
+        for o0 in range(0, O, blk):
+            osl = slice(o0, min(o0 + blk, O))
             acc = None
-            for i0 in range(0, I, MAX_CHANNELS):
-                isl = slice(i0, min(i0 + MAX_CHANNELS, I))
+            for i0 in range(0, I, blk):
+                isl = slice(i0, min(i0 + blk, I))
                 part = field_conv_params(x[:, isl], zonal[osl, isl], spherical[osl, isl], phase[osl, isl], ftype, band_limit,
                                          graph)
                 acc = part if acc is None else acc + part
@@ -303,6 +318,17 @@ def field_conv(x, w_eff, graph):
         raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {w_eff.shape[1]})')
     if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
         raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
+    O, I = w_eff.shape[0], w_eff.shape[1]
+    blk = _channel_block(graph, I, O, (graph.F - 1) // 2)
+    if I > blk or O > blk:              # channel blocks, as in field_conv_params
+        outs = []
+        for o0 in range(0, O, blk):
+            acc = None
+            for i0 in range(0, I, blk):
+                part = field_conv(x[:, i0:i0 + blk], w_eff[o0:o0 + blk, i0:i0 + blk], graph)
+                acc = part if acc is None else acc + part
+            outs.append(acc)
+        return torch.cat(outs, dim=1)
     return _FieldConvFn.apply(x, w_eff, graph)
 
 

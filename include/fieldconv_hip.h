@@ -56,8 +56,11 @@ typedef struct fc_csr {
 int fc_abi_version(void);
 const char* fc_status_string(int status);
 
-/* 1 if the compiled kernels cover these dims, 0 otherwise (then every call returns
- * FC_ERR_UNSUPPORTED for them). */
+/* 1 if the compiled kernels cover these dims, 0 otherwise (then every call returns FC_ERR_UNSUPPORTED for them):
+ * (n_rings, band_limit) among the compiled shapes, at most 64 channels, and slab + partial sums + record ring within
+ * the CU's 160 KB of LDS in the current MFMA mode (8 rings with more than 56 channels are not, in the default mode).
+ * The operator is linear in the input channels and independent across output channels: wider layers are run as
+ * channel blocks by the caller (fieldconv_amd/functional.py does). */
 int fc_supported(const fc_dims* dims);
 
 /* ---- filter packing -------------------------------------------------------------------- *

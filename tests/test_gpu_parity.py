@@ -408,7 +408,7 @@ def _random_shapes(n, seed=2024):
     return shapes
 
 
-@pytest.mark.parametrize('shape', _random_shapes(40), ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d_%s' % (s[:6] + ('geo' if s[6] else 'dense',)))
+@pytest.mark.parametrize('shape', _random_shapes(int(os.environ.get('FC_FUZZ_SHAPES', '40')), int(os.environ.get('FC_FUZZ_SEED', '2024'))), ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d_%s' % (s[:6] + ('geo' if s[6] else 'dense',)))
 def test_random_shapes_vs_oracle(shape, dev):
     """Seeded sweep over (n_rings, band limit, channel counts, mesh size, degree): every compiled shape class
     (one or two frequency groups, one or two slab buffers, ragged tiles, channels off the tile sizes), on
@@ -487,6 +487,35 @@ def test_unsupported_shapes_fail_loudly(dev):
     x = torch.zeros(5, 4, dtype=torch.cfloat, device=dev)
     with pytest.raises(FieldConvNativeError):
         conv(x, torch.zeros(3, 2, dtype=torch.long, device=dev), torch.zeros(3, 9, 3, dtype=torch.cfloat, device=dev))
+
+
+def test_layers_too_large_for_the_lds_run_in_narrower_blocks(dev):
+    """8 rings x 63 channels: slab, partial sums and record ring exceed the CU's LDS in split mode (fc_supported says so);
+    the layer then runs as narrower channel blocks.  Found by the seeded shape sweep with FC_FUZZ_SHAPES=160."""
+    import ctypes
+    from fieldconv_amd import _lib
+    from fieldconv_amd._lib import FcDims
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from oracle.torch_composites import FCPrecomp
+    N, k, I, O, B, R = 40, 14, 63, 42, 2, 8
+    if not REDUCED and os.environ.get('FC_MFMA') != 'f32':
+        assert _lib.load().fc_supported(ctypes.byref(FcDims(N, N * k, I, O, R, B))) == 0
+    assert _lib.load().fc_supported(ctypes.byref(FcDims(N, N * k, 32, 32, R, B))) == 1
+    data = sphere_support(N, k, seed=5)
+    edges, sten, _, _ = FCPrecomp(B, R, float(data.logMag.max()) * 1.0001)(data)
+    g = torch.Generator().manual_seed(8)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    assert rel_err(H(y), orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())) < TOL
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(gx), gx_ref) < TOL and rel_err(H(gW), gW_ref) < TOL
 
 
 def test_wide_layers_are_split_into_channel_blocks(dev):

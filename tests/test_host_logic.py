@@ -52,6 +52,10 @@ def test_supported_query_and_sizes_need_no_gpu():
     assert lib.fc_supported(ctypes.byref(bad)) == 0
     wide = _lib.FcDims(100, 10, 128, 48, 6, 2)
     assert lib.fc_supported(ctypes.byref(wide)) == 0
+    # 8 rings x 63 channels: slab + partial sums + record ring exceed the 160 KB of LDS in split mode (callers block it)
+    if os.environ.get('FC_MFMA') in (None, '', 'split'):
+        assert lib.fc_supported(ctypes.byref(_lib.FcDims(100, 1000, 63, 42, 8, 2))) == 0
+    assert lib.fc_supported(ctypes.byref(_lib.FcDims(100, 1000, 32, 32, 8, 2))) == 1
     assert b'unsupported' in lib.fc_status_string(-2)
 
 
