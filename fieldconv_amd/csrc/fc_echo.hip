@@ -4,6 +4,7 @@
 // The reference does this with `nonzero` compaction (host sync), four index_adds over E*C*4 votes and autograd;
 // here: one target-centric kernel (a wavefront per vertex, lane = channel, lane-private histogram rows in LDS, no
 // global atomics) and one source-centric kernel for the input gradient.
+#include <stdlib.h>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
 
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
 
 // wavefronts per vertex: spread large supports over the workgroup when the mesh alone cannot fill the chip
 static int echo_waves_per_vertex(int N, int E) {
+    if (const char* e = getenv("FC_ECHO_WPV")) return atoi(e);       // development
     const long deg = N > 0 ? (long)E / N : 0;
     if (deg >= 64 && N < 65536) return 4;
     if (deg >= 32 && N < 131072) return 2;

@@ -730,6 +730,9 @@ def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     g = torch.Generator().manual_seed(N + C)
     keep = torch.rand(edges.shape[0], generator=g) > 0.2
     edges, ln, wxp = edges[keep].contiguous(), ln[keep].contiguous(), wxp[keep].contiguous()
+    # self edges: radius exactly 0 as in real data (the synthetic geodesic distance leaves 1e-9; a point a hair off the
+    # raster's centre votes with full weight into a sign-dependent cell in the reference's formula)
+    ln = torch.where(ln.abs() < 1e-6, torch.zeros_like(ln), ln)
     x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
     x[torch.rand(N, C, generator=g) < 0.05] = 0
     m = ECHO(C, n_bins)
@@ -742,8 +745,21 @@ def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     gg, = torch.autograd.grad(dd, [xd], grad_outputs=gd.to(dev))
     # votes are piecewise linear in the rotated point (an fp32 floor/ceil flip moves a vanishing vote to the neighbouring
     # cell); ln is scaled by 0.999 so that no point sits exactly on the raster's rim
-    assert rel_err(H(dd), dr.detach().numpy()) < 5e-6             # measured 1-3e-7
-    assert rel_err(H(gg), gr.numpy()) < 5e-5                      # measured 1-3e-6
+    # The reference's votes vanish at exactly integer raster coordinates (ceil == floor, nn/echo.py:30-61): a coordinate that
+    # rounds to an integer in fp32 but sits 1e-7 beside it in float64 drops a whole vote (about once per 1e6 (edge, channel)
+    # pairs, tools/fuzz/fuzz_components.py).  Entries fed by such a vote are not comparable and are left out.
+    frame = torch.conj(torch.polar(torch.ones(N, C, dtype=torch.float64), torch.angle(x.to(torch.complex128))))
+    qq = torch.view_as_real((ln * 0.999).to(torch.complex128)[:, None] * frame[edges[:, 0]] * n_bins)
+    near = ((qq - torch.round(qq)).abs() < 1e-5).any(dim=2) & (ln.abs() > 0)[:, None]
+    cols = torch.arange(C)[None, :].expand(edges.shape[0], -1)
+    fragile = torch.zeros(N, C, dtype=torch.bool)
+    fragile[edges[:, 1][:, None].expand(-1, C)[near], cols[near]] = True
+    tainted = torch.zeros(N, dtype=torch.bool)
+    tainted[edges[:, 0][fragile.any(dim=1)[edges[:, 1]]]] = True
+    ok, okg = (~fragile)[..., None].numpy(), (~tainted)[:, None].numpy()
+    assert float(fragile.float().mean()) < 1e-2
+    assert rel_err(H(dd) * ok, dr.detach().numpy() * ok) < 5e-6             # measured 1-3e-7
+    assert rel_err(H(gg) * okg, gr.numpy() * okg) < 5e-5                    # measured 1-3e-6
 
 
 @pytest.mark.parametrize('N,k,B,R,shrink', [(300, 20, 2, 6, 1.0), (1024, 128, 2, 6, 0.8), (77, 9, 1, 3, 0.5), (150, 12, 3, 8, 1.0)])

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""One-off seeded fuzz of the kernels around the convolution (ECHO, TransField, FCPrecomp, graph build, edge split) against
+the oracle's restatements.  Not part of the test suite (it imports the oracle: run it from the repo root on a GPU box):
+    python tools/fuzz/fuzz_components.py [seed] [cases]"""
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from fieldconv_amd.data import sphere_support                     # noqa: E402
+from fieldconv_amd.functional import field_conv                   # noqa: E402
+from fieldconv_amd.graph import SupportGraph                      # noqa: E402
+from fieldconv_amd.nn import ECHO, TransField                     # noqa: E402
+from fieldconv_amd.transforms import FCPrecomp                    # noqa: E402
+from oracle import fieldconv_oracle as orc                        # noqa: E402
+from oracle import torch_composites as tc                         # noqa: E402
+
+dev = torch.device('cuda:0')
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rng = np.random.default_rng(seed)
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30)) if a.size else 0.0
+
+
+def mesh(N, k, B, R, drop=0.0, shrink=1.0):
+    k = max(1, min(k, N - 1))
+    data = sphere_support(max(N, k + 2), k, seed=int(rng.integers(1 << 30)))
+    eps = float(data.logMag.max()) * 1.0001 * shrink
+    edges, sten, ln, wxp = tc.fc_precomp(data.logMag, data.logAng, data.w, data.supp_edges, data.xp, B, R, eps)
+    if drop > 0:
+        keep = torch.from_numpy(rng.random(edges.shape[0]) > drop)
+        edges, sten, ln, wxp = edges[keep].contiguous(), sten[keep].contiguous(), ln[keep].contiguous(), wxp[keep].contiguous()
+    return data, eps, edges, sten, ln, wxp
+
+
+def cplx(*shape):
+    return torch.from_numpy((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64))
+
+
+def fuzz_echo():
+    N, k, C, nb = int(rng.integers(3, 200)), int(rng.integers(1, 90)), int(rng.integers(1, 100)), int(rng.integers(1, 5))
+    data, eps, edges, sten, ln, wxp = mesh(N, k, 1, 3, drop=float(rng.random() * 0.5))
+    N = data.num_nodes
+    global last
+    last = f'N={N} k={k} C={C} bins={nb} E={edges.shape[0]}'
+    x = cplx(N, C)
+    x[torch.from_numpy(rng.random((N, C)) < 0.05)] = 0
+    lns = ln * float(0.83 + 0.16 * rng.random())
+    # The reference's votes vanish at exactly integer raster coordinates (ceil == floor, nn/echo.py:30-61): a coordinate
+    # that rounds to an integer in fp32 but sits 1e-7 beside it in fp64 drops a whole vote -- with ~1e6 (edge, channel)
+    # pairs per case that happens about once per case.  Entries fed by such a vote are excluded from the comparison.
+    d_map, _ = tc.disk_map(nb)
+    frame = torch.conj(torch.polar(torch.ones(N, C, dtype=torch.float64), tc.soft_angle(x.to(torch.complex128))))
+    qq = torch.view_as_real(lns.to(torch.complex128)[:, None] * frame[edges[:, 0]] * nb)          # (E, C, 2)
+    near = ((qq - torch.round(qq)).abs() < 1e-5).any(dim=2) & (lns.abs() > 0)[:, None]
+    fragile = torch.zeros(N, C, dtype=torch.bool)
+    fragile[edges[:, 1][:, None].expand(-1, C)[near], torch.arange(C)[None, :].expand(edges.shape[0], -1)[near]] = True
+    # gradients: a dropped vote also changes gx of its SOURCE vertex
+    fragile_src = torch.zeros(N, C, dtype=torch.bool)
+    fragile_src[edges[:, 0][:, None].expand(-1, C)[near], torch.arange(C)[None, :].expand(edges.shape[0], -1)[near]] = True
+    xr = x.to(torch.complex128).requires_grad_(True)
+    dr = tc.echo_descriptors(xr, edges, lns.to(torch.complex128), wxp.to(torch.complex128), nb)
+    gd = torch.from_numpy(rng.standard_normal(tuple(dr.shape)).astype(np.float32))
+    gr, = torch.autograd.grad(dr, [xr], grad_outputs=gd.double())
+    xd = x.to(dev).requires_grad_(True)
+    dd = ECHO(C, nb).to(dev)(xd, edges.to(dev), lns.to(dev), wxp.to(dev))
+    gg, = torch.autograd.grad(dd, [xd], grad_outputs=gd.to(dev))
+    ok = (~fragile)[..., None].numpy()
+    e1 = rel(dd.detach().cpu().numpy() * ok, dr.detach().numpy() * ok)
+    # a target entry with a dropped vote has a different |hist| direction: its gradient reaches every source of that target
+    tainted = torch.zeros(N, dtype=torch.bool)
+    tainted[edges[:, 0][(fragile.any(dim=1))[edges[:, 1]]]] = True
+    okg = (~(fragile_src | tainted[:, None])).numpy()
+    e2 = rel(gg.cpu().numpy() * okg, gr.numpy() * okg)
+    assert e1 < 1e-5 and e2 < 1e-4, (e1, e2, int(fragile.sum()))
+    return f'N={N} k={k} C={C} bins={nb} E={edges.shape[0]}'
+
+
+def fuzz_trans_field():
+    N, k = int(rng.integers(2, 300)), int(rng.integers(0, 100))
+    Cin, O, R, ft = int(rng.integers(1, 5)), int(rng.integers(1, 90)), int(rng.integers(2, 9)), int(rng.integers(0, 2))
+    E = N * k
+    edges = torch.from_numpy(np.stack((rng.integers(0, N, E), rng.integers(0, N, E)), 1))
+    full = cplx(E, R, 5) * 0.2
+    x = torch.from_numpy(rng.standard_normal((N, Cin)).astype(np.float32))
+    gy = cplx(N, O)
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    m = TransField(Cin, O, n_rings=R, ftype=ft)
+    pr = [p.detach().double().requires_grad_(True) for p in m.parameters()]
+    ph = pr[2] if ft != 0 else m.phase.double()
+    xr = x.double().requires_grad_(True)
+    yr = tc.trans_field(xr, edges, full[..., 1:3].to(torch.complex128), pr[0], pr[1], ph, ft)
+    gr = torch.autograd.grad(yr, [xr] + pr, grad_outputs=gy.to(torch.complex128))
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    yd = m(xd, edges.to(dev), full.to(dev)[..., 1:3])
+    gd = torch.autograd.grad(yd, [xd] + list(m.parameters()), grad_outputs=gy.to(dev))
+    errs = [rel(yd.detach().cpu().numpy(), yr.detach().numpy())] + [rel(a.cpu().numpy(), b.numpy()) for a, b in zip(gd, gr)]
+    assert errs[0] < 5e-5 and max(errs[1:]) < 2e-3, errs
+    return f'N={N} k={k} Cin={Cin} O={O} R={R} ftype={ft}'
+
+
+def fuzz_precomp_and_graph():
+    N, k, B, R = int(rng.integers(3, 400)), int(rng.integers(1, 60)), int(rng.integers(1, 4)), int(rng.integers(2, 9))
+    shrink = float(rng.choice([1.0, 1.0, 0.9, 0.6]))
+    k = max(1, min(k, N - 1))
+    data = sphere_support(max(N, k + 2), k, seed=int(rng.integers(1 << 30)))
+    N = data.num_nodes
+    eps = float(data.logMag.max()) * shrink
+    e2, s2, l2, w2 = tc.fc_precomp(data.logMag, data.logAng, data.w, data.supp_edges, data.xp, B, R, eps)
+    e1, s1, l1, w1 = (t.cpu() for t in FCPrecomp(B, R, eps)(data.to(dev)))
+    assert torch.equal(e1, e2), 'kept edges differ'
+    if e1.shape[0]:
+        assert rel(s1.numpy(), s2.numpy()) < 5e-6 and rel(l1.numpy(), l2.numpy()) < 5e-6 and rel(w1.numpy(), w2.numpy()) < 5e-6
+        perm = torch.from_numpy(rng.permutation(e1.shape[0]))
+        ed, sd = e1[perm].contiguous().to(dev), s1[perm].contiguous().to(dev)
+        a = SupportGraph(ed, sd, N, native=True)
+        b = SupportGraph(ed, sd, N, native=False)
+        assert a.factored == b.factored and (a.geo_t is None) == (b.geo_t is None)
+        for name in ('rowptr_t', 'nbr_t', 'runs_t', 'perm_t', 'rowptr_s', 'nbr_s', 'runs_s', 'perm_s'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+    return f'N={N} k={k} B={B} R={R} shrink={shrink} kept={e1.shape[0]}'
+
+
+def fuzz_small_mesh_conv():
+    N, k = int(rng.integers(2, 260)), int(rng.integers(8, 140))
+    I, O, B, R = int(rng.integers(1, 65)), int(rng.integers(1, 65)), int(rng.integers(1, 4)), int(rng.integers(2, 9))
+    data, eps, edges, sten, _, _ = mesh(N, k, B, R, drop=float(rng.random() * 0.4))
+    N = data.num_nodes
+    x, gy = cplx(N, I), cplx(N, O)
+    W = cplx(O, I, R, 2 * B + 1) / (I * R) ** 0.5
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    errs = (rel(y.detach().cpu().numpy(), y_ref), rel(gx.cpu().numpy(), gx_ref), rel(gW.cpu().numpy(), gW_ref))
+    assert max(errs) < 1e-5, errs
+    return f'N={N} k={k} I={I} O={O} B={B} R={R} E={edges.shape[0]}'
+
+
+failures = 0
+last = ''
+only = os.environ.get('FUZZ_ONLY')
+for name, fn in (('echo', fuzz_echo), ('trans_field', fuzz_trans_field), ('precomp+graph', fuzz_precomp_and_graph),
+                 ('small-mesh conv', fuzz_small_mesh_conv)):
+    if only and only != name:
+        continue
+    ok = 0
+    for c in range(cases):
+        state = rng.bit_generator.state
+        try:
+            fn()
+            ok += 1
+        except Exception as exc:          # noqa: BLE001
+            failures += 1
+            print(f'[{name}] case {c} FAILED ({last}): {type(exc).__name__}: {str(exc)[:300]}')
+    print(f'{name}: {ok}/{cases} passed', flush=True)
+sys.exit(1 if failures else 0)
