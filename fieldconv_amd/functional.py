@@ -373,6 +373,17 @@ def tangent_lin(x, re_w, im_w):
         raise ValueError('tangent_lin expects complex64 features')
     if x.dim() != 2 or x.shape[1] != re_w.shape[1]:
         raise ValueError(f'x has shape {tuple(x.shape)}, expected (N, {re_w.shape[1]})')
+    O, I = re_w.shape
+    if I > MAX_CHANNELS or O > MAX_CHANNELS:        # the kernel keeps the whole filter in LDS: wider mixes run as 64 x 64 blocks
+        outs = []
+        for o0 in range(0, O, MAX_CHANNELS):
+            acc = None
+            for i0 in range(0, I, MAX_CHANNELS):
+                part = _TangentLinFn.apply(x[:, i0:i0 + MAX_CHANNELS], re_w[o0:o0 + MAX_CHANNELS, i0:i0 + MAX_CHANNELS],
+                                           im_w[o0:o0 + MAX_CHANNELS, i0:i0 + MAX_CHANNELS])
+                acc = part if acc is None else acc + part
+            outs.append(acc)
+        return torch.cat(outs, dim=1)
     return _TangentLinFn.apply(x, re_w, im_w)
 
 

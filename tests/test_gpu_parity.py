@@ -89,7 +89,7 @@ def test_pointwise_golden(dev):
     assert np.array_equal(H(y)[org], c['x'][org])
 
 
-@pytest.mark.parametrize('N,I,O,offset', [(37, 5, 7, 0), (1000, 48, 48, 0), (333, 64, 33, 0), (20000, 48, 48, 0),
+@pytest.mark.parametrize('N,I,O,offset', [(37, 5, 7, 0), (1000, 48, 48, 0), (333, 64, 33, 0), (20000, 48, 48, 0), (500, 126, 121, 0),
                                           (130, 16, 16, 1), (5, 1, 3, 0), (4099, 24, 40, 0)])
 def test_pointwise_vs_oracle(N, I, O, offset, dev):
     """Ragged sizes, channel counts off the 16-wide MFMA tile, and an input that starts 8 bytes off a

@@ -148,11 +148,40 @@ def fuzz_small_mesh_conv():
     return f'N={N} k={k} I={I} O={O} B={B} R={R} E={edges.shape[0]}'
 
 
+def fuzz_pointwise():
+    from fieldconv_amd.functional import tangent_lin, tangent_nonlin
+    N, I, O = int(rng.integers(1, 3000)), int(rng.integers(1, 130)), int(rng.integers(1, 130))
+    global last
+    last = f'N={N} I={I} O={O}'
+    x, gy = cplx(N, I), cplx(N, O)
+    x[torch.from_numpy(rng.random((N, I)) < 0.03)] = 0
+    Re = torch.from_numpy(rng.standard_normal((O, I)).astype(np.float32)) / I ** 0.5
+    Im = torch.from_numpy(rng.standard_normal((O, I)).astype(np.float32)) / I ** 0.5
+    xd, Rd, Id = x.to(dev).requires_grad_(True), Re.to(dev).requires_grad_(True), Im.to(dev).requires_grad_(True)
+    y = tangent_lin(xd, Rd, Id)
+    gx, gR, gI = torch.autograd.grad(y, [xd, Rd, Id], grad_outputs=gy.to(dev))
+    y_ref = orc.tangent_lin_forward(x.numpy().astype(np.complex128), Re.numpy().astype(np.float64), Im.numpy().astype(np.float64))
+    gx_ref, gR_ref, gI_ref = orc.tangent_lin_backward(x.numpy().astype(np.complex128), Re.numpy().astype(np.float64),
+                                                      Im.numpy().astype(np.float64), gy.numpy().astype(np.complex128))
+    errs = [rel(y.detach().cpu().numpy(), y_ref), rel(gx.cpu().numpy(), gx_ref), rel(gR.cpu().numpy(), gR_ref), rel(gI.cpu().numpy(), gI_ref)]
+    assert max(errs) < 1e-5, ('lin', errs)
+    bias = torch.from_numpy((rng.standard_normal((1, I)) * 0.5).astype(np.float32))
+    g2 = cplx(N, I)
+    xd, bd = x.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    z = tangent_nonlin(xd, bd)
+    gx, gb = torch.autograd.grad(z, [xd, bd], grad_outputs=g2.to(dev))
+    z_ref = orc.tangent_nonlin_forward(x.numpy().astype(np.complex128), bias.numpy().astype(np.float64))
+    gx_ref, gb_ref = orc.tangent_nonlin_backward(x.numpy().astype(np.complex128), bias.numpy().astype(np.float64), g2.numpy().astype(np.complex128))
+    errs = [rel(z.detach().cpu().numpy(), z_ref), rel(gx.cpu().numpy(), gx_ref), rel(gb.cpu().numpy().reshape(-1), np.asarray(gb_ref).reshape(-1))]
+    assert max(errs) < 1e-5, ('nonlin', errs)
+    return last
+
+
 failures = 0
 last = ''
 only = os.environ.get('FUZZ_ONLY')
 for name, fn in (('echo', fuzz_echo), ('trans_field', fuzz_trans_field), ('precomp+graph', fuzz_precomp_and_graph),
-                 ('small-mesh conv', fuzz_small_mesh_conv)):
+                 ('small-mesh conv', fuzz_small_mesh_conv), ('pointwise', fuzz_pointwise)):
     if only and only != name:
         continue
     ok = 0
