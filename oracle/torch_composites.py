@@ -152,3 +152,17 @@ def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
         phi = phi + phase[None]
     rho = soft_absolute(torch.einsum('nir,oir->noi', mag, zonal_mag))
     return torch.polar(rho, phi).sum(dim=-1)
+
+
+# ---- pointwise tangent ops, nn/tangent_lin.py:27-29 and nn/tangent_nonlin.py:24-35 ----
+def tangent_lin(x, re_w, im_w):
+    """y[n,o] = sum_i x[n,i] (Re + i Im)[o,i]"""
+    return x @ torch.complex(re_w, im_w).to(x.dtype).t()
+
+
+def tangent_nonlin(x, bias):
+    """modReLU: non-origin x -> relu(|x| + b_c) x / |x|; entries inside the origin box pass through unchanged."""
+    mask = is_origin(x)
+    mag = torch.abs(_safe(x, mask))
+    out = torch.relu(mag + bias.to(mag.dtype)) / mag * _safe(x, mask)
+    return torch.where(mask, x, out)
