@@ -1,20 +1,23 @@
-"""world_size-2 gloo tests: the vertex-partitioned path (halo exchange forward, transposed exchange backward,
+"""world_size-2 (and 3) gloo tests: the vertex-partitioned path (halo exchange forward, transposed exchange backward,
 filter-gradient all-reduce) against the unpartitioned single-process answer, and the data-parallel path (one mesh per
 rank, one all-reduce of the parameter gradients; BASELINE config 5) against the sum over the meshes."""
 import os
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT, free_port
 
 
-def test_partitioned_fieldconv_two_ranks_gloo():
+@pytest.mark.parametrize('world', [2, 3])
+def test_partitioned_fieldconv_gloo(world):
     env = dict(os.environ, OMP_NUM_THREADS='2', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
-    assert res.stdout.count('err y=') == 2, res.stdout[-3000:]
+    assert res.stdout.count('err y=') == world, res.stdout[-3000:]
 
 
 def test_data_parallel_meshes_two_ranks_gloo():
