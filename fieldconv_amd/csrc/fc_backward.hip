@@ -536,25 +536,22 @@ size_t backward_workspace_bytes(const fc_dims* d) {
 template <int T>
 static int launch_backward_filter(const float2* x, const float* hdump, float2* gwp, const BwdArgs& a, const BwdPlan& p,
                                   const fc_dims* d, hipStream_t stream) {
-    if (p.lds_filter > 64 * 1024) {
-        const void* fn = p.fhalf ? reinterpret_cast<const void*>(fc_backward_filter_half_kernel<T>)
-                                 : reinterpret_cast<const void*>(fc_backward_filter_kernel<T>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_filter) != hipSuccess) return FC_ERR_LAUNCH;
-    }
     static const bool half2 = !(getenv("FC_FILTER2") && atoi(getenv("FC_FILTER2")) == 0);      // FC_FILTER2=0: the LDS-staged kernel (development)
+    static bool ok_half2[kMaxDevices] = {}, ok_half[kMaxDevices] = {}, ok_f32[kMaxDevices] = {};      // per T (this function is a template)
     if (p.fhalf && half2) {
         const size_t lds2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
-        if (lds2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
-            return FC_ERR_LAUNCH;
+        if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T>), lds2, ok_half2)) return FC_ERR_LAUNCH;
         hipLaunchKernelGGL(fc_backward_filter_half2_kernel<T>, dim3(p.P, p.F), dim3(kThreads), lds2, stream, x, hdump, gwp, a, p.F, d->B,
                            d->R * d->O);
-    } else if (p.fhalf)
+    } else if (p.fhalf) {
+        if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half_kernel<T>), p.lds_filter, ok_half)) return FC_ERR_LAUNCH;
         hipLaunchKernelGGL(fc_backward_filter_half_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a,
                            p.F, d->B, d->R * d->O);
-    else
+    } else {
+        if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_kernel<T>), p.lds_filter, ok_f32)) return FC_ERR_LAUNCH;
         hipLaunchKernelGGL(fc_backward_filter_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a, p.F,
                            d->B);
+    }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

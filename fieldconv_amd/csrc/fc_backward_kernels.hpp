@@ -455,11 +455,8 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
                                 float2* gx, float* hdump, const BwdArgs& a, const BwdPlan& p, hipStream_t stream) {
     auto kern = fc_backward_data_kernel<R, B, FACTORED, SPLIT>;
     const size_t lds = FACTORED ? p.lds_data_factored : p.lds_data;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return FC_ERR_LAUNCH;
-    }
+    static bool lds_ok[kMaxDevices] = {};        // per kernel instantiation (this function is a template)
+    if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
     const int grid = FACTORED ? (p.ntiles < kNumCUs ? p.ntiles : kNumCUs) : p.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, gx,
                        hdump, a);

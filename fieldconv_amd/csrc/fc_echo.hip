@@ -257,9 +257,8 @@ int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const
     const size_t lds = (size_t)(fc::kEchoMaxCells + 3 + fc::kEchoWaves * C * dS * 2) * sizeof(float);
     if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
     auto kern = fc::echo_forward_kernel;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return FC_ERR_LAUNCH;
+    static bool lds_ok[fc::kMaxDevices] = {};
+    if (!fc::allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
     const int wpv = fc::echo_waves_per_vertex(N, E);
     const int per_wg = fc::kEchoWaves / wpv;
     hipLaunchKernelGGL(kern, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), lds,

@@ -489,11 +489,8 @@ static int launch_forward(const float2* x, const float* sten, const fc_csr* g, c
                           const FwdArgs& a, size_t lds_bytes, int grid, hipStream_t stream) {
     auto kern = KIND == 2 ? fc_forward_factored_kernel<R, B, SPLIT, true>
                 : KIND == 1 ? fc_forward_factored_kernel<R, B, SPLIT, false> : fc_forward_kernel<R, B, SPLIT>;
-    if (lds_bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess)
-            return FC_ERR_LAUNCH;
-    }
+    static bool lds_ok[kMaxDevices] = {};        // per kernel instantiation (this function is a template)
+    if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok)) return FC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, x, sten, g->rowptr, KIND ? g->runs : g->nbr, wpk, y, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }

@@ -34,6 +34,20 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised -- once per
+// function and device, not per launch (the call costs a few microseconds of host time).  `done`: a static flag array of
+// the calling launcher (one per kernel instantiation).
+constexpr int kMaxDevices = 16;
+inline bool allow_full_lds(const void* fn, size_t lds_bytes, bool (&done)[kMaxDevices]) {
+    if (lds_bytes <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < kMaxDevices && done[dev]) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess) return false;
+    if (dev >= 0 && dev < kMaxDevices) done[dev] = true;
+    return true;
+}
 // LDS budget of the factored kernels in the current MFMA mode (the dense kernels need less)
 bool forward_fits(const fc_dims* d);
 bool backward_fits(const fc_dims* d);
