@@ -446,7 +446,8 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
     a.tails = p.fhalf;
-    { const char* e = getenv("FC_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
+    static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
+    a.dbg = dbg;
     return a;
 }
 

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
 
 // wavefronts per vertex: spread large supports over the workgroup when the mesh alone cannot fill the chip
 static int echo_waves_per_vertex(int N, int E) {
-    if (const char* e = getenv("FC_ECHO_WPV")) return atoi(e);       // development
+    static const int forced = [] { const char* e = getenv("FC_ECHO_WPV"); return e ? atoi(e) : 0; }();       // development, read once
+    if (forced) return forced;
     const long deg = N > 0 ? (long)E / N : 0;
     if (deg >= 64 && N < 65536) return 4;
     if (deg >= 32 && N < 131072) return 2;

@@ -516,7 +516,8 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
     a.part_stride = (uint32_t)forward_part_stride(d);
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, a.g.split) * sizeof(float));
-    { const char* e = getenv("FC_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();       // read once per process
+    a.dbg = dbg;
     a.ring_chunks = factored ? kRingChunks : 0;
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;
     a.slabs = (SPLIT && partial_floats(a.g.NKP, a.g.MP) <= slab_floats(a.g) &&

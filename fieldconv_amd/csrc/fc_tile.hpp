@@ -304,8 +304,7 @@ inline int edge_parts_log2(const fc_dims* d) {
     if (d->N <= 0) return 0;
     const int ntiles = (d->N + kTile - 1) / kTile;
     const long deg = (long)d->E / d->N;
-    int cap = 3;
-    if (const char* e = getenv("FC_EDGE_PARTS_MAX")) cap = atoi(e);
+    static const int cap = [] { const char* e = getenv("FC_EDGE_PARTS_MAX"); return e ? atoi(e) : 3; }();       // read once per process
     int pl = 0;
     while (pl < cap && (ntiles << (pl + 1)) <= kNumCUs && (deg >> (pl + 1)) >= 8) ++pl;
     return pl;
