@@ -520,13 +520,18 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     a.dbg = dbg;
     a.ring_chunks = factored ? kRingChunks : 0;
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;
-    a.slabs = (SPLIT && partial_floats(a.g.NKP, a.g.MP) <= slab_floats(a.g) &&
-               forward_lds_floats(a.g, 2) * sizeof(float) + ring <= kMaxLds) ? 2 : 1;
-    const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;
-    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
     const int nvt = a.ntiles << a.parts_log2;
     const int grid = factored ? (nvt < kNumCUs ? nvt : kNumCUs) : a.ntiles;
+    // With two slab buffers the epilogue parks its fp32 k-partials in the idle one.  A workgroup that walks several
+    // tiles would then read those bits back as halves in the k padding [R*KI, KP) of the next tile's slab rows (the
+    // padding is zeroed once, before the tile loop), and 0 x NaN poisons the accumulators: shapes with k padding
+    // keep the partials in their own region whenever a workgroup sees more than one tile.
+    const bool aliasing_hazard = a.g.KP > d->R * a.g.KI && grid < nvt;
+    a.slabs = (SPLIT && !aliasing_hazard && partial_floats(a.g.NKP, a.g.MP) <= slab_floats(a.g) &&
+               forward_lds_floats(a.g, 2) * sizeof(float) + ring <= kMaxLds) ? 2 : 1;
+    const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;
+    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     int rc = FC_ERR_UNSUPPORTED;
 #define FC_CASE(RR, BB)                                                                                              \
     if (d->R == RR && d->B == BB) {                                                                                  \

@@ -104,7 +104,7 @@ def _rcb_order(pts, parts):
     return np.concatenate(pieces), bounds
 
 
-def sphere_partition(n_total, parts, rank, k=32, seed=0):
+def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all'):
     """G-geo: `n_total` jittered Fibonacci points on the unit sphere, k nearest neighbours
     (self included) as in-neighbours of every vertex, exact geodesic log map / transport, area
     weights.  The vertices are renumbered so that each of the `parts` compact patches (recursive
@@ -116,6 +116,10 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0):
         n_owned        vertices owned by this rank
         halo_global    (n_halo,) global ids of the remote sources, grouped by owning rank
         owner_bounds   (parts+1,) global index ranges of the patches
+
+    support: 'all' -- the filter radius epsilon lies above every k-NN distance (no edge dropped by FCPrecomp, the outer
+    rings stay empty); 'p95' -- epsilon is the 95-percentile of the k-NN distances (SURVEY 8(d) G-geo): FCPrecomp drops
+    the longest 5 % of the edges and every ring of the radial interpolant is populated.
     """
     from scipy.spatial import cKDTree
     pts = _fibonacci_sphere(n_total, 0, n_total, seed)
@@ -145,6 +149,13 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0):
     # filter radius: 1.5 x the expected k-NN radius sqrt(4k/n) of a uniform sphere sampling; the same
     # on every rank and comfortably above the largest k-NN distance, so no edge is dropped (E = n*k)
     eps = float(1.5 * math.sqrt(4.0 * k / n_total))
+    if support == 'p95':
+        # r^2 of the k nearest neighbours is uniform up to ~4k/n on a uniformly sampled unit sphere; 0.987 of that radius
+        # keeps 95.0 % of the edges of the jittered Fibonacci sampling (measured at n = 20 000, k = 32).  A closed form,
+        # not a quantile of this rank's edges, so that every rank of a partitioned mesh filters with the same radius.
+        eps = float(0.987 * math.sqrt(4.0 * k / n_total))
+    elif support != 'all':
+        raise ValueError("support must be 'all' or 'p95'")
     data = SupportData(
         supp_edges=edges,
         logMag=torch.from_numpy(dist[order]).float(),
@@ -155,7 +166,7 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0):
     return data, n_owned, torch.from_numpy(remote), torch.from_numpy(bounds)
 
 
-def sphere_support(N, k=32, seed=0):
+def sphere_support(N, k=32, seed=0, support='all'):
     """Unpartitioned G-geo mesh (parts=1)."""
-    data, _, _, _ = sphere_partition(N, 1, 0, k=k, seed=seed)
+    data, _, _, _ = sphere_partition(N, 1, 0, k=k, seed=seed, support=support)
     return data

@@ -1,0 +1,72 @@
+"""The kernel families that only run under a development switch, and the RCCL code path with one rank.
+
+The library reads its switches once per process (FC_MFMA, FC_FILTER2, ...) and the support-graph build reads
+FIELDCONV_DENSE / FIELDCONV_NO_GEO, so each mode gets a FRESH child process that runs a compact parity subset of
+this suite (golden FieldConv vectors, seeded oracle shapes incl. a multi-tile mesh, the FCResNetBlock fixtures).
+The children are ordinary `python -m pytest` runs started with subprocess (never an exec of this process)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SUBSET = ('test_fieldconv_golden or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
+          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40')
+
+MODES = {
+    'fp32_mfma': {'FC_MFMA': 'f32'},                    # v_mfma_f32_16x16x4_f32 contractions, fp32 filter-gradient kernel
+    'reduced_f16': {'FC_MFMA': 'f16'},                  # single halves; the suite applies its own 5e-3 gate in this mode
+    'dense_rows': {'FIELDCONV_DENSE': '1'},             # FCPrecomp stencils through the dense-stencil kernels
+    'generic_records': {'FIELDCONV_NO_GEO': '1'},       # 64-byte factored records in the forward pass
+    'lds_staged_filter_kernel': {'FC_FILTER2': '0'},
+    'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
+    'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
+}
+
+
+def _clean_env(extra):
+    env = {k: v for k, v in os.environ.items() if not (k.startswith('FC_') or k.startswith('FIELDCONV_'))}
+    env.update(extra)
+    env.pop('PYTEST_CURRENT_TEST', None)
+    return env
+
+
+@pytest.mark.parametrize('mode', sorted(MODES))
+def test_parity_subset_in_mode(mode):
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'),
+           os.path.join(ROOT, 'tests', 'test_gpu_fullsize.py'), '-m', 'gpu', '-x', '-q', '-p', 'no:cacheprovider', '-k', SUBSET]
+    res = subprocess.run(cmd, cwd=ROOT, env=_clean_env(MODES[mode]), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=1500)
+    tail = '\n'.join(res.stdout.strip().splitlines()[-25:])
+    assert res.returncode == 0, f'mode {mode} ({MODES[mode]}):\n{tail}'
+    assert ' passed' in tail and 'failed' not in tail, tail
+
+
+def test_bench_single_rank_over_rccl():
+    """bench.py with BENCH_FORCE_DIST=1: one rank, but the partition / halo-exchange / all-reduce code of
+    fieldconv_amd.dist runs over the nccl (= RCCL) backend exactly as it does with N > 1."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--verts', '3000', '--no-cpu-baseline',
+           '--no-extras']
+    env = _clean_env({'BENCH_FORCE_DIST': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29531', 'RANK': '0', 'WORLD_SIZE': '1',
+                      'LOCAL_RANK': '0'})
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['steps'] == 3
+
+
+def test_bench_data_parallel_mode_single_rank():
+    """bench.py --mode dp (BASELINE configs[4]: one mesh per rank, replicated net, one bucketed all-reduce) with a
+    single rank over RCCL."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'dp', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--no-extras']
+    env = _clean_env({'BENCH_FORCE_DIST': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29532', 'RANK': '0', 'WORLD_SIZE': '1',
+                      'LOCAL_RANK': '0'})
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and 'data-parallel' in line['config']['parallelism']
