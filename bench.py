@@ -88,7 +88,7 @@ def reduced_precision_run(args, conv, x, edges, sten, step):
             path = os.path.join(tmp, 'rp.pt')
             cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup),
                    '--verts', str(args.verts), '--k', str(args.k), '--channels', str(args.channels), '--band-limit',
-                   str(args.band_limit), '--n-rings', str(args.n_rings), '--no-cpu-baseline', '--no-extras', '--dump', path]
+                   str(args.band_limit), '--n-rings', str(args.n_rings), '--support', args.support, '--no-cpu-baseline', '--no-extras', '--dump', path]
             env = dict(os.environ, FC_MFMA='f16')
             res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
             child = json.loads(res.stdout.strip().splitlines()[-1])
@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--channels', type=int, default=48)
     ap.add_argument('--band-limit', type=int, default=2)
     ap.add_argument('--n-rings', type=int, default=6)
+    ap.add_argument('--support', default='p95', choices=['p95', 'all'],
+                    help="support radius: 'p95' = 95-percentile of the k-NN distances (SURVEY 8(d) G-geo: FCPrecomp drops 5 %% of the "
+                         "edges, every ring populated); 'all' = above every k-NN distance (round-1 mesh: E = N*k, outer rings empty)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the reduced-precision child run)')
     ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (reduced-precision child run)')
@@ -170,7 +173,7 @@ def main():
     B, R, C, k = args.band_limit, args.n_rings, args.channels, args.k
     F = 2 * B + 1
     n_total = args.verts * world
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0)
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support)
     data = data.to(dev)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     n_local = data.num_nodes

@@ -27,12 +27,13 @@ _CP = ctypes.POINTER(FcCsr)
 # name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
 SIGNATURES = {
     'fc_abi_version': (ctypes.c_int, []),
+    'fc_debug_stamp_buffer': (None, [_vp]),
     'fc_status_string': (ctypes.c_char_p, [ctypes.c_int]),
     'fc_supported': (ctypes.c_int, [_DP]),
-    'fc_packed_filter_floats_fwd': (_sz, [_DP]),
-    'fc_packed_filter_floats_bwd': (_sz, [_DP]),
-    'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _vp]),
-    'fc_pack_filter_params': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _vp, _vp, _DP, _vp]),
+    'fc_packed_filter_floats_fwd': (_sz, [_DP, _c_int32]),
+    'fc_packed_filter_floats_bwd': (_sz, [_DP, _c_int32]),
+    'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _c_int32, _vp]),
+    'fc_pack_filter_params': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _vp, _vp, _DP, _c_int32, _vp]),
     'fc_filter_param_grads': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _vp, _vp, _vp, _DP, _vp]),
     'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
     'fc_factored_record_floats': (ctypes.c_int, [_c_int32]),

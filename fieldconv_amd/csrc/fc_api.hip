@@ -32,11 +32,16 @@ static bool rows_fit_32bit(const fc_dims* d) {
     return (uint64_t)d->N * c * 8 < (1ull << 32);
 }
 
+static unsigned long long* g_stamps = nullptr;
+unsigned long long* debug_stamp_buffer() { return g_stamps; }
+
 }  // namespace fc
 
 extern "C" {
 
-int fc_abi_version(void) { return 1; }
+void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
+
+int fc_abi_version(void) { return 2; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -51,26 +56,27 @@ const char* fc_status_string(int s) {
 
 int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0; }
 
-size_t fc_packed_filter_floats_fwd(const fc_dims* d) {
+size_t fc_packed_filter_floats_fwd(const fc_dims* d, int32_t records) {
     if (!fc::dims_valid(d)) return 0;
-    return fc::packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, fc::split_mode());
+    return fc::packed_filter_floats_fwd(d, records);
 }
 
-size_t fc_packed_filter_floats_bwd(const fc_dims* d) {
+size_t fc_packed_filter_floats_bwd(const fc_dims* d, int32_t records) {
     if (!fc::dims_valid(d)) return 0;
-    return fc::packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, fc::split_mode());
+    return fc::packed_filter_floats_bwd(d, records);
 }
 
-int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream) {
+int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
     if (!w_eff || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
-    return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, static_cast<hipStream_t>(stream));
+    return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, records, static_cast<hipStream_t>(stream));
 }
 
 int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype, float* wpk_fwd,
-                          float* wpk_bwd, const fc_dims* dims, void* stream) {
+                          float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
     if (!zonal || !spherical || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (ftype < 0 || ftype > 2 || (ftype == 1 && !phase)) return FC_ERR_BAD_ARGUMENT;
-    return fc::pack_filter_params_impl(zonal, spherical, phase, ftype, wpk_fwd, wpk_bwd, dims, static_cast<hipStream_t>(stream));
+    return fc::pack_filter_params_impl(zonal, spherical, phase, ftype, wpk_fwd, wpk_bwd, dims, records,
+                                       static_cast<hipStream_t>(stream));
 }
 
 int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* spherical, const float* phase, int32_t ftype,

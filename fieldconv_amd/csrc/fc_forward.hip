@@ -10,6 +10,7 @@ extern template int forward_impl_mode<true>(const float*, const float*, const fc
 
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y, const fc_dims* d,
                  int kind, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (kind != 0 && forward_ring_fits(d)) return forward_ring_impl(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream);
     return split_mode() ? forward_impl_mode<true>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream)
                         : forward_impl_mode<false>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream);
 }

@@ -1,0 +1,69 @@
+// FieldConv forward on per-edge records, ring-major kernels (fc_forward_ring.hpp): instantiation and launch.
+#include "fc_forward_ring.hpp"
+#include "fc_forward_kernels.hpp"
+
+namespace fc {
+
+// FC_RING=1 selects the ring-major record kernels for the forward pass (read once per process).  They are an
+// experiment that stays opt-in: parity-green, but on MI355X they run the config-2 layer in 145-170 us against the
+// 150 us of the frequency-major kernel (both are bound by vector-instruction issue at four cycles an
+// instruction and leave the SIMDs idle half of the time; reordering the contraction does not change either).  They
+// exist for the default two-halves mode only.
+bool ring_enabled() {
+    static const bool on = [] { const char* e = getenv("FC_RING"); return e && atoi(e) != 0; }();
+    return on && split_mode() == 2;
+}
+
+bool forward_ring_fits(const fc_dims* d) {
+    return ring_enabled() && plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok;
+}
+
+size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {
+    const MmaGeom g = ring_geom(M, F, channels, halves);
+    return (size_t)g.MP + (size_t)R * halves * g.MP * g.KP;
+}
+
+template <int R, int B, bool GEO>
+static int launch_forward_ring(const float2* x, const float* rec, const fc_csr* g, const float* wpk, float2* y, const RingArgs& a,
+                               size_t lds, int grid, hipStream_t stream) {
+    auto kern = fc_forward_ring_kernel<R, B, GEO>;
+    static bool lds_ok[kMaxDevices] = {};
+    if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, rec, g->rowptr, g->runs, wpk, y, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,
+                      void* ws, size_t ws_bytes, hipStream_t stream) {
+    const int F = 2 * d->B + 1;
+    const RingPlan p = plan_ring(d->O, F, d->I, split_mode());
+    if (!p.ok) return FC_ERR_UNSUPPORTED;
+    RingArgs a;
+    a.N = d->N; a.I = d->I; a.O = d->O;
+    a.g = p.g;
+    a.ntiles = (d->N + kTile - 1) / kTile;
+    a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
+    a.part_stride = (uint32_t)forward_part_stride(d);
+    a.NS = p.NS;
+    a.nr = p.nr;
+    a.wpk_bytes = (uint32_t)(packed_ring_image_floats(d->O, F, d->I, d->R, p.g.split) * sizeof(float));
+    a.slab_bytes_w = (uint32_t)(2 * p.g.split * p.g.MP * p.g.KP * 2);
+    static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    a.stamps = debug_stamp_buffer();
+    const int nvt = a.ntiles << a.parts_log2;
+    const int grid = nvt < kNumCUs ? nvt : kNumCUs;
+    int rc = FC_ERR_UNSUPPORTED;
+    const float2* x2 = reinterpret_cast<const float2*>(x);
+    float2* y2 = reinterpret_cast<float2*>(a.parts_log2 ? static_cast<float*>(ws) : y);
+#define FC_CASE(RR, BB)                                                                                    \
+    if (d->R == RR && d->B == BB)                                                                          \
+        rc = kind == 2 ? launch_forward_ring<RR, BB, true>(x2, rec, g, wpk, y2, a, p.lds, grid, stream)    \
+                       : launch_forward_ring<RR, BB, false>(x2, rec, g, wpk, y2, a, p.lds, grid, stream);
+    FC_FOR_EACH_SHAPE(FC_CASE)
+#undef FC_CASE
+    if (rc != FC_OK || a.parts_log2 == 0) return rc;
+    return sum_parts(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, stream);
+}
+
+}  // namespace fc

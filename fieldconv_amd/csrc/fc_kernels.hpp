@@ -27,13 +27,26 @@ int backward_data_impl(const float* x, const float* gy, const float* sten, const
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);
 int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
-int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream);
+// records != 0: images for the record-driven entry points (fc_forward_factored / _geometric, fc_backward_fused)
+int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream);
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
-                            float* wpk_bwd, const fc_dims* d, hipStream_t stream);
+                            float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream);
+size_t packed_filter_floats_fwd(const fc_dims* d, int records);
+size_t packed_filter_floats_bwd(const fc_dims* d, int records);
+
+// ring-major record kernels (fc_forward_ring.hpp)
+bool ring_enabled();
+bool forward_ring_fits(const fc_dims* d);
+size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves);
+int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,
+                      void* ws, size_t ws_bytes, hipStream_t stream);
 int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
+
+// development: device buffer that receives in-kernel time stamps (fc_debug_stamp_buffer), or nullptr
+unsigned long long* debug_stamp_buffer();
 
 // Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised -- once per
 // function and device, not per launch (the call costs a few microseconds of host time).  `done`: a static flag array of

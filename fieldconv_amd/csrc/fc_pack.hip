@@ -9,6 +9,7 @@
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
 #include "fc_tile.hpp"
+#include "fc_forward_ring.hpp"
 
 namespace fc {
 
@@ -47,6 +48,8 @@ struct PackArgs {
     int O, I, R, F, B, ftype;
     MmaGeom gf, gb;          // forward / backward contraction geometry (with their modes)
     unsigned blocks_f;       // workgroups that write the forward image; the rest write the backward image
+    int ring_f;              // forward image in ring-major layout (fc_forward_ring.hpp): one slab of planes per RING,
+                             // k = f*KI + i inside it, instead of one per frequency with k = r*KI + i
 };
 
 constexpr int kPackThreads = 256;
@@ -55,9 +58,12 @@ constexpr int kPackThreads = 256;
 template <bool FROM_PARAMS, bool WITH_PHASE>
 __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, const float* __restrict__ zonal,
                                                const float* __restrict__ sph, const float* __restrict__ phase,
-                                               const PackArgs& a, bool is_bwd, int m, int k, int f) {
+                                               const PackArgs& a, bool is_bwd, int m, int k, int slab) {
     const int KI = is_bwd ? a.gb.KI : a.gf.KI;          // k = r*KI + c, channels c >= their count are padding
-    const int r = k / KI, c = k - r * KI;
+    const bool ring = !is_bwd && a.ring_f;              // ring-major: slab = r, k = f*KI + c
+    const int kk = k / KI, c = k - kk * KI;
+    const int r = ring ? slab : kk, f = ring ? kk : slab;
+    if (f >= a.F) return make_float2(0.f, 0.f);
     const int o = is_bwd ? c : m, i = is_bwd ? m : c;
     if (o >= a.O || i >= a.I || r >= a.R) return make_float2(0.f, 0.f);
     const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!WITH_PHASE && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.I, o, i, r, f)
@@ -90,9 +96,10 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
     // (all frequencies): it bounds both components, needs no phase factor (|c e^{i phi}| = |c|), and every
     // workgroup of the row recomputes it cheaply instead of synchronising.
     __shared__ float red[kPackThreads / kWave];
-    const int m = blk / a.F, f = blk - m * a.F;
+    const int nslab = (!is_bwd && a.ring_f) ? a.R : a.F;     // slabs of planes in the image
+    const int m = blk / nslab, f = blk - m * nslab;
     float mx = 0.f;
-    for (int idx = threadIdx.x; idx < a.F * g.KP; idx += kPackThreads) {
+    for (int idx = threadIdx.x; idx < nslab * g.KP; idx += kPackThreads) {
         const int ff = idx / g.KP, k = idx - ff * g.KP;
         const float2 v = packed_value<FROM_PARAMS, false>(w, zonal, sph, phase, a, is_bwd, m, k, ff);
         mx = fmaxf(mx, v.x * v.x + v.y * v.y);
@@ -125,31 +132,43 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
     }
 }
 
-static unsigned pack_blocks(const MmaGeom& g, int F) {
+static unsigned pack_blocks(const MmaGeom& g, int F) {      // F: slabs of planes in the image
     return g.split ? (unsigned)(g.MP * F) : (unsigned)(((size_t)F * 2 * g.MP * g.KP + kPackThreads - 1) / kPackThreads);
+}
+
+static bool ring_forward_image(const fc_dims* d, int records) { return records && forward_ring_fits(d); }
+
+size_t packed_filter_floats_fwd(const fc_dims* d, int records) {
+    if (ring_forward_image(d, records)) return packed_ring_image_floats(d->O, 2 * d->B + 1, d->I, d->R, split_mode());
+    return packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, split_mode());
+}
+size_t packed_filter_floats_bwd(const fc_dims* d, int records) {
+    (void)records;
+    return packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, split_mode());
 }
 
 template <bool FROM_PARAMS>
 static int launch_pack(const float* w_eff, const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
-                       float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
+                       float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream) {
     PackArgs a;
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
-    a.gf = make_mma_geom(d->O, d->R, d->I, split_mode());
+    a.ring_f = ring_forward_image(d, records) ? 1 : 0;
+    a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
-    a.blocks_f = pack_blocks(a.gf, a.F);
+    a.blocks_f = pack_blocks(a.gf, a.ring_f ? a.R : a.F);
     const unsigned blocks = a.blocks_f + pack_blocks(a.gb, a.F);
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,
                        reinterpret_cast<const float2*>(w_eff), zonal, sph, phase, wpk_fwd, wpk_bwd, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
-    return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, stream);
+int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream) {
+    return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, records, stream);
 }
 
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
-                            float* wpk_bwd, const fc_dims* d, hipStream_t stream) {
-    return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, stream);
+                            float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream) {
+    return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, records, stream);
 }
 
 int split_mode() {

@@ -134,7 +134,7 @@ class _FieldConvFn(torch.autograd.Function):
             st = _stream()
             wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
             wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
-            check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), st), 'fc_pack_filter')
+            check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), plan.records, st), 'fc_pack_filter')
             y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
@@ -156,7 +156,7 @@ class _FieldConvFn(torch.autograd.Function):
 class _ConvPlan:
     """What every launch of one (graph, in, out, band limit) combination needs and never changes: the dims struct, the
     grouping structs, buffer sizes.  Cached on the graph: ~15 ctypes calls per convolution otherwise."""
-    __slots__ = ('dims', 'dref', 'n_fwd', 'n_bwd', 'ws_fwd', 'ws_bwd', 'csr_t', 'csr_s', 'cref_t', 'cref_s')
+    __slots__ = ('dims', 'dref', 'n_fwd', 'n_bwd', 'ws_fwd', 'ws_bwd', 'csr_t', 'csr_s', 'cref_t', 'cref_s', 'records')
 
 
 def _conv_plan(lib, graph, I, O, B):
@@ -171,8 +171,9 @@ def _conv_plan(lib, graph, I, O, B):
         raise _lib.FieldConvNativeError(
             f'FieldConv(in={I}, out={O}, n_rings={graph.R}, band_limit={B}) is outside the compiled HIP kernels '
             '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
-    plan.n_fwd = lib.fc_packed_filter_floats_fwd(plan.dref)
-    plan.n_bwd = lib.fc_packed_filter_floats_bwd(plan.dref)
+    plan.records = 1 if graph.factored else 0      # which entry-point family the packed filter images are for
+    plan.n_fwd = lib.fc_packed_filter_floats_fwd(plan.dref, plan.records)
+    plan.n_bwd = lib.fc_packed_filter_floats_bwd(plan.dref, plan.records)
     plan.ws_bwd = lib.fc_backward_workspace_bytes(plan.dref)
     plan.ws_fwd = 0
     if graph.factored and os.environ.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1':
@@ -239,7 +240,7 @@ class _FieldConvParamFn(torch.autograd.Function):
             wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
             wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
             check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), ctypes.byref(dims),
-                                            st), 'fc_pack_filter_params')
+                                            plan.records, st), 'fc_pack_filter_params')
             y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
         ctx.graph, ctx.ftype, ctx.wshape = graph, ftype, (O, I, R, F)

@@ -54,6 +54,9 @@ typedef struct fc_csr {
 } fc_csr;
 
 int fc_abi_version(void);
+/* Development only (tools/stamps.py): a device buffer of 16 x 256 uint64 that the record-driven kernels fill with in-kernel
+ * time stamps of workgroup 0 (label << 56 | s_memtime), or NULL to switch the stamps off (the default).  Process-wide. */
+void fc_debug_stamp_buffer(void* device_buffer);
 const char* fc_status_string(int status);
 
 /* 1 if the compiled kernels cover these dims, 0 otherwise (then every call returns FC_ERR_UNSUPPORTED for them):
@@ -71,15 +74,20 @@ int fc_supported(const fc_dims* dims);
  *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves,
  *   forward rows o, k = r*ceil8(I) + i;  backward rows i, k = r*ceil8(O) + o, conjugated;
  *   OP = ceil16(rows), KP = ceil32(R * ceil8(channels)).
- * With FC_MFMA=f32 in the environment: F x {re,im} x OP x ceil16(R*channels) floats. */
-size_t fc_packed_filter_floats_fwd(const fc_dims* dims);
-size_t fc_packed_filter_floats_bwd(const fc_dims* dims);
-int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
+ * With FC_MFMA=f32 in the environment: F x {re,im} x OP x ceil16(R*channels) floats.
+ * `records`: which family of convolution entry points the images are for -- 0: the dense-stencil ones (fc_forward,
+ * fc_backward_data), 1: the record-driven ones (fc_forward_factored, fc_forward_geometric, fc_backward_data_factored).
+ * In the default mode the record-driven forward image is RING-major: OP inverse row scales, then
+ * R x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves with k = f*ceil8(I) + i, KP = ceil32(F * ceil8(I))
+ * (csrc/fc_forward_ring.hpp); sizes differ between the two families, ask with the same `records`. */
+size_t fc_packed_filter_floats_fwd(const fc_dims* dims, int32_t records);
+size_t fc_packed_filter_floats_bwd(const fc_dims* dims, int32_t records);
+int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream);
 /* Same, assembling W_eff on the fly from the module parameters exactly as reference
  * nn/field_conv.py:10-33 does (zonal (O,I,R[,2]), spherical (O,I,R,B|2B,2), phase (O,I,B+1), all fp32
  * contiguous; ftype 0/1/2 as in :53-59; phase is read for ftype 1 only). */
 int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype,
-                          float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, void* stream);
+                          float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream);
 /* Autograd twin of the assembly: dL/dW_eff (O,I,R,F) c64 -> gradients shaped like the parameters
  * (overwritten; g_phase written for ftype 1 only). */
 int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* spherical, const float* phase,

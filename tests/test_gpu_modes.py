@@ -25,6 +25,7 @@ MODES = {
     'lds_staged_filter_kernel': {'FC_FILTER2': '0'},
     'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
     'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
+    'ring_major_forward': {'FC_RING': '1'},              # opt-in ring-major forward kernels (csrc/fc_forward_ring.hpp)
 }
 
 

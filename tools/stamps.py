@@ -1,0 +1,93 @@
+"""In-kernel timeline of workgroup 0 of the record-driven kernels (development).
+
+    python tools/stamps.py [fwd|bwd] [--wave W ...]
+
+Runs the config-2 layer a few times, then once with the stamp buffer armed (fc_debug_stamp_buffer), and prints for the
+chosen wavefronts the cycles between consecutive stamps, labelled as in the kernel source."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__  # noqa: E402
+
+LABELS_FWD = {0: 'run gathered', 1: 'flush: buffer free', 2: 'flush: row stored+arrived', 3: 'contract: slab full', 4: 'contract: mma done',
+              5: 'first_rows issued', 6: 'epi: partial stored', 7: 'epi: all partials in', 8: 'epi: y stored', 10: 'tile start'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('which', nargs='?', default='fwd')
+    ap.add_argument('--wave', type=int, nargs='*', default=[0, 7, 15])
+    ap.add_argument('--tiles', type=int, default=2)
+    args = ap.parse_args()
+    __graft_entry__.build()
+    from fieldconv_amd import _lib
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import FieldConv
+    from fieldconv_amd.transforms import FCPrecomp
+    dev = torch.device('cuda:0')
+    N, k, C, B, R = 20000, 32, 48, 2, 6
+    data = sphere_support(N, k, support='p95').to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    conv = FieldConv(C, C, band_limit=B, n_rings=R).to(dev)
+    x = torch.randn(N, C, dtype=torch.cfloat, device=dev).requires_grad_(True)
+    gy = torch.randn(N, C, dtype=torch.cfloat, device=dev)
+    params = list(conv.parameters())
+
+    def step():
+        y = conv(x, edges, sten)
+        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    buf = torch.zeros(16 * 256, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    if args.which == 'fwd':
+        with torch.no_grad():
+            conv(x, edges, sten)
+    else:
+        step()
+    torch.cuda.synchronize()
+    lib.fc_debug_stamp_buffer(None)
+    st = buf.cpu().view(16, 256)
+    labels = LABELS_FWD
+    t0 = min(int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0]))
+    # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
+    import collections
+    print('per-wave cycles by phase (whole launch):')
+    names = sorted(labels)
+    print('wave ' + ' '.join(f'{labels[k][:14]:>15s}' for k in names) + '   total')
+    for w in range(16):
+        acc = collections.Counter()
+        prev = None
+        for v in st[w].tolist():
+            if v == 0:
+                break
+            lab, t = (v >> 56) & 0xff, v & ((1 << 56) - 1)
+            if prev is not None:
+                acc[lab] += t - prev
+            prev = t
+        print(f'{w:4d} ' + ' '.join(f'{acc[k]:15d}' for k in names) + f'  {sum(acc.values()):7d}')
+    for w in args.wave:
+        print(f'--- wave {w}')
+        prev = None
+        tiles = 0
+        for v in st[w].tolist():
+            if v == 0:
+                break
+            lab, t = (v >> 56) & 0xff, v & ((1 << 56) - 1)
+            if lab == 10:
+                tiles += 1
+                if tiles > args.tiles:
+                    break
+            print(f'  {t - t0:9d}  +{0 if prev is None else t - prev:7d}  {labels.get(lab, lab)}')
+            prev = t
+
+
+if __name__ == '__main__':
+    main()

@@ -24,9 +24,9 @@ x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
 gy = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
 W = (torch.complex(torch.randn(C, C, R, 2 * B + 1, generator=g), torch.randn(C, C, R, 2 * B + 1, generator=g)) * 0.05).to(dev)
 dims = make_dims(graph, C, C, B)
-wf = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims)), device=dev)
-wb = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims)), device=dev)
-lib.fc_pack_filter(_p(W), _p(wf), _p(wb), ctypes.byref(dims), _stream())
+wf = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims), 0), device=dev)
+wb = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims), 0), device=dev)
+lib.fc_pack_filter(_p(W), _p(wf), _p(wb), ctypes.byref(dims), 0, _stream())
 y = torch.empty(N, C, dtype=torch.cfloat, device=dev)
 gx = torch.empty_like(x)
 gw = torch.empty_like(W)
