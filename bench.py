@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the FieldConv hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode layer|dp] [--support p95|all]
 
-A step = one FieldConv layer forward + backward (input gradient, filter-parameter gradients, the
-filter assembly and its autograd chain included) on a synthetic sphere mesh of 20 000 vertices per
-GPU, k = 32 in-neighbours, C = 48 -> 48 channels, band_limit 2, n_rings 6, ftype 1, fp32 -- the
-shape BASELINE.json's metric is quoted on.  With N > 1 (launched by torch.distributed.run, one rank
-per GPU) the mesh has N x 20 000 vertices, is partitioned into N latitude bands, and every step
-also runs the one-hop halo exchange (forward and transposed) and the all-reduce of the parameter
-gradients over RCCL: weak scaling.  Inputs are resident in HBM before the timed region; support
-graph preprocessing (CSR by target / by source, stencil permutation) is done once outside it and
-reported separately, as it is shared by every convolution of a network.
+--mode layer (default, the metric of record).  A step = one FieldConv layer forward + backward (input gradient,
+filter-parameter gradients, the filter assembly and its autograd chain included) on a synthetic sphere mesh of
+20 000 vertices per GPU, k = 32 nearest neighbours, support radius = 95-percentile of the k-NN distances (SURVEY 8(d)
+G-geo: FCPrecomp drops the longest 5 % of the edges, every ring populated), C = 48 -> 48 channels, band_limit 2,
+n_rings 6, ftype 1 -- the shape BASELINE.json's metric is quoted on.  With N > 1 (launched by torch.distributed.run,
+one rank per GPU) the mesh has N x 20 000 vertices, is partitioned into N compact patches, and every step also runs
+the one-hop halo exchange (forward and transposed) and one bucketed all-reduce of the parameter gradients over RCCL:
+weak scaling.
 
-Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
+--mode dp (BASELINE configs[4]).  Every rank holds its own FAUST-sized mesh (4 999 vertices, k = 28) and a replica of
+the correspondence network's topology (reference correspondence.ipynb: LiftBlock, eight FCResNetBlocks with
+TangentPerceptron meta-residuals, ECHOBlock) at C = 64, band_limit 3; a step = forward + loss + backward + ONE
+bucketed all-reduce of all parameter gradients (fieldconv_amd.dist.GradientBuckets).  value = edges x convolutions per
+second over all ranks.
+
+Inputs are resident in HBM before the timed region; support-graph preprocessing is done once outside it and reported
+separately, as it is shared by every convolution of a network.  Rank 0 prints one JSON line (README / DESIGN.md).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -29,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 MFMA == fp32 vector peak on gfx950
+DTYPE = 'f32 (complex64 in/out; contractions on f16 MFMA with every operand split into two halves, fp32 accumulate)'
 
 
 def algorithmic_bytes(N, E, I, O, R, F):
@@ -39,86 +48,456 @@ def algorithmic_bytes(N, E, I, O, R, F):
     return fwd, bwd
 
 
-def algorithmic_flops(N, E, I, O, R, F):
-    gather = 8 * E * I * R * F
+def algorithmic_flops(N, E, I, O, R, F, factored):
+    """Real FLOPs of what the kernels evaluate.  Gather: dense stencil = R*F complex multiply-adds per (edge, channel)
+    (8 FLOP each); record-driven = (2+2B) complex products (6) for the rotated, phased copies plus 2F real-times-complex
+    multiply-adds (4) for the two rings.  Contraction: N*O*I*R*F complex multiply-adds, once forward, twice backward."""
+    B = (F - 1) // 2
+    gather = E * I * (((2 + 2 * B) * 6 + 2 * F * 4) if factored else 8 * R * F)
     gemm = 8 * N * O * I * R * F
-    return gather + gemm, gather + 2 * gemm       # fwd, bwd (H gather + two contractions)
+    return gather + gemm, gather + 2 * gemm
 
 
-def cpu_baseline(B, R, C, k, threads):
-    """Reference algorithm (oracle/reference_port_torch.py) on the host cores, bounded sample."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(args, threads):
+    """The reference's algorithm (oracle/reference_port_torch.py: materialised (E,C,R,F) product, index-add, broadcast
+    multiply-and-sum, torch autograd) on the host cores at the METRIC'S OWN config: the 20 000-vertex mesh, processed in
+    target slabs of 4 000 vertices because the reference's temporaries need ~32 GB for the whole mesh (BASELINE.md
+    section 3); every slab is a full forward + backward of its targets.  Plus a one-thread figure on one 1 000-target slab."""
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.nn import FieldConv
     from oracle import reference_port_torch as port
     from oracle.torch_composites import FCPrecomp              # the CPU leg's stencil comes from the oracle as well
-    n_s = 2500
-    torch.set_num_threads(threads)
-    data = sphere_support(n_s, k=k, seed=1)
+    B, R, C, k, N = args.band_limit, args.n_rings, args.channels, args.k, args.verts
+    data = sphere_support(N, k=k, seed=0, support=args.support)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     g = torch.Generator().manual_seed(1)
-    x = torch.complex(torch.randn(n_s, C, generator=g), torch.randn(n_s, C, generator=g)).requires_grad_(True)
-    gy = torch.complex(torch.randn(n_s, C, generator=g), torch.randn(n_s, C, generator=g))
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
+    gy = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
     conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1)       # parameter container only (CPU)
     params = [conv.zonal, conv.spherical, conv.phase]
+    order = torch.argsort(edges[:, 1], stable=True)
+    e_t, s_t = edges[order], sten[order]
+    rowptr = torch.searchsorted(e_t[:, 1].contiguous(), torch.arange(N + 1))
 
-    def step():
-        y = port.field_conv(x, edges, sten, conv.zonal, conv.spherical, conv.phase, 1, B)
-        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
-    step()
-    best = float('inf')
-    for _ in range(4):                     # ~2 s per step on 128 cores: ~10 s of CPU work in all
-        t0 = time.perf_counter()
-        step()
-        best = min(best, time.perf_counter() - t0)
-    E = edges.shape[0]
-    return {'value': E / best / 1e6, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
-            'sample': f'reference-structured torch CPU port (oracle/reference_port_torch.py), one FieldConv fwd+bwd on a '
-                      f'{n_s}-vertex sphere mesh, k={k}, C={C}, B={B}, R={R} (E={E}); best of 4 after 1 warm-up, '
-                      f'{best:.2f} s per step'}
+    def run(slab, lo_hi):
+        total_e, t0 = 0, time.perf_counter()
+        for lo in range(lo_hi[0], lo_hi[1], slab):
+            hi = min(lo + slab, lo_hi[1])
+            a, b = int(rowptr[lo]), int(rowptr[hi])
+            es = e_t[a:b].clone()
+            es[:, 1] -= lo
+            xs = x.clone().requires_grad_(True)
+            y = port.field_conv(xs, es, s_t[a:b], conv.zonal, conv.spherical, conv.phase, 1, B, n_out=hi - lo)
+            torch.autograd.grad(y, [xs] + params, grad_outputs=gy[lo:hi])
+            total_e += b - a
+        return total_e, time.perf_counter() - t0
+
+    torch.set_num_threads(threads)
+    run(1000, (0, 1000))                                        # warm-up (allocator, thread pool)
+    e_all, t_all = run(4000, (0, N))
+    torch.set_num_threads(1)
+    e_one, t_one = run(1000, (0, 1000))
+    torch.set_num_threads(threads)
+    return {'value': e_all / t_all / 1e6, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+            'one_thread': {'value': e_one / t_one / 1e6, 'unit': 'Medges/s', 'sample': f'targets 0..999 of the same mesh ({e_one} edges), '
+                                                                                        f'{t_one:.1f} s'},
+            'sample': f'reference-structured torch CPU port (oracle/reference_port_torch.py), one FieldConv fwd+bwd over the whole '
+                      f'{N}-vertex mesh (E={e_all}, k={k}, C={C}, B={B}, R={R}) in target slabs of 4000 vertices, {threads} threads: '
+                      f'{t_all:.1f} s'}
 
 
-def reduced_precision_run(args, conv, x, edges, sten, step):
-    """Extra, reported separately (BASELINE configs[1] names bf16/fp32): the same workload with the contractions
-    on single f16 halves (FC_MFMA=f16, fp32 accumulation) in a child process -- the mode is fixed per process --
-    and its deviation from this process's fp32-grade result on the same seeded inputs."""
-    import subprocess
-    import tempfile
+def child_run(args, env_extra, extra_args=(), dump=True):
+    """The same workload in a child process (library switches are fixed per process); returns (json line, dumped y / gx)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'out.pt')
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup),
+               '--verts', str(args.verts), '--k', str(args.k), '--channels', str(args.channels), '--band-limit',
+               str(args.band_limit), '--n-rings', str(args.n_rings), '--support', args.support, '--no-cpu-baseline', '--no-extras']
+        cmd += list(extra_args)
+        if dump:
+            cmd += ['--dump', path]
+        env = {k_: v for k_, v in os.environ.items() if not k_.startswith('FC_')}
+        env.update(env_extra)
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        ref = torch.load(path) if dump else None
+    return line, ref
+
+
+def other_mode(args, env_extra, what, y, gx):
+    """Extra, reported separately: the same workload in another arithmetic mode of the library, and the deviation of its
+    result from this process's default-mode result on the same seeded inputs."""
     try:
-        with tempfile.TemporaryDirectory() as tmp:
-            path = os.path.join(tmp, 'rp.pt')
-            cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup),
-                   '--verts', str(args.verts), '--k', str(args.k), '--channels', str(args.channels), '--band-limit',
-                   str(args.band_limit), '--n-rings', str(args.n_rings), '--support', args.support, '--no-cpu-baseline', '--no-extras', '--dump', path]
-            env = dict(os.environ, FC_MFMA='f16')
-            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            child = json.loads(res.stdout.strip().splitlines()[-1])
-            ref = torch.load(path)
-        gx = step()[0].detach().cpu()
-        y = conv(x, edges, sten).detach().cpu()
+        child, ref = child_run(args, env_extra)
         err = lambda a, b: float((a - b).abs().max() / b.abs().max())
-        return {'mfma': 'single f16 halves with per-row power-of-two scales, fp32 accumulation (FC_MFMA=f16)',
-                'value': child['value'], 'unit': child['unit'], 'ms_per_step': child['ms_per_step'],
-                'max_rel_err_y_vs_default': err(ref['y'], y), 'max_rel_err_gx_vs_default': err(ref['gx'], gx)}
+        return {'mfma': what, 'value': child['value'], 'unit': child['unit'], 'ms_per_step': child['ms_per_step'],
+                'kernel_us': {k_: round(v['avg_ms'] * 1e3, 1) for k_, v in child.get('kernels', {}).items()},
+                'max_rel_dev_y_vs_default': err(ref['y'], y), 'max_rel_dev_gx_vs_default': err(ref['gx'], gx)}
     except Exception as exc:
         return {'value': None, 'note': f'failed: {type(exc).__name__}: {exc}'}
+
+
+def committed_counters(kernel_names):
+    """Counter-derived figures cannot be taken inside the timed run (rocprofv3 serialises the kernels); they come from
+    the committed rocprof passes of the same command, stamped with the digest of the sources the library was built
+    from: a kernel change makes them stale, and stale numbers are not reported."""
+    from fieldconv_amd.build import _source_digest
+    out = {'source': 'profiles/pmc_counters.json', 'stale': None}
+    path = os.path.join(ROOT, 'profiles', 'pmc_counters.json')
+    if not os.path.exists(path):
+        out['stale'] = 'missing'
+        return out, {}
+    try:
+        blob = json.load(open(path))
+    except Exception:
+        out['stale'] = 'unreadable'
+        return out, {}
+    out['profiled_library_digest'] = blob.get('library_source_digest')
+    out['stale'] = blob.get('library_source_digest') != _source_digest()
+    out['command'] = blob.get('command')
+    per = {}
+    if not out['stale']:
+        for name in kernel_names:
+            per[name] = blob.get('kernels', {}).get(name, {})
+    return out, per
+
+
+def init_dist(dev, backend):
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    # RCCL prints a version banner to stdout when the communicator is created; keep stdout for the JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # the banner sits in C stdio's buffer
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+
+def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None):
+    for _ in range(warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    if before_timed is not None:
+        before_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if backend == 'gloo':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def sum_over_ranks(value, use_dist, dev, backend):
+    if not use_dist:
+        return value
+    t = torch.tensor([value], device=dev, dtype=torch.int64)
+    if backend == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return int(t.item())
+
+
+# ------------------------------------------------------------------------------------------------ mode dp (config 5)
+def run_dp(args, world, rank, dev, use_dist, backend):
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.dist import GradientBuckets
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock, TangentPerceptron
+    from fieldconv_amd.transforms import FCPrecomp
+    N, k, nf, B, R, n_cls = args.dp_verts, args.dp_k, args.dp_channels, args.dp_band_limit, args.n_rings, 64
+    data = sphere_support(N, k=k, seed=100 + rank, support=args.support).to(dev)       # every rank its own mesh
+    pre = FCPrecomp(B, R, data.epsilon)
+    torch.manual_seed(1234)                                                           # identical replicas
+    blocks = [FCResNetBlock(16, nf, band_limit=B, n_rings=R)] + [FCResNetBlock(nf, nf, band_limit=B, n_rings=R) for _ in range(6)] + \
+             [FCResNetBlock(nf, 16, band_limit=B, n_rings=R, frontload=True)]
+    net = torch.nn.ModuleDict(dict(
+        lift=LiftBlock(3, 16, n_rings=R, ftype=1), blocks=torch.nn.ModuleList(blocks),
+        res=torch.nn.ModuleList([TangentPerceptron(16, nf), TangentPerceptron(nf, nf), TangentPerceptron(nf, nf), TangentPerceptron(nf, 16)]),
+        echo=ECHOBlock(16, nf, n_des=12, n_bins=2, band_limit=B, n_rings=R), lin1=torch.nn.Linear(nf, 256),
+        lin2=torch.nn.Linear(256, n_cls))).to(dev)
+    params = [p for p in net.parameters()]
+    buckets = GradientBuckets(params)
+    g = torch.Generator().manual_seed(200 + rank)
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    labels = torch.randint(0, n_cls, (N,), generator=g).to(dev)
+    n_convs = 2 * len(blocks) + 1
+
+    def step():
+        edges, sten, ln, wxp = pre(data)                       # runs every forward in the reference, too (memoised per mesh)
+        x1 = net['lift'](pos, edges, sten[..., B:B + 2])
+        bl, res = net['blocks'], net['res']
+        x = bl[0](x1, edges, sten)
+        x2 = bl[1](x, edges, sten) + res[0](x1)
+        x = bl[2](x2, edges, sten)
+        x3 = bl[3](x, edges, sten) + res[1](x2)
+        x = bl[4](x3, edges, sten)
+        x4 = bl[5](x, edges, sten) + res[2](x3)
+        x = bl[6](x4, edges, sten)
+        x = bl[7](x, edges, sten) + res[3](x4)
+        h = net['echo'](x, edges, sten, ln, wxp)
+        logits = net['lin2'](torch.relu(net['lin1'](h)))
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        buckets.zero()
+        loss.backward()
+        if use_dist:
+            buckets.all_reduce()                               # the one collective of a data-parallel step
+        return loss
+
+    edges0 = pre(data)[0]
+    E = int(edges0.shape[0])
+    elapsed = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend)
+    E_total = sum_over_ranks(E, use_dist, dev, backend)
+    if rank != 0:
+        return None
+    n_params = sum(p.numel() for p in params)
+    return {
+        'metric': 'FieldConv fwd+bwd Medges/s (config 5: correspondence-net replicas, one mesh per GPU, C=64, M=3)',
+        'value': E_total * n_convs / (elapsed / args.steps) / 1e6, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[4] shape: correspondence-net topology (LiftBlock 3->16, 8 FCResNetBlocks at {nf} channels '
+                               f'with TangentPerceptron meta-residuals, ECHOBlock, 2 linear layers; {n_params} parameters) forward + loss + '
+                               f'backward on one {N}-vertex mesh per GPU, k={k}, band_limit={B}, n_rings={R}; edges counted once per '
+                               f'FieldConv ({n_convs} per network)',
+                   'verts_per_gpu': N, 'edges_per_mesh_rank0': E, 'convs_per_step': n_convs, 'parameters': n_params,
+                   'parallelism': 'single GPU (replica)' if world == 1 and not use_dist else
+                                  f'data-parallel x{world}: one mesh per GPU, one bucketed all-reduce of {4 * buckets.flat.numel()} gradient '
+                                  f'bytes per step over RCCL'},
+        'roofline': None, 'cpu_baseline': None,
+    }
+
+
+# ------------------------------------------------------------------------------------------ mode layer (the metric)
+def run_layer(args, world, rank, dev, use_dist, backend):
+    from fieldconv_amd.data import sphere_partition
+    from fieldconv_amd.dist import GradientBuckets, HaloPlan, halo_exchange, overlap_backward
+    from fieldconv_amd.functional import kernel_timer
+    from fieldconv_amd.graph import SupportGraph, get_graph
+    from fieldconv_amd.nn import FieldConv
+    from fieldconv_amd.transforms import FCPrecomp
+
+    B, R, C, k = args.band_limit, args.n_rings, args.channels, args.k
+    F = 2 * B + 1
+    n_total = args.verts * world
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support)
+    data = data.to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    n_local = data.num_nodes
+    E = int(edges.shape[0])
+    plan = HaloPlan(n_owned, halo_global, bounds, device=dev) if use_dist else None
+
+    torch.manual_seed(1234)                                  # identical parameters on every rank
+    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
+    params = list(conv.parameters())
+    buckets = GradientBuckets(params) if use_dist else None   # parameter gradients land in one flat buffer: one all-reduce, no cat
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g))
+    x[torch.rand(n_owned, C, generator=g) < 0.01] = 0        # 1 % exact zeros (origin-box path)
+    x = x.to(dev).requires_grad_(True)
+    gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
+
+    SupportGraph(edges, sten, n_local)                      # first build pays one-off library initialisation
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    SupportGraph(edges, sten, n_local)                      # steady-state cost of the per-mesh preprocessing
+    torch.cuda.synchronize()
+    prep_ms = (time.perf_counter() - t0) * 1e3
+    mesh_graph = get_graph(edges, sten, n_local)            # the cached instance every convolution will use
+    if plan is not None and os.environ.get('BENCH_NO_OVERLAP', '0') != '1':
+        overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel
+
+    def step():
+        xl = halo_exchange(x, plan) if plan is not None else x
+        y = conv(xl, edges, sten)
+        if plan is not None:
+            y = y[:n_owned]
+        if buckets is None:
+            return torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+        buckets.zero()
+        x.grad = None
+        y.backward(gy)
+        buckets.all_reduce()
+        return (x.grad,) + tuple(p.grad for p in params)
+
+    def arm_timer():
+        kernel_timer.reset(pairs=3 * (args.steps // 4 + 1))
+        kernel_timer.stride = 4            # every 4th launch of each kernel inside the timed region carries a HIP-event pair
+        kernel_timer.enabled = True
+    elapsed = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer)
+    kernel_timer.enabled = False
+    E_total = sum_over_ranks(E, use_dist, dev, backend)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = E_total / (elapsed / args.steps) / 1e6
+    if rank != 0:
+        return None
+
+    factored = bool(mesh_graph.factored)
+    kt = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
+    fwd_b, bwd_b = algorithmic_bytes(n_local, E, C, C, R, F)
+    fwd_f, bwd_f = algorithmic_flops(n_local, E, C, C, R, F, factored)
+    gemm_f = 8 * n_local * C * C * R * F
+    wbytes = 8 * C * C * R * F
+    per_kernel = {}
+    # backward contract bytes split over its two kernels: the data kernel reads stencil, indices, gy, x, W and
+    # writes gx; the filter kernel's contract traffic is x and the filter gradient (its H input is a temporary)
+    for name, nbytes, nflops in (('fc_forward', fwd_b, fwd_f), ('fc_backward_data', bwd_b - wbytes - 8 * n_local * C, bwd_f - gemm_f),
+                                 ('fc_backward_filter', wbytes + 8 * n_local * C, gemm_f)):
+        if name in kt:
+            sec = kt[name] * 1e-3
+            per_kernel[name] = {'avg_ms': kt[name], 'algorithmic_bytes': nbytes, 'GBps': nbytes / sec / 1e9,
+                                'hbm_frac': nbytes / sec / 1e9 / HBM_PEAK_GBS, 'evaluated_flops': nflops,
+                                'TFLOPs': nflops / sec / 1e12,
+                                'flop_rate_vs_fp32_peak': nflops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    counters_meta, counters = committed_counters(list(per_kernel))
+    for name, c in counters.items():
+        for key in ('mfma_busy', 'valu_busy', 'hbm_bytes_per_launch', 'hbm_read_bytes', 'hbm_write_bytes'):
+            if key in c:
+                per_kernel[name][key] = c[key]
+    dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
+    roofline = None
+    if dom:
+        roofline = {'bound': 'hbm', 'kernel': dom + '_kernel', 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': per_kernel[dom]['hbm_frac'], 'traffic': per_kernel[dom].get('hbm_bytes_per_launch'),
+                    'avg_launch_ms': per_kernel[dom]['avg_ms'], 'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes'],
+                    'mfma_busy': per_kernel[dom].get('mfma_busy'), 'valu_busy': per_kernel[dom].get('valu_busy'),
+                    'counters': counters_meta,
+                    'note': 'not HBM-bound: the kernels are bound by vector-instruction issue (valu_busy) with the matrix pipe and '
+                            'the memory system mostly idle; achieved = algorithmic bytes / launch time as SURVEY 8(d) prescribes'}
+    out = {
+        'metric': 'FieldConv fwd+bwd Medges/s (20k verts, k=32, C=48, M=2)',
+        'value': value, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': DTYPE, 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[1] shape: one FieldConv layer fwd+bwd on a synthetic sphere mesh, '
+                               f'{args.verts} verts/GPU, k={k} nearest neighbours, support radius = '
+                               + ('95-percentile of the k-NN distances' if args.support == 'p95' else 'above every k-NN distance')
+                               + f' ({E} edges kept on rank 0), C={C}->{C}, band_limit={B}, n_rings={R}, ftype=1',
+                   'verts_per_gpu': args.verts, 'edges_total': E_total, 'k': k, 'channels': C, 'band_limit': B, 'n_rings': R,
+                   'support': args.support, 'stencil_path': 'geometric records' if mesh_graph.geo_t is not None else
+                   ('factored records' if factored else 'dense rows'),
+                   'parallelism': 'single GPU' if world == 1 else f'vertex partition x{world}, one-hop halo over RCCL',
+                   'halo_rows_rank0': 0 if plan is None else plan.n_halo},
+        'roofline': roofline,
+        'kernels': per_kernel,
+        'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
+        'graph_preprocessing_ms': prep_ms,
+    }
+    y_def = gx_def = None
+    if args.dump or (world == 1 and not use_dist and not args.no_extras):
+        gd = step()
+        y_def, gx_def = conv(x, edges, sten).detach().cpu(), gd[0].detach().cpu()
+    if args.dump:
+        torch.save({'y': y_def, 'gx': gx_def}, args.dump)
+    if world == 1 and not use_dist and not args.no_extras:
+        # extras (not the metric of record)
+        from fieldconv_amd.nn import FCResNetBlock
+        blk = FCResNetBlock(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
+        bparams = list(blk.parameters())
+
+        def bstep():
+            yb = blk(x, edges, sten)
+            torch.autograd.grad(yb, [x] + bparams, grad_outputs=gy)
+        for _ in range(10):
+            bstep()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(50):
+            bstep()
+        torch.cuda.synchronize()
+        bms = (time.perf_counter() - tb) / 50 * 1e3
+        out['fc_resnet_block'] = {'ms_per_step': bms, 'medges_per_s': 2 * E / (bms * 1e-3) / 1e6,
+                                  'note': 'FCResNetBlock fwd+bwd, edges counted once per FieldConv (2 per block)'}
+        if os.environ.get('FC_MFMA') is None:
+            out['fp32_mfma'] = other_mode(args, {'FC_MFMA': 'f32'}, 'v_mfma_f32_16x16x4_f32 on fp32 operands throughout (FC_MFMA=f32)',
+                                          y_def, gx_def)
+            out['reduced_precision'] = other_mode(args, {'FC_MFMA': 'f16'}, 'single f16 halves with per-row power-of-two scales, fp32 '
+                                                  'accumulation (FC_MFMA=f16)', y_def, gx_def)
+        if args.support == 'p95':
+            try:
+                other, _ = child_run(args, {}, extra_args=['--support', 'all'], dump=False)
+                out['round1_mesh'] = {'value': other['value'], 'unit': other['unit'], 'ms_per_step': other['ms_per_step'],
+                                      'edges_total': other['config']['edges_total'],
+                                      'note': "the round-1 mesh (--support all: no edge dropped, E = N*k, rings 4-5 empty)"}
+            except Exception as exc:
+                out['round1_mesh'] = {'value': None, 'note': f'failed: {type(exc).__name__}: {exc}'}
+    if world == 1 and not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 2
+        threads = max(1, ncpu // 2)                 # physical cores (SMT siblings excluded)
+        try:
+            out['cpu_baseline'] = cpu_baseline(args, threads)
+        except Exception as exc:                   # the GPU numbers stand on their own
+            out['cpu_baseline'] = {'value': None, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
+                                   'sample': f'failed: {type(exc).__name__}: {exc}'}
+    else:
+        out['cpu_baseline'] = None
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)       # 0.5 ms each: long enough for steady clocks and a full launch queue
+    ap.add_argument('--steps', type=int, default=200)       # 0.4 ms each: long enough for steady clocks and a full launch queue
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--verts', type=int, default=20000, help='vertices per GPU')
+    ap.add_argument('--mode', default='layer', choices=['layer', 'dp'])
+    ap.add_argument('--verts', type=int, default=20000, help='vertices per GPU (mode layer)')
     ap.add_argument('--k', type=int, default=32)
     ap.add_argument('--channels', type=int, default=48)
     ap.add_argument('--band-limit', type=int, default=2)
     ap.add_argument('--n-rings', type=int, default=6)
+    ap.add_argument('--dp-verts', type=int, default=4999, help='vertices per mesh (mode dp: FAUST-remeshed size)')
+    ap.add_argument('--dp-k', type=int, default=28)
+    ap.add_argument('--dp-channels', type=int, default=64)
+    ap.add_argument('--dp-band-limit', type=int, default=3)
     ap.add_argument('--support', default='p95', choices=['p95', 'all'],
                     help="support radius: 'p95' = 95-percentile of the k-NN distances (SURVEY 8(d) G-geo: FCPrecomp drops 5 %% of the "
                          "edges, every ring populated); 'all' = above every k-NN distance (round-1 mesh: E = N*k, outer rings empty)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the reduced-precision child run)')
-    ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (reduced-precision child run)')
+    ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the child runs)')
+    ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (child runs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -136,200 +515,12 @@ def main():
     force_dist = os.environ.get('BENCH_FORCE_DIST', '0') == '1'        # exercise the RCCL path with a single rank
     use_dist = world > 1 or force_dist
     if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        # RCCL prints a version banner to stdout when the communicator is created; keep stdout for the JSON line
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if backend == 'nccl':
-                dist.init_process_group('nccl', device_id=dev)
-            else:
-                dist.init_process_group(backend)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            try:
-                import ctypes
-                ctypes.CDLL(None).fflush(None)          # the banner sits in C stdio's buffer
-            except Exception:
-                pass
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        init_dist(dev, backend)
 
     import __graft_entry__
     __graft_entry__.build()
-    from fieldconv_amd.data import sphere_partition
-    from fieldconv_amd.dist import HaloPlan, halo_exchange, overlap_backward
-    from fieldconv_amd.functional import kernel_timer
-    from fieldconv_amd.graph import get_graph
-    from fieldconv_amd.nn import FieldConv
-    from fieldconv_amd.transforms import FCPrecomp
-
-    B, R, C, k = args.band_limit, args.n_rings, args.channels, args.k
-    F = 2 * B + 1
-    n_total = args.verts * world
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support)
-    data = data.to(dev)
-    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
-    n_local = data.num_nodes
-    E = int(edges.shape[0])
-    plan = HaloPlan(n_owned, halo_global, bounds, device=dev) if use_dist else None
-
-    torch.manual_seed(1234)                                  # identical parameters on every rank
-    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
-    params = list(conv.parameters())
-    g = torch.Generator().manual_seed(100 + rank)
-    x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g))
-    x[torch.rand(n_owned, C, generator=g) < 0.01] = 0        # 1 % exact zeros (origin-box path)
-    x = x.to(dev).requires_grad_(True)
-    gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
-
-    from fieldconv_amd.graph import SupportGraph
-    SupportGraph(edges, sten, n_local)                      # first build pays one-off library initialisation
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    SupportGraph(edges, sten, n_local)                      # steady-state cost of the per-mesh preprocessing
-    torch.cuda.synchronize()
-    prep_ms = (time.perf_counter() - t0) * 1e3
-    mesh_graph = get_graph(edges, sten, n_local)            # the cached instance every convolution will use
-    if plan is not None and os.environ.get('BENCH_NO_OVERLAP', '0') != '1':
-        overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel
-
-    def _all_reduce(t, op=dist.ReduceOp.SUM):
-        if backend == 'gloo':                       # host-staged (test rigs only)
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=op)
-
-    def step():
-        xl = halo_exchange(x, plan) if plan is not None else x
-        y = conv(xl, edges, sten)
-        if plan is not None:
-            y = y[:n_owned]
-        grads = torch.autograd.grad(y, [x] + params, grad_outputs=gy)
-        if use_dist:
-            flat = torch.cat([t.reshape(-1) for t in grads[1:]])
-            _all_reduce(flat)
-        return grads
-
-    for _ in range(args.warmup):
-        step()
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    kernel_timer.reset(pairs=3 * (args.steps // 4 + 1))
-    kernel_timer.stride = 4            # every 4th launch of each kernel inside the timed region carries a HIP-event pair
-    kernel_timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_timer.enabled = False
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        _all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ecount = torch.tensor([E], device=dev, dtype=torch.int64)
-        _all_reduce(ecount)
-        E_total = int(ecount.item())
-    else:
-        E_total = E
-    ms_per_step = elapsed / args.steps * 1e3
-    value = E_total / (elapsed / args.steps) / 1e6
-
+    out = (run_dp if args.mode == 'dp' else run_layer)(args, world, rank, dev, use_dist, backend)
     if rank == 0:
-        kt = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
-        fwd_b, bwd_b = algorithmic_bytes(n_local, E, C, C, R, F)
-        fwd_f, bwd_f = algorithmic_flops(n_local, E, C, C, R, F)
-        per_kernel = {}
-        gemm_f = 8 * n_local * C * C * R * F
-        wbytes = 8 * C * C * R * F
-        # backward contract bytes split over its two kernels: the data kernel reads stencil, indices, gy, x, W and
-        # writes gx; the filter kernel's contract traffic is x and the filter gradient (its H input is a temporary)
-        for name, nbytes, nflops in (('fc_forward', fwd_b, fwd_f), ('fc_backward_data', bwd_b - wbytes - 8 * n_local * C, bwd_f - gemm_f),
-                                     ('fc_backward_filter', wbytes + 8 * n_local * C, gemm_f)):
-            if name in kt:
-                sec = kt[name] * 1e-3
-                per_kernel[name] = {'avg_ms': kt[name], 'algorithmic_bytes': nbytes, 'GBps': nbytes / sec / 1e9,
-                                    'hbm_frac': nbytes / sec / 1e9 / HBM_PEAK_GBS, 'algorithmic_flops': nflops,
-                                    'TFLOPs': nflops / sec / 1e12, 'mfma_f32_frac': nflops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
-        dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if dom and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        roofline = None
-        if dom:
-            roofline = {'bound': 'hbm', 'kernel': dom + '_kernel', 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS,
-                        'unit': 'GB/s', 'frac': per_kernel[dom]['hbm_frac'], 'traffic': traffic,
-                        'avg_launch_ms': per_kernel[dom]['avg_ms'], 'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes'],
-                        'mfma_f32_frac': per_kernel[dom]['mfma_f32_frac']}
-        out = {
-            'metric': 'FieldConv fwd+bwd Medges/s (20k verts, k=32, C=48, M=2)',
-            'value': value, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1] shape: one FieldConv layer fwd+bwd on a synthetic sphere mesh, '
-                                   f'{args.verts} verts/GPU, k={k}, C={C}->{C}, band_limit={B}, n_rings={R}, ftype=1',
-                       'verts_per_gpu': args.verts, 'edges_total': E_total, 'k': k, 'channels': C, 'band_limit': B, 'n_rings': R,
-                       'parallelism': 'single GPU' if world == 1 else f'vertex partition x{world}, one-hop halo over RCCL',
-                       'halo_rows_rank0': 0 if plan is None else plan.n_halo},
-            'roofline': roofline,
-            'kernels': per_kernel,
-            'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
-            'graph_preprocessing_ms': prep_ms,
-        }
-        if args.dump:
-            gd = step()
-            torch.save({'y': conv(x, edges, sten).detach().cpu(), 'gx': gd[0].detach().cpu()}, args.dump)
-        if world == 1 and not use_dist and not args.no_extras:
-            # extra (not the metric of record): one FCResNetBlock = 2 FieldConv + TangentLin + 2 modReLU, fwd+bwd
-            from fieldconv_amd.nn import FCResNetBlock
-            blk = FCResNetBlock(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
-            bparams = list(blk.parameters())
-
-            def bstep():
-                yb = blk(x, edges, sten)
-                torch.autograd.grad(yb, [x] + bparams, grad_outputs=gy)
-            for _ in range(10):
-                bstep()
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(50):
-                bstep()
-            torch.cuda.synchronize()
-            bms = (time.perf_counter() - tb) / 50 * 1e3
-            out['fc_resnet_block'] = {'ms_per_step': bms, 'medges_per_s': 2 * E / (bms * 1e-3) / 1e6,
-                                      'note': 'FCResNetBlock fwd+bwd, edges counted once per FieldConv (2 per block)'}
-        if world == 1 and not use_dist and not args.no_extras and os.environ.get('FC_MFMA') is None:
-            out['reduced_precision'] = reduced_precision_run(args, conv, x, edges, sten, step)
-        if world == 1 and not args.no_cpu_baseline:
-            ncpu = os.cpu_count() or 2
-            threads = max(1, ncpu // 2)                 # physical cores (SMT siblings excluded)
-            try:
-                out['cpu_baseline'] = cpu_baseline(B, R, C, k, threads)
-            except Exception as exc:                   # the GPU numbers stand on their own
-                out['cpu_baseline'] = {'value': None, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port',
-                                       'sample': f'failed: {type(exc).__name__}: {exc}'}
-        else:
-            out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

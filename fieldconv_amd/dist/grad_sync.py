@@ -1,0 +1,63 @@
+"""Bucketed gradient all-reduce for data-parallel training (BASELINE configs[4]: one mesh per GPU, replicated
+parameters; the reference has no multi-GPU code).
+
+Every parameter's `.grad` becomes a view into ONE flat float32 buffer (the same layout FusedAdam uses; an existing
+FusedAdam's buffer is adopted instead of allocating a second one), so that a step's gradient exchange is one
+`all_reduce` per bucket of at most `bucket_bytes` -- a single collective for the ~1 M parameters (4 MB) of the
+networks in this package.  xGMI rings are per-link bound: few, large messages.  Backend "nccl" is RCCL on ROCm; with
+"gloo" and device tensors (several test ranks on one GPU) the bucket is staged through the host.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientBuckets:
+    def __init__(self, params_or_optimizer, group=None, bucket_bytes=64 << 20, average=False):
+        self.group = group
+        self.average = average
+        flat = getattr(params_or_optimizer, '_grad', None)          # FusedAdam: gradients already live in one buffer
+        if flat is not None:
+            self.flat = flat
+        else:
+            params = [p for p in params_or_optimizer if p.requires_grad]
+            if not params:
+                raise ValueError('GradientBuckets needs at least one parameter')
+            dev, dt = params[0].device, params[0].dtype
+            if any(p.device != dev or p.dtype != dt for p in params):
+                raise ValueError('GradientBuckets: parameters of one dtype on one device')
+            sizes = [p.numel() for p in params]
+            offs, total = [], 0
+            for n in sizes:                     # every tensor starts on a 16-byte boundary
+                offs.append(total)
+                total += (n + 3) // 4 * 4
+            self.flat = torch.zeros(total, dtype=dt, device=dev)
+            for p, o, n in zip(params, offs, sizes):
+                p.grad = self.flat[o:o + n].view(p.shape)
+        per = max(1, int(bucket_bytes) // self.flat.element_size())
+        self.buckets = [self.flat[i:i + per] for i in range(0, self.flat.numel(), per)]
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, async_op=False):
+        """Sum (or average) the gradients over the group; returns the Work handles when async_op (empty on the
+        host-staged path, which completes here)."""
+        world = dist.get_world_size(self.group)
+        works = []
+        staged = self.flat.is_cuda and dist.get_backend(self.group) == 'gloo'
+        for b in self.buckets:
+            if staged:
+                h = b.cpu()
+                dist.all_reduce(h, group=self.group)
+                b.copy_(h)
+            else:
+                w = dist.all_reduce(b, group=self.group, async_op=async_op)
+                if async_op:
+                    works.append(w)
+        if self.average and world > 1:
+            if works:
+                for w in works:
+                    w.wait()
+                works = []
+            self.flat.div_(world)
+        return works

@@ -37,12 +37,57 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = torch.zeros(total, dtype=torch.float32, device=dev)
         self._v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._offsets, self._sizes = offs, sizes
         with torch.no_grad():
             for p, o, n in zip(ps, offs, sizes):
                 view = self._flat[o:o + n].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self._grad[o:o + n].view(p.shape)
+        self._built = True
+
+    def add_param_group(self, param_group):
+        if getattr(self, '_built', False):
+            raise RuntimeError('FusedAdam keeps every parameter in one flat buffer laid out at construction: '
+                               'parameter groups cannot be added afterwards')
+        super().add_param_group(param_group)
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: per-parameter `step`, `exp_avg`, `exp_avg_sq` (copies of the flat buffers' slices),
+        so that a checkpoint written here resumes under torch.optim.Adam and vice versa."""
+        ps = self.param_groups[0]['params']
+        step = self._step.detach().clone().reshape(())
+        state = {i: {'step': step.clone(), 'exp_avg': self._m[o:o + n].view(p.shape).clone(),
+                     'exp_avg_sq': self._v[o:o + n].view(p.shape).clone()}
+                 for i, (p, o, n) in enumerate(zip(ps, self._offsets, self._sizes))}
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        group['params'] = list(range(len(ps)))
+        return {'state': state, 'param_groups': [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict['param_groups']
+        ps = self.param_groups[0]['params']
+        if len(groups) != 1 or len(groups[0]['params']) != len(ps):
+            raise ValueError('FusedAdam.load_state_dict: expected one parameter group with '
+                             f'{len(ps)} parameters')
+        for k, v in groups[0].items():
+            if k != 'params' and k in self.param_groups[0]:
+                self.param_groups[0][k] = v
+        state = state_dict['state']
+        steps = set()
+        for i, (p, o, n) in enumerate(zip(ps, self._offsets, self._sizes)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:                      # a parameter that never received a gradient under torch.optim.Adam
+                self._m[o:o + n].zero_()
+                self._v[o:o + n].zero_()
+                continue
+            self._m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self._v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(float(st['step']))
+        if len(steps) > 1:
+            raise ValueError('FusedAdam keeps one step counter: the checkpoint has parameters at different steps')
+        self._step.fill_(steps.pop() if steps else 0.0)
 
     def zero_grad(self, set_to_none=False):
         """One fill; the gradient views stay in place (set_to_none would detach them from the flat buffer)."""

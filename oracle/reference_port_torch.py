@@ -18,8 +18,10 @@ def soft_angle(z):
     return torch.where(box, torch.zeros_like(z.real), torch.angle(torch.where(box, torch.ones_like(z), z)))
 
 
-def field_conv(x, supp_edges, supp_sten, zonal, spherical, phase, ftype, B):
-    N = x.shape[0]
+def field_conv(x, supp_edges, supp_sten, zonal, spherical, phase, ftype, B, n_out=None):
+    """n_out: number of output rows when the targets (supp_edges[:, 1]) are numbered 0..n_out-1 independently of the
+    sources -- a slab of targets of a larger mesh (bench.py's cpu_baseline processes 20k-vertex meshes in slabs)."""
+    N = x.shape[0] if n_out is None else n_out
     F = 2 * B + 1
     phi = soft_angle(x)
     m = torch.arange(-B, B + 1, device=x.device, dtype=phi.dtype)

@@ -19,13 +19,16 @@ from oracle import fieldconv_oracle as orc                          # noqa: E402
 from oracle.torch_composites import FCPrecomp                       # noqa: E402
 
 
+CH = (64, 64)        # BASELINE configs[4]: C = 64, band limit 3
+
+
 def mesh(rank_like, B, R):
     """every rank has its own mesh: different size, degree and features"""
     n, k = (180, 7) if rank_like == 0 else (140, 9)
     data = sphere_support(n, k, seed=11 + rank_like)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     g = torch.Generator().manual_seed(50 + rank_like)
-    C, O = 6, 5
+    C, O = CH
     x = torch.complex(torch.randn(n, C, generator=g), torch.randn(n, C, generator=g))
     gy = torch.complex(torch.randn(n, O, generator=g), torch.randn(n, O, generator=g))
     return edges, sten, x, gy
@@ -46,16 +49,22 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = os.environ.get('FC_DIST_TEST_DEVICE', 'cpu') == 'cuda'
     dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
-    B, R = 2, 4
+    from fieldconv_amd.dist import GradientBuckets
+    B, R = 3, 6
     torch.manual_seed(77)                                # identical replicas
-    conv = FieldConv(6, 5, band_limit=B, n_rings=R, ftype=1)
+    conv = FieldConv(*CH, band_limit=B, n_rings=R, ftype=1)
     if on_gpu:
         conv = conv.to(dev)
+    params = [conv.zonal, conv.spherical, conv.phase]
+    buckets = GradientBuckets(params, bucket_bytes=256 << 10)        # several buckets: 188 416 floats = 736 KB
+    assert len(buckets.buckets) > 1 and all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in params)
     grads = local_grads(conv, *mesh(rank, B, R), B, on_gpu, dev)
-    flat = torch.cat([g_.reshape(-1).cpu() for g_ in grads])
-    dist.all_reduce(flat)                                # the one collective of a data-parallel step
+    for p, g_ in zip(params, grads):
+        p.grad.copy_(g_)
+    buckets.all_reduce()                                 # the one (bucketed) collective of a data-parallel step
+    flat = torch.cat([p.grad.reshape(-1).cpu() for p in params])
     # single-process answer: the sum over all meshes, from the oracle
-    ref_conv = FieldConv(6, 5, band_limit=B, n_rings=R, ftype=1)
+    ref_conv = FieldConv(*CH, band_limit=B, n_rings=R, ftype=1)
     ref_conv.load_state_dict({k_: v.cpu() for k_, v in conv.state_dict().items()})
     total = None
     for r in range(world):

@@ -826,3 +826,45 @@ def test_fused_adam_matches_torch_adam(dev):
     for (name, pa), pb, pc in zip(ma.named_parameters(), mb.parameters(), mc.parameters()):
         assert rel_err(H(pb), H(pa)) < 2e-5, name
         assert rel_err(H(pc), H(pa)) < 2e-5, name
+
+
+def test_fused_adam_checkpoint_round_trip(dev):
+    """FusedAdam.state_dict() carries the moments and the step in torch.optim.Adam's layout: a run that is saved,
+    restored into a FRESH FusedAdam (and into a torch.optim.Adam) and continued matches the uninterrupted run; a later
+    add_param_group is refused (the flat buffers are laid out at construction)."""
+    import copy
+    from fieldconv_amd.nn import TangentPerceptron
+    from fieldconv_amd.optim import FusedAdam
+    torch.manual_seed(4)
+    g = torch.Generator().manual_seed(4)
+    x = torch.complex(torch.randn(300, 12, generator=g), torch.randn(300, 12, generator=g)).to(dev)
+    ma = TangentPerceptron(12, 9).to(dev)
+    mb, mc = copy.deepcopy(ma), copy.deepcopy(ma)
+    kw = dict(lr=2e-3, betas=(0.8, 0.95), eps=1e-8, weight_decay=1e-3)
+
+    def train(m, o, n):
+        for _ in range(n):
+            o.zero_grad()
+            m(x).abs().square().mean().backward()
+            o.step()
+    oa = FusedAdam(ma.parameters(), **kw)
+    train(ma, oa, 7)                                           # the uninterrupted run
+    ob = FusedAdam(mb.parameters(), **kw)
+    train(mb, ob, 3)
+    sd = copy.deepcopy(ob.state_dict())
+    assert float(sd['state'][0]['step']) == 3 and float(sd['state'][0]['exp_avg'].abs().max()) > 0
+    weights = copy.deepcopy(mb.state_dict())
+    mb2 = TangentPerceptron(12, 9).to(dev)
+    mb2.load_state_dict(weights)
+    ob2 = FusedAdam(mb2.parameters(), lr=1.0)                  # hyper-parameters come back with the checkpoint
+    ob2.load_state_dict(sd)
+    train(mb2, ob2, 4)
+    mc.load_state_dict(weights)
+    oc = torch.optim.Adam(mc.parameters(), **kw)
+    oc.load_state_dict(sd)                                     # the same checkpoint resumes under torch's Adam
+    train(mc, oc, 4)
+    for (name, pa), pb, pc in zip(ma.named_parameters(), mb2.parameters(), mc.parameters()):
+        assert rel_err(H(pb), H(pa)) < 1e-6, name
+        assert rel_err(H(pc), H(pa)) < 2e-5, name
+    with pytest.raises(RuntimeError):
+        ob2.add_param_group({'params': [torch.nn.Parameter(torch.zeros(4, device=dev))]})
