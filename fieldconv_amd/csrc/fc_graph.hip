@@ -157,6 +157,86 @@ __global__ __launch_bounds__(kAnalyzeEdges) void graph_analyze_kernel(
     atomicAdd(cnt_s + ks, 1);
 }
 
+// ---- per input edge, straight from FCPrecomp's inputs (reference transforms/fc_precomp.py:53-97): what graph_analyze_kernel
+// recovers from a materialised (E,R,F) stencil is known in closed form here -- lower ring q, the two interpolation weights,
+// c = wxp, g = e^{i theta} -- so the dense stencil is never written or read.  Kept edges (r <= epsilon) keep their order:
+// slot = pos[e].  Also emits what the module API returns per edge: supp_edges, ln, wxp, and the factor table
+// [q bits, w_q, w_{q+1}, 0, Re c, Im c, Re g, Im g] in that order (FactoredStencil materialises from it on demand).
+struct FactorArgs {
+    const float* log_mag;
+    const float* log_ang;
+    const float2* xp;
+    const float* w;
+    const int64_t* edges_in;
+    const int32_t* keep;
+    const int32_t* pos;
+    const float* total;
+    float eps;
+    int E_in;
+    int64_t* edges_out;
+    float2* ln;
+    float2* wxp;
+    float* factors;
+};
+
+__global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec, float* __restrict__ geo, uint32_t* __restrict__ key_t,
+                                    uint32_t* __restrict__ key_s, uint32_t* __restrict__ val, int32_t* __restrict__ cnt_t,
+                                    int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags, const GraphArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E_in || !p.keep[e]) return;
+    const int slot = p.pos[e];
+    const int R = a.R, F = a.F, B = (F - 1) / 2;
+    int64_t src = p.edges_in[2 * (size_t)e], dst = p.edges_in[2 * (size_t)e + 1];
+    if (src < 0 || src >= a.N || dst < 0 || dst >= a.N) {
+        atomicOr(flags, 4);
+        src = min(max(src, (int64_t)0), (int64_t)a.N - 1);
+        dst = min(max(dst, (int64_t)0), (int64_t)a.N - 1);
+    }
+    const float r = p.log_mag[e] / p.eps, theta = p.log_ang[e];
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    p.ln[slot] = make_float2(r * cs, r * sn);
+    const float scale = p.w[src] / (1e-12f + p.total[dst]);
+    const float2 x = p.xp[e];
+    const float2 c = make_float2(scale * x.x, scale * x.y);
+    p.wxp[slot] = c;
+    p.edges_out[2 * (size_t)slot] = src;
+    p.edges_out[2 * (size_t)slot + 1] = dst;
+    // upper knot: the first knot >= r, never knot 0 (csrc/fc_precomp.hip: precomp_stencil_kernel)
+    int hi = R - 1;
+    for (int k = R - 1; k >= 1; --k)
+        if (sqrtf((float)k / (float)(R - 1)) >= r) hi = k;
+    const float k_lo = sqrtf((float)(hi - 1) / (float)(R - 1)), k_hi = sqrtf((float)hi / (float)(R - 1));
+    const float w1 = (r - k_lo) / (k_hi - k_lo), w0 = 1.f - w1;
+    const int q = hi - 1;
+    const float4 head = make_float4(__int_as_float(q), w0, w1, 0.f);
+    const float4 cg = make_float4(c.x, c.y, cs, sn);
+    float4* fp = reinterpret_cast<float4*>(p.factors + (size_t)slot * 8);
+    fp[0] = head;
+    fp[1] = cg;
+    if (geo) {
+        float4* gp = reinterpret_cast<float4*>(geo + (size_t)slot * 8);
+        gp[0] = head;
+        gp[1] = cg;
+    }
+    float* rp = rec + (size_t)slot * a.recf;
+    rp[0] = head.x; rp[1] = w0; rp[2] = w1; rp[3] = 0.f;
+    for (int f = 0; f < F; ++f) {          // ph_f = e^{i (f-B) theta} * c, in the reference's order of operations
+        float s_, c_;
+        sincosf((float)(f - B) * theta, &s_, &c_);
+        const float2 ph = cmul(make_float2(c_, s_), c);
+        rp[4 + 2 * f] = ph.x;
+        rp[5 + 2 * f] = ph.y;
+    }
+    for (int k = 4 + 2 * F; k < a.recf; ++k) rp[k] = 0.f;
+    const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
+    key_t[slot] = kt;
+    key_s[slot] = ks;
+    val[slot] = (uint32_t)slot;
+    atomicAdd(cnt_t + kt, 1);
+    atomicAdd(cnt_s + ks, 1);
+}
+
 // ---- per vertex: ring-run offsets (exclusive over q) and the degree, both sides
 __global__ void graph_runs_kernel(const int32_t* __restrict__ cnt_t, const int32_t* __restrict__ cnt_s, int32_t* __restrict__ runs_t,
                                   int32_t* __restrict__ runs_s, int32_t* __restrict__ deg_t, int32_t* __restrict__ deg_s, int N) {
@@ -244,14 +324,14 @@ size_t fc_graph_workspace_bytes(int32_t N, int32_t E, int32_t R, int32_t F, int3
     return fc::plan_graph(N, E, recf, with_stencil != 0).total;
 }
 
-int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N, int32_t E, int32_t R, int32_t F,
-                   int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s, int32_t* nbr_s,
-                   int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, const fc::FactorArgs* factors, int32_t N, int32_t E,
+                            int32_t R, int32_t F, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
+                            int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (N <= 0 || E < 0 || !rowptr_t || !rowptr_s || !runs_t || !runs_s || !flags || !workspace) return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!supp_edges || !nbr_t || !nbr_s || !perm_t || !perm_s)) return FC_ERR_BAD_ARGUMENT;
     if ((uint64_t)N * 8 >= ((uint64_t)1 << 32)) return FC_ERR_UNSUPPORTED;
-    const bool with_sten = supp_sten != nullptr;
+    const bool with_sten = supp_sten != nullptr || factors != nullptr;
     if (with_sten && (R < 2 || R > fc::kGraphMaxR || F < 1 || F > fc::kGraphMaxF || (F & 1) == 0 || !rec_t || !rec_s)) return FC_ERR_UNSUPPORTED;
     const int recf = (4 + 2 * F + 3) / 4 * 4;
     const fc::GraphPlan p = fc::plan_graph(N, E, recf, with_sten);
@@ -276,10 +356,15 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
 
     if (hipMemsetAsync(cnt_t, 0, (size_t)N * 8 * 4 * 2, s) != hipSuccess) return FC_ERR_LAUNCH;
     if (hipMemsetAsync(flags, 0, 4, s) != hipSuccess) return FC_ERR_LAUNCH;
-    if (E > 0)
+    if (factors) {
+        if (factors->E_in > 0)
+            hipLaunchKernelGGL(fc::graph_factor_kernel, dim3((factors->E_in + 255) / 256), dim3(256), 0, s, *factors, rec, geo, key_t, key_s,
+                               val, cnt_t, cnt_s, flags, a);
+    } else if (E > 0) {
         hipLaunchKernelGGL(fc::graph_analyze_kernel, dim3((E + fc::kAnalyzeEdges - 1) / fc::kAnalyzeEdges), dim3(fc::kAnalyzeEdges),
                            with_sten ? (size_t)fc::kAnalyzeEdges * (R * F + 1) * sizeof(float2) : 0, s, supp_edges,
                            reinterpret_cast<const float2*>(supp_sten), rec, geo, key_t, key_s, val, cnt_t, cnt_s, flags, a);
+    }
     hipLaunchKernelGGL(fc::graph_runs_kernel, dim3((N + 1 + 255) / 256), dim3(256), 0, s, cnt_t, cnt_s, runs_t, runs_s, deg_t, deg_s, N);
     if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, deg_t, rowptr_t, N + 1, s) != hipSuccess) return FC_ERR_LAUNCH;
     cub_bytes = p.cub_bytes;
@@ -299,6 +384,42 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
                            with_sten ? rec_s : nullptr, nullptr, a);
     }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N, int32_t E, int32_t R, int32_t F,
+                   int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s, int32_t* nbr_s,
+                   int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    return graph_build_impl(supp_edges, supp_sten, nullptr, N, E, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
+                            rec_t, rec_s, geo_t, flags, workspace, workspace_bytes, stream);
+}
+
+int fc_precomp_graph(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
+                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int64_t* supp_edges_out, float* ln,
+                     float* wxp, float* factors, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
+                     int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags,
+                     void* precomp_workspace, size_t precomp_workspace_bytes, void* graph_workspace, size_t graph_workspace_bytes,
+                     void* stream) {
+    if (!log_mag || !log_ang || !xp || !w || !supp_edges || !precomp_workspace || N <= 0 || E <= 0 || E_kept <= 0 || E_kept > E)
+        return FC_ERR_BAD_ARGUMENT;
+    if (!supp_edges_out || !ln || !wxp || !factors || !(epsilon > 0.f)) return FC_ERR_BAD_ARGUMENT;
+    if (precomp_workspace_bytes < fc_precomp_workspace_bytes(N, E)) return FC_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // layout of the selection left by fc_precomp_mark (csrc/fc_precomp.hip): keep | pos | total (N)
+    const size_t seg = ((size_t)(E + 2) * 4 + 255) / 256 * 256;
+    char* wsp = static_cast<char*>(precomp_workspace);
+    fc::FactorArgs fa;
+    fa.log_mag = log_mag; fa.log_ang = log_ang; fa.xp = reinterpret_cast<const float2*>(xp); fa.w = w; fa.edges_in = supp_edges;
+    fa.keep = reinterpret_cast<const int32_t*>(wsp);
+    fa.pos = reinterpret_cast<const int32_t*>(wsp + seg);
+    float* total = reinterpret_cast<float*>(wsp + 2 * seg);
+    fa.total = total;
+    fa.eps = epsilon; fa.E_in = E;
+    fa.edges_out = supp_edges_out; fa.ln = reinterpret_cast<float2*>(ln); fa.wxp = reinterpret_cast<float2*>(wxp); fa.factors = factors;
+    const int rc = fc::precomp_area_sums(supp_edges, fa.keep, w, total, N, E, s);
+    if (rc != FC_OK) return rc;
+    return graph_build_impl(supp_edges_out, nullptr, &fa, N, E_kept, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
+                            rec_t, rec_s, geo_t, flags, graph_workspace, graph_workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -45,6 +45,9 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
 
 bool shape_compiled(int R, int B);
 
+// FCPrecomp's area sums total[dst] += w[src] over the kept edges (csrc/fc_precomp.hip), shared with the fused build
+int precomp_area_sums(const int64_t* edges, const int32_t* keep, const float* w, float* total, int N, int E, hipStream_t s);
+
 // development: device buffer that receives in-kernel time stamps (fc_debug_stamp_buffer), or nullptr
 unsigned long long* debug_stamp_buffer();
 

@@ -22,7 +22,7 @@ import os
 
 import torch
 
-_CACHE_SIZE = 4
+_CACHE_SIZE = 16        # meshes whose preprocessing is kept (a graph is ~100 B per edge)
 _cache = collections.OrderedDict()
 
 
@@ -139,6 +139,98 @@ def _native_build(supp_edges, sten, N, R, F, want_rec, want_geo):
 
 
 
+class FactoredStencil:
+    """FCPrecomp's `supp_sten` without the (E,R,F) tensor (reference transforms/fc_precomp.py:95).
+
+    The fused build (fc_precomp_graph) goes from FCPrecomp's inputs straight to the support graph and the per-edge records
+    the convolutions consume; what the reference returns as `supp_sten` is then only a name for that graph.  This object
+    stands in for the tensor: it has its shape / dtype / device, FieldConv takes the attached SupportGraph from it,
+    `sten[..., B:B+2]` (what the notebooks hand to LiftBlock, segmentation.ipynb:204) builds just those two columns, and any
+    other use -- indexing, torch functions, tensor methods -- materialises the dense rows from the (E,8) factor table
+    [q, w_q, w_{q+1}, 0, wxp, e^{i theta}] once and then behaves like the tensor."""
+
+    def __init__(self, factors, R, F, graph):
+        self.factors = factors
+        self.R, self.F = int(R), int(F)
+        self.graph = graph
+        self.shape = torch.Size((int(factors.shape[0]), self.R, self.F))
+        self.dtype = torch.complex64
+        self.device = factors.device
+        self.is_cuda = factors.is_cuda
+        self.requires_grad = False
+        self._dense = None
+        self._lift = None
+
+    def dim(self):
+        return 3
+
+    ndim = property(lambda self: 3)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def numel(self):
+        return self.shape[0] * self.R * self.F
+
+    def is_complex(self):
+        return True
+
+    def _parts(self):
+        fac = self.factors
+        q = fac[:, 0].view(torch.int32).to(torch.int64)
+        ring = torch.zeros((fac.shape[0], self.R), dtype=torch.float32, device=fac.device)
+        ring.scatter_(1, q[:, None], fac[:, 1:2])
+        ring.scatter_(1, q[:, None] + 1, fac[:, 2:3])
+        c = torch.view_as_complex(fac[:, 4:6].contiguous())
+        g = torch.view_as_complex(fac[:, 6:8].contiguous())
+        return ring, c, g
+
+    def columns(self, m_lo, m_hi):
+        """(E, R, m_hi - m_lo) complex64: the stencil columns of the angular frequencies m_lo <= m < m_hi."""
+        ring, c, g = self._parts()
+        cols = []
+        for m in range(m_lo, m_hi):
+            p = c
+            for _ in range(abs(m)):
+                p = p * (g if m > 0 else g.conj())
+            cols.append(ring.to(torch.complex64) * p[:, None])
+        return torch.stack(cols, dim=2)
+
+    def materialize(self):
+        if self._dense is None:
+            B = (self.F - 1) // 2
+            self._dense = self.columns(-B, B + 1)
+        return self._dense
+
+    def __getitem__(self, idx):
+        B = (self.F - 1) // 2
+        if (self._dense is None and isinstance(idx, tuple) and len(idx) == 2 and idx[0] is Ellipsis and isinstance(idx[1], slice)
+                and idx[1].step in (None, 1) and idx[1].start == B and idx[1].stop == B + 2 and B >= 1):
+            if self._lift is None:
+                self._lift = self.columns(0, 2)
+            return self._lift
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getattr__(self, name):            # anything else a tensor has: the materialised tensor's
+        if name.startswith('__') or name in ('factors', 'graph', '_dense', '_lift'):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        unwrap = lambda a: a.materialize() if isinstance(a, FactoredStencil) else a
+        args = tuple(unwrap(a) for a in args)
+        kwargs = {k: unwrap(v) for k, v in kwargs.items()}
+        return func(*args, **kwargs)
+
+    def __repr__(self):
+        return f'FactoredStencil(shape={tuple(self.shape)}, device={self.device}, dense={self._dense is not None})'
+
+
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
                  'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx')
@@ -233,6 +325,21 @@ class SupportGraph:
                 by_source = bool((src[1:] >= src[:-1]).all()) if E > 1 else True
                 self.sten_s = sten if by_source else sten.index_select(0, perm_s)
 
+    @classmethod
+    def from_precomp(cls, supp_edges, N, R, F, built, geo_ok):
+        """The graph fc_precomp_graph built (transforms/fc_precomp.py): records straight from FCPrecomp's inputs."""
+        g = cls.__new__(cls)
+        g.N, g.E, g.R, g.F = int(N), int(supp_edges.shape[0]), int(R), int(F)
+        g._keep = (supp_edges,)
+        g._plans = {}
+        g.on_gx = None
+        g.sten_t = g.sten_s = None
+        for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', 'rec_t', 'rec_s', 'runs_t', 'runs_s'):
+            setattr(g, name, built[name])
+        g.factored = True
+        g.geo_t = built['geo_t'] if geo_ok else None
+        return g
+
     def _build_native(self, supp_edges, sten, allow_factored):
         """csrc/fc_graph.hip: everything the torch code above does, in ~12 launches."""
         want_rec = allow_factored and os.environ.get('FIELDCONV_DENSE', '0') != '1'
@@ -261,7 +368,20 @@ def _key(t):
     return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device), t.dtype)
 
 
+def register_graph(supp_edges, stencil, N, graph):
+    """Make a graph that was built together with its stencil stand-in (FactoredStencil) findable by get_graph /
+    get_edge_csr under the tensors the modules will be called with."""
+    key = (_key(supp_edges), ('factored', id(stencil)), int(N))
+    _cache[key] = graph
+    while len(_cache) > _CACHE_SIZE:
+        _cache.popitem(last=False)
+
+
 def get_graph(supp_edges, supp_sten, N):
+    if isinstance(supp_sten, FactoredStencil):
+        if supp_sten.graph.N != int(N):
+            raise ValueError(f'x has {int(N)} rows but the stencil was built for {supp_sten.graph.N} vertices')
+        return supp_sten.graph
     key = (_key(supp_edges), _key(supp_sten), int(N))
     g = _cache.get(key)
     if g is not None:

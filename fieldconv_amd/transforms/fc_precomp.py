@@ -1,6 +1,10 @@
-"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97): three launches of
-csrc/fc_precomp.hip (fc_precomp_mark / fc_precomp_build).  Device tensors only, like every operator of this package."""
+"""Run-time stencil assembly (same call contract as reference transforms/fc_precomp.py:30-97).  Device tensors only, like
+every operator of this package.  By default the call goes from the inputs STRAIGHT to the support graph and per-edge
+records the convolutions consume (fc_precomp_mark + fc_precomp_graph, csrc/fc_graph.hip) and returns a FactoredStencil in
+place of the (E,R,F) tensor -- the dense stencil (154 MB at BASELINE configs[1]) is built only if something asks for it.
+FIELDCONV_EAGER_STENCIL=1 keeps the reference's literal outputs (fc_precomp_build)."""
 import ctypes
+import os
 
 import torch
 
@@ -60,21 +64,54 @@ class FCPrecomp(object):
         wv = w.reshape(-1).contiguous()
         edges = supp_edges.to(torch.int64).contiguous()
         eps = float(self.max_r)
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             nbytes = lib.fc_precomp_workspace_bytes(N, E)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.fc_precomp_mark(p(r), eps, N, E, p(ws), nbytes, st), 'fc_precomp_mark')
+            _lib.check(lib.fc_precomp_mark(p(r), p(edges), eps, N, E, p(ws), nbytes, st), 'fc_precomp_mark')
             off = lib.fc_precomp_kept_count_ptr(p(ws), E) - ws.data_ptr()
-            kept = int(ws[off:off + 4].view(torch.int32).item())          # the one synchronisation (the reference's `nonzero`)
+            kept, bad = ws[off:off + 8].view(torch.int32).tolist()        # the one synchronisation (the reference's `nonzero`)
+            if bad:
+                raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+            c64 = dict(dtype=torch.complex64, device=dev)
             edges_out = torch.empty((kept, 2), dtype=torch.int64, device=dev)
-            sten = torch.empty((kept, R, F), dtype=torch.complex64, device=dev)
-            ln = torch.empty(kept, dtype=torch.complex64, device=dev)
-            wxp = torch.empty(kept, dtype=torch.complex64, device=dev)
-            _lib.check(lib.fc_precomp_build(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, R, F, p(edges_out), p(sten), p(ln),
-                                            p(wxp), p(ws), nbytes, st), 'fc_precomp_build')
-        return edges_out.to(supp_edges.dtype), sten, ln, wxp
+            ln, wxp = torch.empty(kept, **c64), torch.empty(kept, **c64)
+            if kept == 0:
+                return edges_out.to(supp_edges.dtype), torch.zeros((0, R, F), **c64), ln, wxp
+            if os.environ.get('FIELDCONV_EAGER_STENCIL', '0') == '1' or os.environ.get('FIELDCONV_DENSE', '0') == '1':
+                sten = torch.empty((kept, R, F), **c64)
+                _lib.check(lib.fc_precomp_build(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, R, F, p(edges_out), p(sten), p(ln),
+                                                p(wxp), p(ws), nbytes, st), 'fc_precomp_build')
+                return edges_out.to(supp_edges.dtype), sten, ln, wxp
+            # fused: records and both groupings straight from the inputs
+            from ..graph import FactoredStencil, SupportGraph, register_graph
+            recf = (4 + 2 * F + 3) // 4 * 4
+            i32 = dict(dtype=torch.int32, device=dev)
+            b = {}
+            for side in ('t', 's'):
+                b['rowptr_' + side] = torch.empty(N + 1, **i32)
+                b['nbr_' + side] = torch.empty(kept, **i32)
+                b['runs_' + side] = torch.empty((N, 8), **i32)
+                b['perm_' + side] = torch.empty(kept, dtype=torch.int64, device=dev)
+            # zeroed: the kernels stream up to 1 KiB past the last record
+            b['rec_t'] = torch.zeros((kept + 1024 // (recf * 4) + 16, recf), dtype=torch.float32, device=dev)
+            b['rec_s'] = torch.zeros_like(b['rec_t'])
+            want_geo = F >= 3 and os.environ.get('FIELDCONV_NO_GEO', '0') != '1'
+            b['geo_t'] = torch.zeros((kept + 1024 // 32 + 16, 8), dtype=torch.float32, device=dev) if want_geo else None
+            factors = torch.empty((kept, 8), dtype=torch.float32, device=dev)
+            flags = torch.empty(1, **i32)
+            gbytes = lib.fc_graph_workspace_bytes(N, kept, R, F, 1)
+            gws = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.fc_precomp_graph(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, kept, R, F, p(edges_out), p(ln), p(wxp),
+                                            p(factors), p(b['rowptr_t']), p(b['nbr_t']), p(b['runs_t']), p(b['perm_t']),
+                                            p(b['rowptr_s']), p(b['nbr_s']), p(b['runs_s']), p(b['perm_s']), p(b['rec_t']), p(b['rec_s']),
+                                            p(b['geo_t']), p(flags), p(ws), nbytes, p(gws), gbytes, st), 'fc_precomp_graph')
+        edges_ret = edges_out.to(supp_edges.dtype)
+        graph = SupportGraph.from_precomp(edges_ret, N, R, F, b, want_geo)
+        sten = FactoredStencil(factors, R, F, graph)
+        register_graph(edges_ret, sten, N, graph)
+        return edges_ret, sten, ln, wxp
 
     def __repr__(self):
         return '{}(n_rings={}, epsilon={})'.format(self.__class__.__name__, self.R, self.max_r)

@@ -220,17 +220,31 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
 /* ---- FCPrecomp (stencil assembly), reference transforms/fc_precomp.py:53-97 ------------------------------------------ *
  * Inputs as the reference's data object holds them: log_mag (E) f32, log_ang (E) f32, xp (E) c64, w (N) f32 (vertex
  * areas), supp_edges (E,2) int64, epsilon (support radius).  Two steps because the number of kept edges E' (those with
- * log_mag / epsilon <= 1) sizes the outputs: fc_precomp_mark enqueues the selection; the int32 at
- * fc_precomp_kept_count_ptr() then holds E' (device memory: the caller's one synchronisation); fc_precomp_build, with the
- * same workspace, writes supp_edges_out (E',2) int64, supp_sten (E',R,F) c64, ln (E') c64 and wxp (E') c64 in the
- * original edge order. */
+ * log_mag / epsilon <= 1) sizes the outputs: fc_precomp_mark enqueues the selection; the two int32 at
+ * fc_precomp_kept_count_ptr() then hold E' and a flag that is non-zero when a kept edge refers to a vertex outside [0, N)
+ * (device memory: the caller's one synchronisation; supp_edges may be NULL for fc_precomp_mark: no range check).  Then, with
+ * the same workspace, EITHER
+ *   fc_precomp_build   writes supp_edges_out (E',2) int64, supp_sten (E',R,F) c64, ln (E') c64 and wxp (E') c64 in the
+ *                      original edge order (the reference's outputs as they are), OR
+ *   fc_precomp_graph   goes straight to what the convolutions consume: supp_edges_out, ln, wxp as above,
+ *                      `factors` (E',8) f32 = [q bits, w_q, w_{q+1}, 0, Re wxp, Im wxp, cos theta, sin theta] per kept edge
+ *                      (the stencil row is w_r * wxp * e^{i m theta}: anything that wants dense rows builds them from this),
+ *                      and every output of fc_graph_build (both groupings, ring-run offsets, permutations, factored and
+ *                      geometric records) -- the (E',R,F) stencil is never written or read.  graph_workspace:
+ *                      fc_graph_workspace_bytes(N, E', R, F, 1) bytes; flags as for fc_graph_build (bits 0/1 never set). */
 size_t fc_precomp_workspace_bytes(int32_t N, int32_t E);
-int fc_precomp_mark(const float* log_mag, float epsilon, int32_t N, int32_t E, void* workspace, size_t workspace_bytes,
-                    void* stream);
+int fc_precomp_mark(const float* log_mag, const int64_t* supp_edges, float epsilon, int32_t N, int32_t E, void* workspace,
+                    size_t workspace_bytes, void* stream);
 const int32_t* fc_precomp_kept_count_ptr(const void* workspace, int32_t E);
 int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
                      float epsilon, int32_t N, int32_t E, int32_t R, int32_t F, int64_t* supp_edges_out, float* supp_sten,
                      float* ln, float* wxp, void* workspace, size_t workspace_bytes, void* stream);
+int fc_precomp_graph(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
+                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int64_t* supp_edges_out, float* ln,
+                     float* wxp, float* factors, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t,
+                     int32_t* rowptr_s, int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t,
+                     int32_t* flags, void* precomp_workspace, size_t precomp_workspace_bytes, void* graph_workspace,
+                     size_t graph_workspace_bytes, void* stream);
 
 /* ---- fused Adam over a flat float32 parameter buffer (torch.optim.Adam arithmetic, L2 weight decay, no amsgrad) -------- *
  * params, grads, exp_avg, exp_avg_sq: n floats each, n a multiple of 4, 16-byte aligned; step: one device float holding

@@ -80,13 +80,14 @@ def test_multi_tile_workgroups_whole_tensors(shape, dev, monkeypatch):
     y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
     gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
     ed, sd = edges.to(dev), sten.to(dev)
+    no_geo_run = os.environ.get('FIELDCONV_NO_GEO') == '1'           # a mode run of tests/test_gpu_modes.py
     graphs = {'geometric': SupportGraph(ed, sd, N)}
     monkeypatch.setenv('FIELDCONV_NO_GEO', '1')
     graphs['factored'] = SupportGraph(ed, sd, N)
     monkeypatch.delenv('FIELDCONV_NO_GEO')
     graphs['dense'] = SupportGraph(ed, sd, N, allow_factored=False)
     if os.environ.get('FIELDCONV_DENSE', '0') != '1':
-        assert graphs['geometric'].geo_t is not None or os.environ.get('FIELDCONV_NO_GEO') == '1'
+        assert graphs['geometric'].geo_t is not None or no_geo_run
         assert graphs['factored'].factored and graphs['factored'].geo_t is None and not graphs['dense'].factored
     for name, graph in graphs.items():
         y, gx, gW = run_conv(graph, x, W, gy, dev)
@@ -194,3 +195,54 @@ def test_config2_fc_resnet_block_rows(dev):
     assert rel_err(gxd[verts.numpy()], gr[0].numpy()) < 2 * TOL
     for name, a, b in zip(names, gd[1:], gr[1:]):
         assert rel_err(H(a), b.numpy()) < 2 * TOL, name
+
+
+@pytest.mark.parametrize('N,k,B,R', [(6000, 9, 2, 6), (300, 20, 3, 8), (900, 12, 1, 3)])
+def test_fused_precomp_graph(dev, monkeypatch, N, k, B, R):
+    """FCPrecomp's default path (fc_precomp_mark + fc_precomp_graph) goes from the reference's inputs straight to the
+    support graph and the per-edge records and returns a FactoredStencil in place of the (E,R,F) tensor.  Against the
+    literal outputs (fc_precomp_build), the oracle's FCPrecomp, and the convolution on either: same edges / ln / wxp, the
+    dense rows on demand, the two columns LiftBlock takes without materialising the rest, equal convolution results."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import FactoredStencil, SupportGraph, get_edge_csr, get_graph
+    from fieldconv_amd.transforms import FCPrecomp
+    from oracle.torch_composites import FCPrecomp as FCPrecompRef
+    if os.environ.get('FIELDCONV_DENSE') == '1' or os.environ.get('FIELDCONV_EAGER_STENCIL') == '1':
+        pytest.skip('the fused build is switched off in this mode')
+    data = sphere_support(N, k, seed=N, support='p95')
+    dd = data.to(dev)
+    e1, s1, l1, w1 = FCPrecomp(B, R, data.epsilon)(dd)
+    assert isinstance(s1, FactoredStencil) and tuple(s1.shape) == (e1.shape[0], R, 2 * B + 1) and s1._dense is None
+    monkeypatch.setenv('FIELDCONV_EAGER_STENCIL', '1')
+    e2, s2, l2, w2 = FCPrecomp(B, R, data.epsilon)(dd)
+    monkeypatch.delenv('FIELDCONV_EAGER_STENCIL')
+    assert torch.is_tensor(s2) and torch.equal(e1, e2) and torch.equal(torch.view_as_real(l1), torch.view_as_real(l2))
+    assert torch.equal(torch.view_as_real(w1), torch.view_as_real(w2))
+    e3, s3, _, _ = FCPrecompRef(B, R, data.epsilon)(data)
+    assert torch.equal(e1.cpu(), e3)
+
+    I, O = 24, 16
+    g = torch.Generator().manual_seed(N)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    graph = get_graph(e1, s1, N)
+    assert graph is s1.graph and graph.factored and get_edge_csr(e1, N).rowptr_t is graph.rowptr_t
+    ya, gxa, gWa = run_conv(graph, x, W, gy, dev)
+    yb, gxb, gWb = run_conv(SupportGraph(e2, s2, N), x, W, gy, dev)
+    y_ref = orc.fieldconv_forward(x.numpy(), e3.numpy(), s3.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), e3.numpy(), s3.numpy(), W.numpy(), gy.numpy())
+    for a, b, r in ((ya, yb, y_ref), (gxa, gxb, gx_ref), (gWa, gWb, gW_ref)):
+        assert rel_err(H(a), r) < TOL and rel_err(H(a), H(b)) < TOL
+    if B >= 1:
+        lift = s1[..., B:B + 2]                          # what the notebooks hand to LiftBlock
+        assert s1._dense is None and tuple(lift.shape) == (e1.shape[0], R, 2)
+        assert rel_err(H(lift), H(s2[..., B:B + 2])) < 2e-6
+    assert rel_err(H(s1), H(s2)) < 2e-6 and s1._dense is not None          # any other use: the dense rows, once
+    assert rel_err(H(torch.abs(s1)), H(s2.abs())) < 2e-6 and tuple(s1[5].shape) == (R, 2 * B + 1)
+    bad = dd.supp_edges.clone()
+    bad[7, 0] = N + 3
+    dd.supp_edges = bad
+    with pytest.raises(IndexError):
+        FCPrecomp(B, R, data.epsilon)(dd)

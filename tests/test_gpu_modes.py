@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SUBSET = ('test_fieldconv_golden or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
+SUBSET = ('test_fused_precomp_graph or test_fieldconv_golden or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
           'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40')
 
 MODES = {
@@ -25,6 +25,7 @@ MODES = {
     'lds_staged_filter_kernel': {'FC_FILTER2': '0'},
     'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
     'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
+    'eager_stencil': {'FIELDCONV_EAGER_STENCIL': '1'},   # FCPrecomp returns the dense (E,R,F) tensor; graph built from it
     'ring_major_forward': {'FC_RING': '1'},              # opt-in ring-major forward kernels (csrc/fc_forward_ring.hpp)
 }
 
