@@ -87,22 +87,35 @@ class FCPrecomp(object):
             # fused: records and both groupings straight from the inputs
             from ..graph import FactoredStencil, SupportGraph, register_graph
             recf = (4 + 2 * F + 3) // 4 * 4
-            i32 = dict(dtype=torch.int32, device=dev)
-            b = {}
-            for side in ('t', 's'):
-                b['rowptr_' + side] = torch.empty(N + 1, **i32)
-                b['nbr_' + side] = torch.empty(kept, **i32)
-                b['runs_' + side] = torch.empty((N, 8), **i32)
-                b['perm_' + side] = torch.empty(kept, dtype=torch.int64, device=dev)
-            # zeroed: the kernels stream up to 1 KiB past the last record
-            b['rec_t'] = torch.zeros((kept + 1024 // (recf * 4) + 16, recf), dtype=torch.float32, device=dev)
-            b['rec_s'] = torch.zeros_like(b['rec_t'])
             want_geo = F >= 3 and os.environ.get('FIELDCONV_NO_GEO', '0') != '1'
-            b['geo_t'] = torch.zeros((kept + 1024 // 32 + 16, 8), dtype=torch.float32, device=dev) if want_geo else None
-            factors = torch.empty((kept, 8), dtype=torch.float32, device=dev)
-            flags = torch.empty(1, **i32)
+            # one allocation for everything the build writes (a dozen separate ones cost more host time than the kernels
+            # take on a small mesh); the record arrays get 1 KiB + 16 rows of zeroed padding: the kernels stream past the end
+            pad_rec, pad_geo = 1024 // (recf * 4) + 16, 1024 // 32 + 16
+            sizes = [('rowptr_t', (N + 1,), torch.int32), ('rowptr_s', (N + 1,), torch.int32), ('nbr_t', (kept,), torch.int32),
+                     ('nbr_s', (kept,), torch.int32), ('runs_t', (N, 8), torch.int32), ('runs_s', (N, 8), torch.int32),
+                     ('perm_t', (kept,), torch.int64), ('perm_s', (kept,), torch.int64), ('factors', (kept, 8), torch.float32),
+                     ('flags', (1,), torch.int32), ('rec_t', (kept + pad_rec, recf), torch.float32),
+                     ('rec_s', (kept + pad_rec, recf), torch.float32)]
+            if want_geo:
+                sizes.append(('geo_t', (kept + pad_geo, 8), torch.float32))
             gbytes = lib.fc_graph_workspace_bytes(N, kept, R, F, 1)
-            gws = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+            offs, total = {}, 0
+            for name, shape, dt in sizes:
+                nb = dt.itemsize
+                for d in shape:
+                    nb *= d
+                offs[name] = (total, nb)
+                total += (nb + 255) // 256 * 256
+            arena = torch.empty(total + gbytes, dtype=torch.uint8, device=dev)
+            b = {name: arena[offs[name][0]:offs[name][0] + offs[name][1]].view(dt).view(shape) for name, shape, dt in sizes}
+            b['rec_t'][kept:].zero_()
+            b['rec_s'][kept:].zero_()
+            if want_geo:
+                b['geo_t'][kept:].zero_()
+            else:
+                b['geo_t'] = None
+            factors, flags = b['factors'], b['flags']
+            gws = arena[total:]
             _lib.check(lib.fc_precomp_graph(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, kept, R, F, p(edges_out), p(ln), p(wxp),
                                             p(factors), p(b['rowptr_t']), p(b['nbr_t']), p(b['runs_t']), p(b['perm_t']),
                                             p(b['rowptr_s']), p(b['nbr_s']), p(b['runs_s']), p(b['perm_s']), p(b['rec_t']), p(b['rec_s']),

@@ -218,7 +218,7 @@ def test_fused_precomp_graph(dev, monkeypatch, N, k, B, R):
     e2, s2, l2, w2 = FCPrecomp(B, R, data.epsilon)(dd)
     monkeypatch.delenv('FIELDCONV_EAGER_STENCIL')
     assert torch.is_tensor(s2) and torch.equal(e1, e2) and torch.equal(torch.view_as_real(l1), torch.view_as_real(l2))
-    assert torch.equal(torch.view_as_real(w1), torch.view_as_real(w2))
+    assert rel_err(H(w1), H(w2)) < 1e-6                          # the area sums are float atomics: order-dependent rounding
     e3, s3, _, _ = FCPrecompRef(B, R, data.epsilon)(data)
     assert torch.equal(e1.cpu(), e3)
 
@@ -242,7 +242,7 @@ def test_fused_precomp_graph(dev, monkeypatch, N, k, B, R):
     assert rel_err(H(s1), H(s2)) < 2e-6 and s1._dense is not None          # any other use: the dense rows, once
     assert rel_err(H(torch.abs(s1)), H(s2.abs())) < 2e-6 and tuple(s1[5].shape) == (R, 2 * B + 1)
     bad = dd.supp_edges.clone()
-    bad[7, 0] = N + 3
+    bad[int(torch.argmin(dd.logMag)), 0] = N + 3          # an edge inside the support radius (dropped edges are never read)
     dd.supp_edges = bad
     with pytest.raises(IndexError):
         FCPrecomp(B, R, data.epsilon)(dd)
