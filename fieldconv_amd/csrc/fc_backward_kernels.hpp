@@ -150,6 +150,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         float2 exs = make_float2(0.f, 0.f);
         if (e_active && ejn < a.N) exs = gx_[(size_t)ejn * I + ei];
         float2 gxacc = make_float2(0.f, 0.f);
+        float eq = 0.f;                                   // sum_f m Im(conj(gxt_f) xt_f) of my entry
+        float2 eu1 = make_float2(1.f, 0.f), eu2 = eu1, eu3 = eu1;       // u, u^2, u^3 with u = exp(-i angle(x)) (1 inside the origin box)
+        float einv2 = 0.f;                                // 1 / |x|^2, 0 inside the origin box
+        bool e_ready = false;
 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -354,6 +358,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                                 }
                         }
                     }
+                    if (e_active && !e_ready) {         // (after the first slab: the load of exs has long landed)
+                        eu1 = unit_conj(exs);
+                        eu2 = cmul(eu1, eu1);
+                        if (B >= 3) eu3 = cmul(eu2, eu1);
+                        einv2 = is_origin(exs) ? 0.f : 1.f / (exs.x * exs.x + exs.y * exs.y);
+                        e_ready = true;
+                    }
                     if (e_active) {
                         const int m = f - B;
                         float2 z = sum_partials(part, mg, ev, ei);
@@ -362,24 +373,28 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             z.x *= k;
                             z.y *= k;
                         }
-                        const float2 c = unit_power(unit_conj(exs), m);
+                        // gx += gxt_f conj(u^m) + [x != 0] (i x / |x|^2) m Im(conj(gxt_f) x u^m); u, u^2, u^3 and 1/|x|^2 are
+                        // formed once per tile (eu1..eu3, einv2), the second term is collected as a scalar (eq)
+                        const int am = m < 0 ? -m : m;
+                        float2 c = am == 0 ? make_float2(1.f, 0.f) : (am == 1 ? eu1 : (am == 2 ? eu2 : eu3));
+                        if (m < 0) c.y = -c.y;
                         const float2 xtv = cmul(exs, c);
-                        float2 out = cmul_conj(z, c);
-                        if (m != 0 && !is_origin(exs)) {
-                            const float n2 = exs.x * exs.x + exs.y * exs.y;
-                            const float q = (float)m * (z.x * xtv.y - z.y * xtv.x) / n2;
-                            out.x += -exs.y * q;
-                            out.y += exs.x * q;
-                        }
+                        const float2 out = cmul_conj(z, c);
                         gxacc.x += out.x;
                         gxacc.y += out.y;
+                        eq += (float)m * (z.x * xtv.y - z.y * xtv.x);
                     }
                     // (`part` is next written after the following slab's first barrier)
                 }
             }
             if constexpr (SPLIT) vs = (vs == vscale) ? vscale + 2 * kTile : vscale;   // the next group writes the other buffer
         }
-        if (e_active && ejn < a.N) ggx[(size_t)(tile & ((1 << pl) - 1)) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
+        if (e_active && ejn < a.N) {
+            const float q = eq * einv2;                   // (i x / |x|^2) sum_f m Im(conj(gxt_f) xt_f)
+            gxacc.x += -exs.y * q;
+            gxacc.y += exs.x * q;
+            ggx[(size_t)(tile & ((1 << pl) - 1)) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
+        }
         beg = nbeg;
         end = nend;
 #pragma unroll

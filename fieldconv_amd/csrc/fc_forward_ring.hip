@@ -29,7 +29,7 @@ static int launch_forward_ring(const float2* x, const float* rec, const fc_csr* 
     auto kern = fc_forward_ring_kernel<R, B, GEO>;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, rec, g->rowptr, g->runs, wpk, y, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDuoThreads), lds, stream, x, rec, g->rowptr, g->runs, wpk, y, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -44,7 +44,6 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.ntiles = (d->N + kTile - 1) / kTile;
     a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
     a.part_stride = (uint32_t)forward_part_stride(d);
-    a.NS = p.NS;
     a.nr = p.nr;
     a.wpk_bytes = (uint32_t)(packed_ring_image_floats(d->O, F, d->I, d->R, p.g.split) * sizeof(float));
     a.slab_bytes_w = (uint32_t)(2 * p.g.split * p.g.MP * p.g.KP * 2);
@@ -52,7 +51,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
     const int nvt = a.ntiles << a.parts_log2;
-    const int grid = nvt < kNumCUs ? nvt : kNumCUs;
+    const int grid = nvt < 2 * kNumCUs ? nvt : 2 * kNumCUs;      // persistent: two workgroups per CU
     int rc = FC_ERR_UNSUPPORTED;
     const float2* x2 = reinterpret_cast<const float2*>(x);
     float2* y2 = reinterpret_cast<float2*>(a.parts_log2 ? static_cast<float*>(ws) : y);

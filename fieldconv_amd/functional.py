@@ -547,10 +547,19 @@ def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
         raise ValueError('trans_field: feature / stencil shapes do not match the zonal filters')
     if lift_sten.shape[2] > 2:          # the reference reads columns 0 and 1 of whatever it is given (classification.ipynb:195
         lift_sten = lift_sten[..., :2]  # passes the full stencil); a strided view, read in place
-    if Cin > 4 or R > 8:
-        raise ValueError('trans_field supports at most 4 scalar input channels and 8 rings')
+    if R > 8:
+        raise ValueError('trans_field supports at most 8 rings (n_rings 2..8 are compiled)')
     from .graph import get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
+    if Cin > 4:
+        # The output is a SUM over the input channels of per-channel terms (reference nn/trans_field.py:104-113): more
+        # than four scalar inputs (the kernels' lanes hold (channel, ring) pairs of four channels) run as blocks of four.
+        out = None
+        for i0 in range(0, Cin, 4):
+            part = trans_field(x[:, i0:i0 + 4], supp_edges, lift_sten, zonal_ang[:, i0:i0 + 4], zonal_mag[:, i0:i0 + 4],
+                               phase[:, i0:i0 + 4], ftype)
+            out = part if out is None else out + part
+        return out
     if O > MAX_CHANNELS:                   # the output channels are independent: blocks of 64 (one per lane)
         return torch.cat([_TransFieldFn.apply(x, lift_sten, zonal_ang[o0:o0 + MAX_CHANNELS], zonal_mag[o0:o0 + MAX_CHANNELS],
                                               phase[o0:o0 + MAX_CHANNELS], csr, int(ftype))

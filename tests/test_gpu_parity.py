@@ -194,7 +194,8 @@ def test_echo_block_and_lift_block_golden(dev):
 
 @pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1),
                                              (100, 80, 3, 48, 6, 1), (90, 40, 2, 16, 4, 1),      # 4 / 2 wavefronts per vertex
-                                             (120, 7, 3, 150, 6, 1)])                             # output channels in blocks of 64
+                                             (120, 7, 3, 150, 6, 1),                              # output channels in blocks of 64
+                                             (150, 9, 7, 20, 5, 1), (90, 6, 10, 70, 6, 0)])       # more than four scalar inputs: blocks of 4
 def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
     """The TransField kernels against the oracle's torch restatement run on the CPU in float64 (pinned to the reference
     fixtures by the CPU suite): ragged in-degrees, isolated vertices, a strided stencil view."""

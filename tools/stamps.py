@@ -14,14 +14,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__  # noqa: E402
 
-LABELS_FWD = {0: 'run gathered', 1: 'flush: buffer free', 2: 'flush: row stored+arrived', 3: 'contract: slab full', 4: 'contract: mma done',
-              5: 'first_rows issued', 6: 'epi: partial stored', 7: 'epi: all partials in', 8: 'epi: y stored', 10: 'tile start'}
+LABELS_FWD = {0: 'run gathered (2 targets)', 1: 'rows converted', 2: 'barrier: slab full', 3: 'contracted', 4: 'barrier: slab free',
+              5: 'last slab contracted, partials stored', 6: 'y stored', 10: 'tile start'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('which', nargs='?', default='fwd')
-    ap.add_argument('--wave', type=int, nargs='*', default=[0, 7, 15])
+    ap.add_argument('--wave', type=int, nargs='*', default=[0, 7])
     ap.add_argument('--tiles', type=int, default=2)
     args = ap.parse_args()
     __graft_entry__.build()
@@ -45,6 +45,7 @@ def main():
         step()
     torch.cuda.synchronize()
     buf = torch.zeros(16 * 256, dtype=torch.int64, device=dev)
+    os.environ.setdefault('FC_RING', '1')
     lib = _lib.load()
     lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     if args.which == 'fwd':
@@ -56,7 +57,7 @@ def main():
     lib.fc_debug_stamp_buffer(None)
     st = buf.cpu().view(16, 256)
     labels = LABELS_FWD
-    t0 = min(int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0]))
+    t0 = min([int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0])] or [0])
     # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
     import collections
     print('per-wave cycles by phase (whole launch):')
@@ -69,10 +70,17 @@ def main():
             if v == 0:
                 break
             lab, t = (v >> 56) & 0xff, v & ((1 << 56) - 1)
+            if lab in (29, 31):
+                continue
             if prev is not None:
                 acc[lab] += t - prev
             prev = t
         print(f'{w:4d} ' + ' '.join(f'{acc[k]:15d}' for k in names) + f'  {sum(acc.values()):7d}')
+    # clock of the launch: shader cycles (28 -> 30) over the constant 100 MHz counter (29 -> 31)
+    ev = {(int(v) >> 56) & 0xff: int(v) & ((1 << 56) - 1) for v in st[0].tolist() if v}
+    if all(k in ev for k in (28, 29, 30, 31)) and ev[31] > ev[29]:
+        print(f'workgroup 0, wave 0: {ev[30] - ev[28]} shader cycles in {(ev[31] - ev[29]) / 100:.1f} us -> '
+              f'{(ev[30] - ev[28]) / (ev[31] - ev[29]) * 0.1:.2f} GHz')
     for w in args.wave:
         print(f'--- wave {w}')
         prev = None
@@ -81,6 +89,8 @@ def main():
             if v == 0:
                 break
             lab, t = (v >> 56) & 0xff, v & ((1 << 56) - 1)
+            if lab in (28, 29, 30, 31):
+                continue
             if lab == 10:
                 tiles += 1
                 if tiles > args.tiles:
