@@ -340,13 +340,18 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
 
     # per-mesh preprocessing = everything between the reference's data object and the first convolution launch: FCPrecomp's
-    # selection, the two edge groupings and the per-edge records (one fused build; the first call above paid one-off
-    # library initialisation)
+    # selection, the two edge groupings and the per-edge records (one fused build).  Mean of 20 builds after 3 untimed ones
+    # (the first ones pay library initialisation and the caching allocator's first large blocks).
+    pre_fresh = FCPrecomp(B, R, data.epsilon)
+    inputs = (data.logMag, data.logAng, data.w, data.supp_edges, data.xp)
+    for _ in range(3):
+        pre_fresh._compute(*inputs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    FCPrecomp(B, R, data.epsilon)(data)
+    for _ in range(20):
+        pre_fresh._compute(*inputs)
     torch.cuda.synchronize()
-    prep_ms = (time.perf_counter() - t0) * 1e3
+    prep_ms = (time.perf_counter() - t0) / 20 * 1e3
     mesh_graph = get_graph(edges, sten, n_local)            # the instance every convolution will use
     if plan is not None and os.environ.get('BENCH_NO_OVERLAP', '0') != '1':
         overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel

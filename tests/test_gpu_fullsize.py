@@ -246,3 +246,38 @@ def test_fused_precomp_graph(dev, monkeypatch, N, k, B, R):
     dd.supp_edges = bad
     with pytest.raises(IndexError):
         FCPrecomp(B, R, data.epsilon)(dd)
+
+
+def test_precomp_cache_round_trip(dev, tmp_path):
+    """Cached per-mesh preprocessing (transforms/precomp_cache.py): what the fused FCPrecomp produced is written to a file
+    and read back; the loaded (supp_edges, supp_sten, ln, wxp) drive a FCResNetBlock and an ECHOBlock to bit-identical
+    results without any preprocessing kernel."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.graph import FactoredStencil
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
+    from fieldconv_amd.transforms import FCPrecomp, load_precomp, save_precomp
+    if os.environ.get('FIELDCONV_DENSE') == '1' or os.environ.get('FIELDCONV_EAGER_STENCIL') == '1':
+        pytest.skip('the fused build is switched off in this mode')
+    N, k, C, B, R = 700, 18, 12, 2, 6
+    data = sphere_support(N, k, seed=3, support='p95').to(dev)
+    out = FCPrecomp(B, R, data.epsilon)(data)
+    path = str(tmp_path / 'mesh.fcp')
+    save_precomp(path, out, B, data.epsilon)
+    e2, s2, l2, w2 = load_precomp(path, dev)
+    assert isinstance(s2, FactoredStencil) and torch.equal(e2, out[0]) and torch.equal(s2.factors, out[1].factors)
+    for name in ('rowptr_t', 'nbr_t', 'runs_s', 'perm_s', 'rec_t', 'rec_s', 'geo_t'):
+        assert torch.equal(getattr(s2.graph, name), getattr(out[1].graph, name)), name
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleDict(dict(lift=LiftBlock(3, C, n_rings=R), res=FCResNetBlock(C, C, band_limit=B, n_rings=R),
+                                    echo=ECHOBlock(C, 5, n_des=C, n_bins=2, band_limit=B, n_rings=R))).to(dev)
+    pos = torch.randn(N, 3, device=dev)
+
+    def run(edges, sten, ln, wxp):
+        x = mods['lift'](pos, edges, sten[..., B:B + 2])
+        x = mods['res'](x, edges, sten)
+        return mods['echo'](x, edges, sten, ln, wxp)
+    ya, yb = run(*out), run(e2, s2, l2, w2)
+    assert torch.equal(ya, yb)
+    with pytest.raises(ValueError):
+        torch.save({'format': 'something else'}, path)
+        load_precomp(path, dev)

@@ -271,3 +271,24 @@ def test_factored_and_geometric_records_reconstruct_the_stencil():
     g = torch.Generator().manual_seed(0)
     dense = torch.complex(torch.randn(50, 4, 5, generator=g), torch.randn(50, 4, 5, generator=g))
     assert factor_stencil(dense) is None
+
+
+def test_factored_stencil_stands_in_for_the_tensor():
+    """FactoredStencil (what the fused FCPrecomp returns in place of supp_sten): dense rows, the two LiftBlock columns
+    and torch functions from the (E,8) factor table, against the oracle's FCPrecomp stencil."""
+    import torch
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.graph import FactoredStencil, factor_stencil, geometric_phases
+    from oracle.torch_composites import FCPrecomp
+    B, R = 2, 6
+    data = sphere_support(120, 9, seed=2, support='p95')
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    fac = geometric_phases(factor_stencil(sten), 2 * B + 1)          # [q, w_q, w_{q+1}, 0, c, g]: the factor table's layout
+    assert fac is not None
+    s = FactoredStencil(fac, R, 2 * B + 1, graph=None)
+    assert tuple(s.shape) == tuple(sten.shape) and s.dim() == 3 and s.dtype == torch.complex64 and len(s) == sten.shape[0]
+    lift = s[..., B:B + 2]
+    assert s._dense is None and float((lift - sten[..., B:B + 2]).abs().max()) < 2e-6 * float(sten.abs().max())
+    assert float((s.materialize() - sten).abs().max()) < 2e-6 * float(sten.abs().max())
+    assert torch.allclose(torch.abs(s), sten.abs(), atol=1e-6) and torch.allclose(s.abs(), sten.abs(), atol=1e-6)
+    assert tuple(s[3:7].shape) == (4, R, 2 * B + 1) and s.contiguous().is_contiguous()
