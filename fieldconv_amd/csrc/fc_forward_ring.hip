@@ -4,13 +4,11 @@
 
 namespace fc {
 
-// FC_RING=1 selects the ring-major record kernels for the forward pass (read once per process).  They are an
-// experiment that stays opt-in: parity-green, but on MI355X they run the config-2 layer in 145-170 us against the
-// 150 us of the frequency-major kernel (both are bound by vector-instruction issue at four cycles an
-// instruction and leave the SIMDs idle half of the time; reordering the contraction does not change either).  They
-// exist for the default two-halves mode only.
+// The record-driven forward pass runs the ring-major kernels (two 8-wavefront workgroups per CU) in the default
+// two-halves mode; FC_RING=0 keeps the frequency-major ones (one 16-wavefront workgroup per CU; also what FC_MFMA=f32 / f16
+// run).  Read once per process.  Config 2 on MI355X: 138 us against 150 us.
 bool ring_enabled() {
-    static const bool on = [] { const char* e = getenv("FC_RING"); return e && atoi(e) != 0; }();
+    static const bool on = [] { const char* e = getenv("FC_RING"); return !(e && atoi(e) == 0); }();
     return on && split_mode() == 2;
 }
 
@@ -52,6 +50,15 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.stamps = debug_stamp_buffer();
     const int nvt = a.ntiles << a.parts_log2;
     const int grid = nvt < 2 * kNumCUs ? nvt : 2 * kNumCUs;      // persistent: two workgroups per CU
+    // the last, partly filled round: as half tiles when those still fit one round
+    const int rem = nvt % grid;
+    a.nv_full = nvt;
+    a.nv_total = nvt;
+    static const bool halves = !(getenv("FC_RING_HALVES") && atoi(getenv("FC_RING_HALVES")) == 0);
+    if (halves && a.parts_log2 == 0 && rem > 0 && 2 * rem <= grid) {
+        a.nv_full = nvt - rem;
+        a.nv_total = a.nv_full + 2 * rem;
+    }
     int rc = FC_ERR_UNSUPPORTED;
     const float2* x2 = reinterpret_cast<const float2*>(x);
     float2* y2 = reinterpret_cast<float2*>(a.parts_log2 ? static_cast<float*>(ws) : y);

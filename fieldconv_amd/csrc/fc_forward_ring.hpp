@@ -38,6 +38,10 @@ struct RingArgs {
     int parts_log2;         // edge split for small meshes, as in FwdArgs
     uint32_t part_stride;
     int nr;                 // 1 KiB record chunks per stream in the LDS ring (2 or 4)
+    int nv_full;            // work items [0, nv_full) are whole 16-vertex tiles; items beyond are HALF tiles (8 vertices, one per
+                            // wavefront): the last, partly filled round of a persistent grid is cut in two so that every
+                            // workgroup gets a share of it (1250 tiles on 512 workgroups: 2.6 tile times instead of 3)
+    int nv_total;           // work items in all
     uint32_t wpk_bytes;
     uint32_t slab_bytes_w;  // bytes of one ring's planes in the packed image: 2 * halves * MP * KP * 2
     int dbg;                // development only (FC_DEBUG): bit0 skip gather, bit1 skip MFMA
@@ -117,6 +121,10 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
     for (int idx = tid; idx < sfl; idx += kDuoThreads) l.slab[idx] = 0.f;
     __syncthreads();
 
+    // The second wavefront of a workgroup on each SIMD (waves 4..7) is the younger one and loses the issue arbitration to
+    // its older partner all the way: it gathers ~30 % slower and the older half waits for it at every barrier.  A static
+    // priority for the younger half evens that out (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+    if (wave >= kDuoWaves / 2 && !(a.dbg & 4)) __builtin_amdgcn_s_setprio(1);
     Stamper stamp{(a.stamps && blockIdx.x == 0) ? a.stamps + wave * 256 : nullptr, 0};
     const int cl = lane < I ? lane : 0;      // lanes >= I gather channel 0; lanes >= KI are never stored
     const int mt = wave % g.NMT, kp = wave / g.NMT;
@@ -139,8 +147,14 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
         int run[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) run[q] = 0;
-        const int t = (vt >> pl) * kTile + wave + kDuoWaves * j;
-        if (vt < nvt && t < a.N) {
+        int t = (vt >> pl) * kTile + wave + kDuoWaves * j;
+        bool live = vt < nvt;
+        if (vt >= a.nv_full) {                 // half tile: stream 0 only
+            const int h = vt - a.nv_full;
+            t = (a.nv_full + (h >> 1)) * kTile + (h & 1) * kDuoWaves + wave;
+            live = vt < a.nv_total && j == 0;
+        }
+        if (live && t < a.N) {
             const int rb = growptr[t];
             const int n = growptr[t + 1] - rb;
             const int part = vt & ((1 << pl) - 1);
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
 
     stamp.realtime(29);
     stamp(28);
-    for (int vt = first_tile_of_block(); vt < nvt; vt += gridDim.x) {
+    for (int vt = first_tile_of_block(); vt < a.nv_total; vt += gridDim.x) {
         int nbeg[2], nend[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) slot_range(vt + gridDim.x, j, par ^ 1, nbeg[j], nend[j]);
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
             }
             prefetch_w(q);                               // ring q's first filter fragments fly during the conversions
             flush_row(clo[0], 0);                        // ring q is final for both of my targets
-            flush_row(clo[1], 1);
+            if (vt < a.nv_full) flush_row(clo[1], 1);     // (half tile: rows 8..15 keep whatever finite values they hold)
             stamp(1);
             __syncthreads();
             stamp(2);
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
         }
         prefetch_w(R - 1);
         flush_row(clo[0], 0);                            // the outermost ring
-        flush_row(clo[1], 1);
+        if (vt < a.nv_full) flush_row(clo[1], 1);
         __syncthreads();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the next tile's first record chunks have landed)
 #pragma unroll
@@ -393,11 +407,14 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
         stamp(5);
         __syncthreads();                                 // partials complete; every MFMA read of the slab is done
         {
-            const int tile = vt >> pl;
-            float2* const yout = gy_ + (size_t)(vt & ((1 << pl) - 1)) * a.part_stride;
-            for (int idx = tid; idx < kTile * a.O; idx += kDuoThreads) {
+            const bool half = vt >= a.nv_full;
+            const int hh = vt - a.nv_full;
+            const int row0 = half ? (a.nv_full + (hh >> 1)) * kTile + (hh & 1) * kDuoWaves : (vt >> pl) * kTile;
+            const int nrows = half ? kDuoWaves : kTile;
+            float2* const yout = gy_ + (size_t)(half ? 0 : (vt & ((1 << pl) - 1))) * a.part_stride;
+            for (int idx = tid; idx < nrows * a.O; idx += kDuoThreads) {
                 const int v = idx / a.O, o = idx - v * a.O;
-                const int n = tile * kTile + v;
+                const int n = row0 + v;
                 float2 sm = sum_partials(l.part, g, v, o);
                 const float k = gwpk[o];             // the filter row's scale (a power of two)
                 sm.x *= k;

@@ -70,6 +70,7 @@ def run_conv(graph, x, W, gy, dev):
     (4400, 6, 8, 16, 1, 3),        # narrow layer: k = 24 padded to 32
     (5000, 7, 64, 64, 3, 6),       # FAUST shape (C=64, B=3): two frequency groups
     (4200, 9, 24, 56, 1, 8),       # eight rings
+    (8990, 7, 12, 16, 2, 6),       # 562 tiles: more than two workgroups per CU can hold at once (FC_RING=1: half tiles in the last round)
 ], ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d' % s)
 def test_multi_tile_workgroups_whole_tensors(shape, dev, monkeypatch):
     """Every output of the record-driven kernels against the oracle on meshes where a workgroup walks more than one

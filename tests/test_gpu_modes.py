@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ('test_fused_precomp_graph or test_fieldconv_golden or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
-          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40')
+          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or test_config2_record_kernels')
 
 MODES = {
     'fp32_mfma': {'FC_MFMA': 'f32'},                    # v_mfma_f32_16x16x4_f32 contractions, fp32 filter-gradient kernel
@@ -26,7 +26,8 @@ MODES = {
     'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
     'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
     'eager_stencil': {'FIELDCONV_EAGER_STENCIL': '1'},   # FCPrecomp returns the dense (E,R,F) tensor; graph built from it
-    'ring_major_forward': {'FC_RING': '1'},              # opt-in ring-major forward kernels (csrc/fc_forward_ring.hpp)
+    'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
+    'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
 }
 
 

@@ -45,7 +45,6 @@ def main():
         step()
     torch.cuda.synchronize()
     buf = torch.zeros(16 * 256, dtype=torch.int64, device=dev)
-    os.environ.setdefault('FC_RING', '1')
     lib = _lib.load()
     lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     if args.which == 'fwd':
