@@ -12,8 +12,12 @@ bool ring_enabled() {
     return on && split_mode() == 2;
 }
 
+// Meshes of fewer than 2 x 256 tiles (8192 vertices) cannot give every CU its two workgroups: they keep the frequency-major
+// kernels (with the edge split for the smallest ones); FC_RING=2 forces the ring-major kernels for any size (tests).
 bool forward_ring_fits(const fc_dims* d) {
-    return ring_enabled() && plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok;
+    static const bool force = [] { const char* e = getenv("FC_RING"); return e && atoi(e) == 2; }();
+    if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
+    return force || (d->N + kTile - 1) / kTile >= 2 * kNumCUs;
 }
 
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {
