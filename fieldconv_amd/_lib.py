@@ -21,8 +21,13 @@ class FcCsr(ctypes.Structure):
     _fields_ = [('rowptr', _vp), ('nbr', _vp), ('runs', _vp)]
 
 
+class FcEpilogue(ctypes.Structure):
+    _fields_ = [('addend', _vp), ('modrelu_bias', _vp), ('activated', _vp)]
+
+
 _DP = ctypes.POINTER(FcDims)
 _CP = ctypes.POINTER(FcCsr)
+_EP = ctypes.POINTER(FcEpilogue)
 
 # name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
 SIGNATURES = {
@@ -35,12 +40,12 @@ SIGNATURES = {
     'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _c_int32, _vp]),
     'fc_pack_filter_params': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _vp, _vp, _DP, _c_int32, _vp]),
     'fc_filter_param_grads': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _vp, _vp, _vp, _DP, _vp]),
-    'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _vp]),
+    'fc_forward': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _DP, _EP, _vp]),
     'fc_factored_record_floats': (ctypes.c_int, [_c_int32]),
     'fc_forward_workspace_bytes': (_sz, [_DP]),
-    'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
+    'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
     'fc_geometric_record_floats': (ctypes.c_int, []),
-    'fc_forward_geometric': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
+    'fc_forward_geometric': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
     'fc_backward_workspace_bytes': (_sz, [_DP]),
     'fc_backward_data': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),

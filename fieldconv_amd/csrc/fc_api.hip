@@ -41,7 +41,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 2; }
+int fc_abi_version(void) { return 3; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -87,12 +87,15 @@ int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* 
                                        static_cast<hipStream_t>(stream));
 }
 
+static bool epilogue_valid(const fc_epilogue* e) { return !e || !e->modrelu_bias || e->activated; }
+
 int fc_forward(const float* x, const float* sten, const fc_csr* by_target, const float* wpk_fwd, float* y,
-               const fc_dims* dims, void* stream) {
+               const fc_dims* dims, const fc_epilogue* epilogue, void* stream) {
+    if (!epilogue_valid(epilogue)) return FC_ERR_BAD_ARGUMENT;
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!sten || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, sten, by_target, wpk_fwd, y, dims, 0, nullptr, 0, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, sten, by_target, wpk_fwd, y, dims, 0, nullptr, 0, epilogue, static_cast<hipStream_t>(stream));
 }
 
 int fc_factored_record_floats(int32_t band_limit) { return band_limit >= 0 ? fc::factored_record_floats(band_limit) : 0; }
@@ -103,21 +106,23 @@ size_t fc_forward_workspace_bytes(const fc_dims* dims) {
 }
 
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd, float* y,
-                        void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+                        void* workspace, size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream) {
+    if (!epilogue_valid(epilogue)) return FC_ERR_BAD_ARGUMENT;
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!rec_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, 1, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, rec_t, by_target, wpk_fwd, y, dims, 1, workspace, workspace_bytes, epilogue, static_cast<hipStream_t>(stream));
 }
 
 int fc_geometric_record_floats(void) { return fc::kGeoRecordFloats; }
 
 int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_target, const float* wpk_fwd, float* y,
-                         void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+                         void* workspace, size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream) {
+    if (!epilogue_valid(epilogue)) return FC_ERR_BAD_ARGUMENT;
     if (!x || !y || !wpk_fwd || !by_target || !by_target->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!geo_t || !by_target->runs)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
-    return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, workspace, workspace_bytes, epilogue, static_cast<hipStream_t>(stream));
 }
 
 size_t fc_backward_workspace_bytes(const fc_dims* dims) {

@@ -4,15 +4,15 @@
 namespace fc {
 
 template int forward_impl_mode<false>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*, int,
-                                      void*, size_t, hipStream_t);
+                                      void*, size_t, const fc_epilogue*, hipStream_t);
 extern template int forward_impl_mode<true>(const float*, const float*, const fc_csr*, const float*, float*, const fc_dims*,
-                                            int, void*, size_t, hipStream_t);
+                                            int, void*, size_t, const fc_epilogue*, hipStream_t);
 
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y, const fc_dims* d,
-                 int kind, void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (kind != 0 && forward_ring_fits(d)) return forward_ring_impl(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream);
-    return split_mode() ? forward_impl_mode<true>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream)
-                        : forward_impl_mode<false>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, stream);
+                 int kind, void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream) {
+    if (kind != 0 && forward_ring_fits(d)) return forward_ring_impl(x, sten, g, wpk, y, d, kind, ws, ws_bytes, epi, stream);
+    return split_mode() ? forward_impl_mode<true>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, epi, stream)
+                        : forward_impl_mode<false>(x, sten, g, wpk, y, d, kind, ws, ws_bytes, epi, stream);
 }
 
 size_t forward_workspace_bytes(const fc_dims* d, int kind) { return forward_workspace_bytes_impl(d, kind); }

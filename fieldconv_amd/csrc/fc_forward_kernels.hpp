@@ -44,6 +44,7 @@ struct FwdArgs {
                         // the k-partials of the epilogue then live in whichever buffer is idle
     uint32_t wpk_bytes; // size of the packed filter image
     int dbg;            // development only (FC_DEBUG env): bit0 skip gather loop, bit1 skip MFMA loop
+    FwdEpi epi;         // residual / modReLU applied to the output tile (only when parts_log2 == 0; otherwise after the parts' sum)
 };
 
 // Frequencies are processed in NG groups of at most MG so that the per-lane response
@@ -192,7 +193,10 @@ __device__ __forceinline__ void forward_epilogue(const FwdLds& l, float* part, c
             s.x *= k;
             s.y *= k;
         }
-        if (n < a.N) gy_[(size_t)n * a.O + o] = s;
+        if (n < a.N) {
+            if (a.parts_log2 == 0) s = apply_epilogue(s, (size_t)n * a.O + o, o, a.epi);
+            gy_[(size_t)n * a.O + o] = s;
+        }
     }
     // `part` is rewritten only after the next tile's slab barriers; the next tile uses the other scale buffer
 }
@@ -506,7 +510,7 @@ inline size_t forward_workspace_bytes_impl(const fc_dims* d, int kind) {
 
 template <bool SPLIT>
 int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                      const fc_dims* d, int kind, void* ws, size_t ws_bytes, hipStream_t stream) {
+                      const fc_dims* d, int kind, void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream) {
     const bool factored = kind != 0;
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
@@ -515,6 +519,7 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     // without a workspace the tiles are not split (same result, fewer workgroups)
     a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
     a.part_stride = (uint32_t)forward_part_stride(d);
+    a.epi = make_epi(epi);
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, a.g.split) * sizeof(float));
     static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
@@ -544,7 +549,7 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
     if (rc != FC_OK || a.parts_log2 == 0) return rc;
-    return sum_parts(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, stream);
+    return sum_parts_epilogue(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, d->O, a.epi, stream);
 }
 
 }  // namespace fc

@@ -36,7 +36,7 @@ static int launch_forward_ring(const float2* x, const float* rec, const fc_csr* 
 }
 
 int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,
-                      void* ws, size_t ws_bytes, hipStream_t stream) {
+                      void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream) {
     const int F = 2 * d->B + 1;
     const RingPlan p = plan_ring(d->O, F, d->I, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
@@ -46,6 +46,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.ntiles = (d->N + kTile - 1) / kTile;
     a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;
     a.part_stride = (uint32_t)forward_part_stride(d);
+    a.epi = make_epi(epi);
     a.nr = p.nr;
     a.wpk_bytes = (uint32_t)(packed_ring_image_floats(d->O, F, d->I, d->R, p.g.split) * sizeof(float));
     a.slab_bytes_w = (uint32_t)(2 * p.g.split * p.g.MP * p.g.KP * 2);
@@ -73,7 +74,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
     if (rc != FC_OK || a.parts_log2 == 0) return rc;
-    return sum_parts(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, stream);
+    return sum_parts_epilogue(static_cast<const float*>(ws), y, (size_t)d->N * d->O, a.part_stride, 1 << a.parts_log2, d->O, a.epi, stream);
 }
 
 }  // namespace fc

@@ -45,6 +45,7 @@ struct RingArgs {
     uint32_t wpk_bytes;
     uint32_t slab_bytes_w;  // bytes of one ring's planes in the packed image: 2 * halves * MP * KP * 2
     int dbg;                // development only (FC_DEBUG): bit0 skip gather, bit1 skip MFMA
+    FwdEpi epi;             // residual / modReLU applied to the output tile (when parts_log2 == 0; otherwise after the parts' sum)
     unsigned long long* stamps;   // development only (fc_debug_stamp_buffer): s_memtime stamps of workgroup 0, [8 waves][256]
 };
 
@@ -419,7 +420,10 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
                 const float k = gwpk[o];             // the filter row's scale (a power of two)
                 sm.x *= k;
                 sm.y *= k;
-                if (n < a.N) yout[(size_t)n * a.O + o] = sm;
+                if (n < a.N) {
+                    if (pl == 0) sm = apply_epilogue(sm, (size_t)n * a.O + o, o, a.epi);
+                    yout[(size_t)n * a.O + o] = sm;
+                }
             }
         }
         stamp(6);

@@ -20,7 +20,7 @@ constexpr int kMaxChannels = 64;     // one channel per lane in the gather phase
 // kind: 0 dense stencil rows, 1 factored records, 2 geometric-phase records
 // ws: optional scratch of forward_workspace_bytes(d, kind) bytes that lets several workgroups share a tile on small meshes
 int forward_impl(const float* x, const float* sten, const fc_csr* g, const float* wpk, float* y,
-                 const fc_dims* d, int kind, void* ws, size_t ws_bytes, hipStream_t stream);
+                 const fc_dims* d, int kind, void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream);
 size_t forward_workspace_bytes(const fc_dims* d, int kind);
 size_t backward_workspace_bytes(const fc_dims* d);
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
@@ -39,7 +39,7 @@ bool ring_enabled();
 bool forward_ring_fits(const fc_dims* d);
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves);
 int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,
-                      void* ws, size_t ws_bytes, hipStream_t stream);
+                      void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream);
 int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 

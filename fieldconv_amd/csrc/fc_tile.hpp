@@ -270,6 +270,40 @@ __device__ __forceinline__ float2 sum_partials(const float* part, const MmaGeom&
     return make_float2(re, im);
 }
 
+// ---- forward epilogue (include/fieldconv_hip.h: fc_epilogue) ----
+struct FwdEpi {
+    const float2* addend;
+    const float* bias;
+    float2* activated;
+};
+inline FwdEpi make_epi(const fc_epilogue* e) {
+    FwdEpi r;
+    r.addend = e ? reinterpret_cast<const float2*>(e->addend) : nullptr;
+    r.bias = e ? e->modrelu_bias : nullptr;
+    r.activated = e ? reinterpret_cast<float2*>(e->activated) : nullptr;
+    return r;
+}
+// s = convolution output of entry idx (channel o): adds the residual, returns the pre-activation (what `y` receives) and
+// writes modReLU of it -- the arithmetic of tangent_nonlin_fwd_kernel (fc_pointwise.hip), bit for bit
+__device__ __forceinline__ float2 apply_epilogue(float2 s, size_t idx, int o, const FwdEpi& e) {
+    if (e.addend) {
+        const float2 a = e.addend[idx];
+        s.x += a.x;
+        s.y += a.y;
+    }
+    if (e.bias) {
+        float2 act = s;
+        if (!is_origin(s)) {
+            const float r = sqrtf(s.x * s.x + s.y * s.y);
+            const float f = fmaxf(r + e.bias[o], 0.f);
+            const float k = f / r;
+            act = make_float2(s.x * k, s.y * k);
+        }
+        e.activated[idx] = act;
+    }
+    return s;
+}
+
 // ---- edge split for small meshes (forward and backward data kernels) ----
 // dst[idx] = sum over parts of part[p][idx], in part order (float4 per thread; the parts are part_stride complex numbers
 // apart, a multiple of 2)
@@ -287,6 +321,20 @@ static __global__ void fc_sum_parts_kernel(const f32x4* __restrict__ part, f32x4
 }
 
 
+// the same for the forward pass with an epilogue: one complex number per thread (channel o = idx % O)
+static __global__ void fc_sum_parts_epilogue_kernel(const float2* __restrict__ part, float2* __restrict__ dst, size_t count, size_t stride,
+                                                    int parts, int O, const FwdEpi e) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    float2 s = part[idx];
+    for (int p = 1; p < parts; ++p) {
+        const float2 v = part[(size_t)p * stride + idx];
+        s.x += v.x;
+        s.y += v.y;
+    }
+    dst[idx] = apply_epilogue(s, idx, (int)(idx % (size_t)O), e);
+}
+
 // complex numbers between the partial outputs of the parts: `count` rounded up to a multiple of 2 (16-byte rows)
 inline size_t part_stride(size_t count) { return ((count + 1) / 2) * 2; }
 
@@ -295,6 +343,14 @@ inline int sum_parts(const float* part, float* dst, size_t count, size_t stride,
     const size_t floats = count * 2, count4 = (floats + 3) / 4;
     hipLaunchKernelGGL(fc_sum_parts_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dst), count4, stride / 2, parts, floats % 4);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+inline int sum_parts_epilogue(const float* part, float* dst, size_t count, size_t stride, int parts, int O, const FwdEpi& e,
+                              hipStream_t stream) {
+    if (!e.addend && !e.bias) return sum_parts(part, dst, count, stride, parts, stream);
+    hipLaunchKernelGGL(fc_sum_parts_epilogue_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(part), reinterpret_cast<float2*>(dst), count, stride, parts, O, e);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

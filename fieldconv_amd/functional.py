@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import FcCsr, FcDims, check
+from ._lib import FcCsr, FcDims, FcEpilogue, check
 
 
 class KernelTimer:
@@ -185,21 +185,28 @@ def _conv_plan(lib, graph, I, O, B):
     return plan
 
 
-def _launch_forward(lib, x, graph, wpk_f, plan, O, st):
+def _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=None, bias=None):
+    """-> y, or (pre-activation, activated) when a modReLU bias is given: the residual `addend` and the modReLU run in the
+    kernel's epilogue (include/fieldconv_hip.h: fc_epilogue)."""
     y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
+    act = torch.empty_like(y) if bias is not None else None
+    epi = None
+    if addend is not None or bias is not None:
+        epi = ctypes.byref(FcEpilogue(addend.data_ptr() if addend is not None else None, bias.data_ptr() if bias is not None else None,
+                                      act.data_ptr() if act is not None else None))
     nbytes = plan.ws_fwd
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     wsp = _p(ws) if ws is not None else None
     with _timed('fc_forward'):
         if graph.geo_t is not None:
-            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, st),
+            check(lib.fc_forward_geometric(_p(x), _p(graph.geo_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, epi, st),
                   'fc_forward_geometric')
         elif graph.factored:
-            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, st),
+            check(lib.fc_forward_factored(_p(x), _p(graph.rec_t), plan.cref_t, _p(wpk_f), _p(y), wsp, nbytes, plan.dref, epi, st),
                   'fc_forward_factored')
         else:
-            check(lib.fc_forward(_p(x), _p(graph.sten_t), plan.cref_t, _p(wpk_f), _p(y), plan.dref, st), 'fc_forward')
-    return y
+            check(lib.fc_forward(_p(x), _p(graph.sten_t), plan.cref_t, _p(wpk_f), _p(y), plan.dref, epi, st), 'fc_forward')
+    return y if bias is None else (y, act)
 
 
 def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
@@ -263,6 +270,81 @@ class _FieldConvParamFn(torch.autograd.Function):
             check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ctx.ftype, _p(g_z), _p(g_s),
                                             _p(g_p) if g_p is not None else None, ctypes.byref(dims), st), 'fc_filter_param_grads')
         return gx, g_z, g_s, g_p, None, None, None
+
+
+class _FieldConvActFn(torch.autograd.Function):
+    """modReLU(FieldConv(x) [+ addend]) with the residual add and the modReLU in the convolution's epilogue (SURVEY 8 row
+    f4; reference nn/fc_resnet_block.py:84-88, nn/tangent_nonlin.py:24-35).  The kernel leaves the pre-activation too; the
+    backward pass is the modReLU's VJP on it (fc_tangent_nonlin_backward) followed by the convolution's."""
+
+    @staticmethod
+    def forward(ctx, x, zonal, spherical, phase, bias, addend, ftype, B, graph):
+        lib = _lib.load()
+        x = x.contiguous()
+        zonal, spherical, phase = zonal.contiguous(), spherical.contiguous(), phase.contiguous()
+        bias = bias.contiguous()
+        addend = addend.contiguous() if addend is not None else None
+        O, I, R = zonal.shape[0], zonal.shape[1], zonal.shape[2]
+        F = 2 * B + 1
+        plan = _conv_plan(lib, graph, I, O, B)
+        with _on(x.device):
+            st = _stream()
+            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
+            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
+            check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), plan.dref,
+                                            plan.records, st), 'fc_pack_filter_params')
+            pre, act = _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=addend, bias=bias)
+        ctx.save_for_backward(x, wpk_b, zonal, spherical, phase, bias, pre)
+        ctx.graph, ctx.ftype, ctx.wshape, ctx.has_addend = graph, ftype, (O, I, R, F), addend is not None
+        return act
+
+    @staticmethod
+    def backward(ctx, g_act):
+        lib = _lib.load()
+        x, wpk_b, zonal, spherical, phase, bias, pre = ctx.saved_tensors
+        O, I, R, F = ctx.wshape
+        plan = _conv_plan(lib, ctx.graph, I, O, (F - 1) // 2)
+        g_act = g_act.contiguous()
+        N = pre.shape[0]
+        with _on(x.device):
+            st = _stream()
+            g_pre = torch.empty_like(pre)
+            g_bias = torch.empty_like(bias)
+            nbytes = lib.fc_tangent_nonlin_backward_workspace_bytes(N, O)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            check(lib.fc_tangent_nonlin_backward(_p(pre), _p(bias), _p(g_act), _p(g_pre), _p(g_bias), _p(ws), nbytes, N, O, st),
+                  'fc_tangent_nonlin_backward')
+            gx, gw = _launch_backward(lib, x, g_pre, ctx.graph, wpk_b, plan, ctx.wshape, st)
+            g_z = torch.empty_like(zonal)
+            g_s = torch.empty_like(spherical)
+            g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
+            check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ctx.ftype, _p(g_z), _p(g_s),
+                                            _p(g_p) if g_p is not None else None, plan.dref, st), 'fc_filter_param_grads')
+        return gx, g_z, g_s, g_p, g_bias, (g_pre if ctx.has_addend else None), None, None, None
+
+
+def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, addend=None):
+    """modReLU(FieldConv(x) + addend) as one forward kernel (see _FieldConvActFn); `bias` (1,O) or (O,), `addend` (N,O)
+    complex64 or None.  Layers wider than the kernels' channel block fall back to the separate operators."""
+    _require_device(x, 'field_conv')
+    O, I = zonal.shape[0], zonal.shape[1]
+    blk = _channel_block(graph, I, O, band_limit)
+    if I > blk or O > blk or os.environ.get('FIELDCONV_NO_FUSED_EPILOGUE', '0') == '1':
+        h = field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph)
+        if addend is not None:
+            h = h + addend
+        return tangent_nonlin(h, bias)
+    if x.dtype != torch.complex64:
+        raise ValueError('field_conv expects complex64 features')
+    if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != I:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {I})')
+    if zonal.shape[2] != graph.R or 2 * band_limit + 1 != graph.F:
+        raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={zonal.shape[2]}, band_limit={band_limit}')
+    if bias.numel() != O:
+        raise ValueError(f'bias has {bias.numel()} channels, the convolution {O}')
+    if addend is not None and (addend.dtype != torch.complex64 or tuple(addend.shape) != (graph.N, O)):
+        raise ValueError(f'addend must be complex64 of shape ({graph.N}, {O})')
+    return _FieldConvActFn.apply(x, zonal, spherical, phase, bias.reshape(-1), addend, int(ftype), int(band_limit), graph)
 
 
 MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)

@@ -36,17 +36,12 @@ class ECHOBlock(nn.Module):
         self.n_des = n_des
 
     def forward(self, x, supp_edges, supp_sten, ln, wxp):
-        h = self.conv(x, supp_edges, supp_sten)
         bias = self.nonlin.bias
-        if bias.shape[1] != h.shape[1]:
-            # reference behaviour: bias[0, channel index] is gathered per entry, so only the first
-            # n_des biases are ever used (requires n_des <= in_channels)
-            if bias.shape[1] < h.shape[1]:
-                raise ValueError('ECHOBlock requires n_des <= in_channels (reference nn/echo_block.py:57,93)')
-            from ..functional import tangent_nonlin
-            h = tangent_nonlin(h, bias[:, : h.shape[1]])
-        else:
-            h = self.nonlin(h)
+        if bias.shape[1] < self.n_des:
+            raise ValueError('ECHOBlock requires n_des <= in_channels (reference nn/echo_block.py:57,93)')
+        # reference behaviour: bias[0, channel index] is gathered per entry, so only the first n_des biases are ever used;
+        # the modReLU runs in the convolution's epilogue
+        h = self.conv.forward_act(x, supp_edges, supp_sten, bias[:, : self.n_des])
         d = self.echo(h, supp_edges, ln, wxp)
         d = d.reshape(d.shape[0], -1)
         d = F.relu(self.lin1(d))

@@ -19,6 +19,6 @@ class FCResNetBlock(nn.Module):
         self.res = TangentLin(in_channels, out_channels)
 
     def forward(self, x, supp_edges, supp_sten):
-        h = self.nonlin1(self.conv1(x, supp_edges, supp_sten))
-        h = self.conv2(h, supp_edges, supp_sten)
-        return self.nonlin2(self.res(x) + h)
+        # nonlin1(conv1(x)) and nonlin2(res(x) + conv2(h)): residual add and modReLU run in the convolutions' epilogues
+        h = self.conv1.forward_act(x, supp_edges, supp_sten, self.nonlin1.bias)
+        return self.conv2.forward_act(h, supp_edges, supp_sten, self.nonlin2.bias, addend=self.res(x))

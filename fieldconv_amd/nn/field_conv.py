@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 from torch.nn import Parameter
 
-from ..functional import field_conv, field_conv_params
+from ..functional import field_conv, field_conv_act, field_conv_params
 from ..graph import get_graph
 
 
@@ -93,3 +93,11 @@ class FieldConv(nn.Module):
             raise ValueError(f'supp_sten must be (E, {self.R}, {2 * self.B + 1}), got {tuple(supp_sten.shape)}')
         graph = get_graph(supp_edges, supp_sten, x.shape[0])
         return field_conv_params(x, self.zonal, self.spherical, self.phase, self.ftype, self.B, graph)
+
+    def forward_act(self, x, supp_edges, supp_sten, bias, addend=None):
+        """modReLU(self(x) + addend) with the residual add and the modReLU in the convolution kernel's epilogue: what
+        FCResNetBlock / ECHOBlock compute around their convolutions (reference nn/fc_resnet_block.py:84-88)."""
+        if supp_sten.dim() != 3 or supp_sten.shape[1] != self.R or supp_sten.shape[2] != 2 * self.B + 1:
+            raise ValueError(f'supp_sten must be (E, {self.R}, {2 * self.B + 1}), got {tuple(supp_sten.shape)}')
+        graph = get_graph(supp_edges, supp_sten, x.shape[0])
+        return field_conv_act(x, self.zonal, self.spherical, self.phase, self.ftype, self.B, graph, bias, addend)

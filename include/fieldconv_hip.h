@@ -94,12 +94,24 @@ int fc_filter_param_grads(const float* gw_eff, const float* zonal, const float* 
                           int32_t ftype, float* g_zonal, float* g_spherical, float* g_phase,
                           const fc_dims* dims, void* stream);
 
+/* Optional epilogue of the forward convolutions (reference nn/fc_resnet_block.py:84-88): what follows a
+ * FieldConv inside an FCResNetBlock / ECHOBlock is applied to the output tile before it leaves the kernel.
+ *   addend        (N,O) c64 or NULL   added to the convolution's output (the block's TangentLin residual)
+ *   modrelu_bias  O floats or NULL    TangentNonLin (reference nn/tangent_nonlin.py:24-35) of (conv + addend)
+ *   activated     (N,O) c64           receives the activated values; required with modrelu_bias
+ * `y` always receives conv + addend (the pre-activation: the backward pass of the modReLU needs it).  NULL epilogue = none. */
+typedef struct fc_epilogue {
+    const float* addend;
+    const float* modrelu_bias;
+    float* activated;
+} fc_epilogue;
+
 /* ---- FieldConv.forward, reference nn/field_conv.py:128-137 ------------------------------- *
  * y[n,o] = 1/F sum_{e: dst_e=n} sum_{i,r,f} x[src_e,i] e^{-i(f-B)phi[src_e,i]} S[e,r,f] W_eff[o,i,r,f]
  * x (N,I) c64; by_target: CSR grouped by target; sten_t (E,R,F) c64 = supp_sten rows permuted into
  * by_target slot order; y (N,O) c64 (overwritten). */
 int fc_forward(const float* x, const float* sten_t, const fc_csr* by_target, const float* wpk_fwd,
-               float* y, const fc_dims* dims, void* stream);
+               float* y, const fc_dims* dims, const fc_epilogue* epilogue, void* stream);
 
 /* ---- factored stencil fast path ---------------------------------------------------------- *
  * FCPrecomp's stencil (reference transforms/fc_precomp.py:24-25,95) is rank-1 and 2-sparse in the
@@ -115,7 +127,8 @@ int fc_forward(const float* x, const float* sten_t, const fc_csr* by_target, con
 int fc_factored_record_floats(int32_t band_limit);
 size_t fc_forward_workspace_bytes(const fc_dims* dims);
 int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_target, const float* wpk_fwd,
-                        float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
+                        float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue,
+                        void* stream);
 
 /* ---- geometric-phase records (forward only) ---------------------------------------------- *
  * FCPrecomp's phases are geometric in the frequency: ph[e,f] = c[e] * g[e]^(f-B) with |g| = 1
@@ -125,7 +138,8 @@ int fc_forward_factored(const float* x, const float* rec_t, const fc_csr* by_tar
  * bits, [4],[5] = Re, Im c, [6],[7] = Re, Im g.  Same result as fc_forward up to fp32 rounding. */
 int fc_geometric_record_floats(void);
 int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_target, const float* wpk_fwd,
-                         float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
+                         float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue,
+                         void* stream);
 
 /* ---- autograd of the above (the reference relies on torch autograd through :128-137) ----- *
  * Three calls on the same stream, sharing `workspace` (fc_backward_workspace_bytes(dims) bytes,

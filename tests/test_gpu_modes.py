@@ -26,6 +26,7 @@ MODES = {
     'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
     'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
     'eager_stencil': {'FIELDCONV_EAGER_STENCIL': '1'},   # FCPrecomp returns the dense (E,R,F) tensor; graph built from it
+    'separate_pointwise_operators': {'FIELDCONV_NO_FUSED_EPILOGUE': '1'},   # no residual / modReLU epilogue in the convolutions
     'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes below 8192 vertices

@@ -40,9 +40,9 @@ FACT = os.environ.get('FACT', '1') == '1' and graph.factored
 
 def fwd():
     if FACT:
-        lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(ct), _p(wf), _p(y), None, 0, ctypes.byref(dims), _stream())
+        lib.fc_forward_factored(_p(x), _p(graph.rec_t), ctypes.byref(ct), _p(wf), _p(y), None, 0, ctypes.byref(dims), None, _stream())
     else:
-        lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(ct), _p(wf), _p(y), ctypes.byref(dims), _stream())
+        lib.fc_forward(_p(x), _p(graph.sten_t), ctypes.byref(ct), _p(wf), _p(y), ctypes.byref(dims), None, _stream())
 
 
 def bwd_data():
