@@ -313,7 +313,7 @@ def run_dp(args, world, rank, dev, use_dist, backend):
 # ------------------------------------------------------------------------------------------ mode layer (the metric)
 def run_layer(args, world, rank, dev, use_dist, backend):
     from fieldconv_amd.data import sphere_partition
-    from fieldconv_amd.dist import GradientBuckets, HaloPlan, halo_exchange, overlap_backward
+    from fieldconv_amd.dist import GradientBuckets, HaloPlan, halo_exchange, overlap_backward, overlap_forward
     from fieldconv_amd.functional import kernel_timer
     from fieldconv_amd.graph import get_graph
     from fieldconv_amd.nn import FieldConv
@@ -322,7 +322,9 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     B, R, C, k = args.band_limit, args.n_rings, args.channels, args.k
     F = 2 * B + 1
     n_total = args.verts * world
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support)
+    overlap = use_dist and os.environ.get('BENCH_NO_OVERLAP', '0') != '1'
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support, interior_first=overlap)
+    n_interior = data.n_interior
     data = data.to(dev)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     n_local = data.num_nodes
@@ -354,11 +356,13 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) / 20 * 1e3
     mesh_graph = get_graph(edges, sten, n_local)            # the instance every convolution will use
-    if plan is not None and os.environ.get('BENCH_NO_OVERLAP', '0') != '1':
+    if overlap:
         overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel
+        overlap_forward(mesh_graph, plan, n_interior)       # interior targets are convolved while the halo rows travel
+    split_fwd = overlap and 0 < n_interior < n_local        # two forward launches per step
 
     def step():
-        xl = halo_exchange(x, plan) if plan is not None else x
+        xl = halo_exchange(x, plan, deferred=overlap) if plan is not None else x
         y = conv(xl, edges, sten)
         if plan is not None:
             y = y[:n_owned]
@@ -371,8 +375,10 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         return (x.grad,) + tuple(p.grad for p in params)
 
     def arm_timer():
-        kernel_timer.reset(pairs=3 * (args.steps // 4 + 1))
-        kernel_timer.stride = 4            # every 4th launch of each kernel inside the timed region carries a HIP-event pair
+        kernel_timer.reset(pairs=4 * (args.steps // 3 + 1))
+        # every 4th launch of each kernel inside the timed region carries a HIP-event pair (every 3rd when the forward pass
+        # is two launches per step, so that interior and boundary launches are sampled alternately)
+        kernel_timer.stride = 3 if split_fwd else 4
         kernel_timer.enabled = True
     elapsed = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer)
     kernel_timer.enabled = False
@@ -384,6 +390,8 @@ def run_layer(args, world, rank, dev, use_dist, backend):
 
     factored = bool(mesh_graph.factored)
     kt = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
+    if split_fwd and 'fc_forward' in kt:
+        kt['fc_forward'] *= 2               # interior + boundary launch
     fwd_b, bwd_b = algorithmic_bytes(n_local, E, C, C, R, F)
     fwd_f, bwd_f = algorithmic_flops(n_local, E, C, C, R, F, factored)
     gemm_f = 8 * n_local * C * C * R * F

@@ -104,7 +104,7 @@ def _rcb_order(pts, parts):
     return np.concatenate(pieces), bounds
 
 
-def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all'):
+def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all', interior_first=False):
     """G-geo: `n_total` jittered Fibonacci points on the unit sphere, k nearest neighbours
     (self included) as in-neighbours of every vertex, exact geodesic log map / transport, area
     weights.  The vertices are renumbered so that each of the `parts` compact patches (recursive
@@ -120,6 +120,9 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all'):
     support: 'all' -- the filter radius epsilon lies above every k-NN distance (no edge dropped by FCPrecomp, the outer
     rings stay empty); 'p95' -- epsilon is the 95-percentile of the k-NN distances (SURVEY 8(d) G-geo): FCPrecomp drops
     the longest 5 % of the edges and every ring of the radial interpolant is populated.
+
+    interior_first: inside every patch the vertices whose k neighbours all lie in the patch come first;
+    `data.n_interior` counts them for this rank (dist.overlap_forward convolves them while the halo rows travel).
     """
     from scipy.spatial import cKDTree
     pts = _fibonacci_sphere(n_total, 0, n_total, seed)
@@ -128,6 +131,13 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all'):
         pts = pts[perm]
     else:
         bounds = np.array([0, n_total], dtype=np.int64)
+    n_interior = None
+    if interior_first and parts > 1:
+        _, nbr_all = cKDTree(pts).query(pts, k=k)
+        owner = np.searchsorted(bounds[1:], np.arange(n_total), side='right')
+        boundary = (owner[nbr_all] != owner[:, None]).any(1)
+        pts = pts[np.argsort(owner * 2 + boundary, kind='stable')]          # patches stay contiguous ranges
+        n_interior = int(np.count_nonzero(~boundary[bounds[rank]:bounds[rank + 1]]))
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     e1, e2 = _frames(pts)
     tree = cKDTree(pts)
@@ -162,7 +172,7 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all'):
         logAng=torch.from_numpy(ang[order]).float(),
         xp=torch.polar(torch.ones(order.size), torch.from_numpy(xp_ang[order]).float()),
         w=torch.from_numpy(w_local).float()[:, None],
-        epsilon=eps, num_nodes=n_owned + int(remote.size))
+        epsilon=eps, num_nodes=n_owned + int(remote.size), n_interior=n_owned if n_interior is None else n_interior)
     return data, n_owned, torch.from_numpy(remote), torch.from_numpy(bounds)
 
 

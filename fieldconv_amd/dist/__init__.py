@@ -1,4 +1,4 @@
 from .grad_sync import GradientBuckets
-from .halo import HaloPlan, halo_exchange, overlap_backward
+from .halo import HaloPlan, halo_exchange, overlap_backward, overlap_forward
 
-__all__ = ['GradientBuckets', 'HaloPlan', 'halo_exchange', 'overlap_backward']
+__all__ = ['GradientBuckets', 'HaloPlan', 'halo_exchange', 'overlap_backward', 'overlap_forward']

@@ -43,16 +43,28 @@ class HaloPlan:
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_owned):
             raise ValueError('a peer asked for a vertex this rank does not own')
         self._early = {}           # gradient exchanges started by overlap_backward's hook: data_ptr -> (work, send, recv)
+        self._pending = None       # forward exchange still in flight (halo_exchange(..., deferred=True)): (work, send, x_local)
+
+    def wait_forward(self):
+        """The current stream waits for the forward exchange started by halo_exchange(..., deferred=True), if any."""
+        pending, self._pending = self._pending, None
+        if pending is not None and pending[0] is not None:
+            pending[0].wait()
 
 
 class _HaloExchange(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_owned, plan):
+    def forward(ctx, x_owned, plan, deferred):
         ctx.plan = plan
+        plan.wait_forward()                                     # an earlier deferred exchange nobody waited for
         send = x_owned.index_select(0, plan.send_idx).contiguous()
-        recv = torch.empty((plan.n_halo,) + tuple(x_owned.shape[1:]), dtype=x_owned.dtype, device=x_owned.device)
-        _a2a(recv, send, plan.recv_counts, plan.send_counts, plan.group)
-        return torch.cat((x_owned, recv), dim=0)
+        x_local = torch.empty((plan.n_owned + plan.n_halo,) + tuple(x_owned.shape[1:]), dtype=x_owned.dtype, device=x_owned.device)
+        recv = x_local[plan.n_owned:]                           # the halo rows arrive in place: no concatenation afterwards
+        work = _a2a(recv, send, plan.recv_counts, plan.send_counts, plan.group, async_op=deferred)
+        x_local[: plan.n_owned].copy_(x_owned)
+        if deferred:
+            plan._pending = (work, send, x_local)
+        return x_local
 
     @staticmethod
     def backward(ctx, g_local):
@@ -69,7 +81,7 @@ class _HaloExchange(torch.autograd.Function):
             recv = torch.empty((plan.send_idx.numel(),) + tuple(g_local.shape[1:]), dtype=g_local.dtype, device=g_local.device)
             _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group)
         g_owned.index_add_(0, plan.send_idx, recv)
-        return g_owned, None
+        return g_owned, None, None
 
 
 def _all_to_all(recv, send, recv_counts, send_counts, group, async_op=False):
@@ -110,6 +122,20 @@ def overlap_backward(graph, plan):
     graph.on_gx = on_gx
 
 
-def halo_exchange(x_owned, plan):
-    """(n_owned, C) -> (n_owned + n_halo, C): owned rows followed by the halo rows, differentiable."""
-    return _HaloExchange.apply(x_owned, plan)
+def overlap_forward(graph, plan, n_interior):
+    """Hide the forward halo exchange under the convolution of the interior targets.  With the owned vertices numbered so
+    that the first `n_interior` read owned sources only (data.sphere_partition(..., interior_first=True)), the forward pass
+    over this graph becomes two launches: targets [0, n_interior) while the halo rows are still arriving, then -- after the
+    stream waited for the exchange -- the boundary targets.  Use with halo_exchange(x, plan, deferred=True); per mesh."""
+    if not 0 <= int(n_interior) <= plan.n_owned:
+        raise ValueError('n_interior must lie in [0, n_owned]')
+    graph.forward_split = (int(n_interior), plan.wait_forward)
+
+
+def halo_exchange(x_owned, plan, deferred=False):
+    """(n_owned, C) -> (n_owned + n_halo, C): owned rows followed by the halo rows, differentiable.
+
+    deferred: return while the exchange is still in flight on the communicator's stream.  The halo rows of the result must
+    then not be read before plan.wait_forward(); a convolution over a graph prepared with overlap_forward(graph, plan, ...)
+    does that between its interior and boundary launches.  For any other consumer leave it False."""
+    return _HaloExchange.apply(x_owned, plan, bool(deferred))

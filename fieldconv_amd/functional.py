@@ -129,13 +129,12 @@ class _FieldConvFn(torch.autograd.Function):
         O, I, R, F = w_eff.shape
         B = (F - 1) // 2
         plan = _conv_plan(lib, graph, I, O, B)
-        dims = plan.dims
         with _on(x.device):
             st = _stream()
-            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
-            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
-            check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), ctypes.byref(dims), plan.records, st), 'fc_pack_filter')
-            y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
+
+            def pack(pl, wpk_f, wpk_b):
+                check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), pl.dref, pl.records, st), 'fc_pack_filter')
+            y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack)
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
         ctx.wshape = (O, I, R, F)
@@ -185,11 +184,17 @@ def _conv_plan(lib, graph, I, O, B):
     return plan
 
 
-def _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=None, bias=None):
+def _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=None, bias=None, out=None, row0=0):
     """-> y, or (pre-activation, activated) when a modReLU bias is given: the residual `addend` and the modReLU run in the
-    kernel's epilogue (include/fieldconv_hip.h: fc_epilogue)."""
-    y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
-    act = torch.empty_like(y) if bias is not None else None
+    kernel's epilogue (include/fieldconv_hip.h: fc_epilogue).  `plan` may cover the targets [row0, row0 + plan.dims.N) only
+    (_row_plan); the rows then land in the tensors of `out` = (y, activated)."""
+    n = plan.dims.N
+    if out is None:
+        y = torch.empty((n, O), dtype=torch.complex64, device=x.device)
+        act = torch.empty_like(y) if bias is not None else None
+    else:
+        y, act = out[0][row0:row0 + n], (out[1][row0:row0 + n] if out[1] is not None else None)
+        addend = addend[row0:row0 + n] if addend is not None else None
     epi = None
     if addend is not None or bias is not None:
         epi = ctypes.byref(FcEpilogue(addend.data_ptr() if addend is not None else None, bias.data_ptr() if bias is not None else None,
@@ -207,6 +212,59 @@ def _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=None, bias=None):
         else:
             check(lib.fc_forward(_p(x), _p(graph.sten_t), plan.cref_t, _p(wpk_f), _p(y), plan.dref, epi, st), 'fc_forward')
     return y if bias is None else (y, act)
+
+
+def _row_plan(lib, graph, whole, row0, nrows):
+    """Forward-launch plan for the targets [row0, row0 + nrows) of `graph`: the same records and sources, the grouping arrays
+    entered at row0 (fc_csr: row pointers are absolute slots, runs are per row).  The kernel variant -- and with it the
+    layout of the packed filter image -- follows the number of rows of the launch, hence a plan (and an image) of its own."""
+    key = ('rows', whole.dims.I, whole.dims.O, whole.dims.B, int(row0), int(nrows))
+    plan = graph._plans.get(key)
+    if plan is not None:
+        return plan
+    plan = _ConvPlan()
+    ends = graph.rowptr_t[[row0, row0 + nrows]].tolist()
+    plan.dims = FcDims(int(nrows), int(ends[1] - ends[0]), whole.dims.I, whole.dims.O, graph.R, whole.dims.B)
+    plan.dref = ctypes.byref(plan.dims)
+    plan.records = whole.records
+    plan.n_fwd = lib.fc_packed_filter_floats_fwd(plan.dref, plan.records)
+    plan.n_bwd = whole.n_bwd
+    plan.ws_bwd = whole.ws_bwd
+    plan.ws_fwd = 0
+    if os.environ.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1':
+        plan.ws_fwd = lib.fc_forward_workspace_bytes(plan.dref)
+    plan.csr_t = _csr(graph.rowptr_t[row0:], graph.nbr_t, graph.runs_t[row0:] if graph.runs_t is not None else None)
+    plan.csr_s, plan.cref_s = whole.csr_s, whole.cref_s
+    plan.cref_t = ctypes.byref(plan.csr_t)
+    graph._plans[key] = plan
+    return plan
+
+
+def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None):
+    """Filter images + forward launch(es).  pack(plan, wpk_f, wpk_b) enqueues the packing kernel.  -> (result of
+    _launch_forward, wpk_b).  A graph with `forward_split` = (n_first, between) (dist/halo.py: overlap_forward) runs the
+    targets [0, n_first) first, calls between() -- the wait for the halo rows of x, which only later targets read -- and
+    then the rest."""
+    dev = x.device
+    wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=dev)
+    split = graph.forward_split
+    if split is None or not graph.factored or not (0 < split[0] < graph.N):
+        wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=dev)
+        pack(plan, wpk_f, wpk_b)
+        if split is not None:
+            split[1]()
+        return _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=addend, bias=bias), wpk_b
+    n_first, between = split
+    y = torch.empty((graph.N, O), dtype=torch.complex64, device=dev)
+    act = torch.empty_like(y) if bias is not None else None
+    for row0, nrows in ((0, n_first), (n_first, graph.N - n_first)):
+        sub = _row_plan(lib, graph, plan, row0, nrows)
+        wpk_f = torch.empty(sub.n_fwd, dtype=torch.float32, device=dev)
+        pack(sub, wpk_f, wpk_b)
+        _launch_forward(lib, x, graph, wpk_f, sub, O, st, addend=addend, bias=bias, out=(y, act), row0=row0)
+        if row0 == 0:
+            between()
+    return (y if bias is None else (y, act)), wpk_b
 
 
 def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
@@ -241,14 +299,13 @@ class _FieldConvParamFn(torch.autograd.Function):
         O, I, R = zonal.shape[0], zonal.shape[1], zonal.shape[2]
         F = 2 * B + 1
         plan = _conv_plan(lib, graph, I, O, B)
-        dims = plan.dims
         with _on(x.device):
             st = _stream()
-            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
-            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
-            check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), ctypes.byref(dims),
-                                            plan.records, st), 'fc_pack_filter_params')
-            y = _launch_forward(lib, x, graph, wpk_f, plan, O, st)
+
+            def pack(pl, wpk_f, wpk_b):
+                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), pl.dref,
+                                                pl.records, st), 'fc_pack_filter_params')
+            y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
         ctx.graph, ctx.ftype, ctx.wshape = graph, ftype, (O, I, R, F)
         return y
@@ -289,11 +346,10 @@ class _FieldConvActFn(torch.autograd.Function):
         plan = _conv_plan(lib, graph, I, O, B)
         with _on(x.device):
             st = _stream()
-            wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=x.device)
-            wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=x.device)
-            check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), plan.dref,
-                                            plan.records, st), 'fc_pack_filter_params')
-            pre, act = _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=addend, bias=bias)
+            def pack(pl, wpk_f, wpk_b):
+                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), pl.dref,
+                                                pl.records, st), 'fc_pack_filter_params')
+            (pre, act), wpk_b = _run_forward(lib, x, graph, plan, O, st, pack, addend=addend, bias=bias)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase, bias, pre)
         ctx.graph, ctx.ftype, ctx.wshape, ctx.has_addend = graph, ftype, (O, I, R, F), addend is not None
         return act

@@ -233,7 +233,7 @@ class FactoredStencil:
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -274,6 +274,7 @@ class SupportGraph:
         self.perm_t = self.perm_s = None
         self._plans = {}           # launch plans per (in, out, band limit): functional._conv_plan
         self.on_gx = None          # optional callback(gx) between the data and filter kernels of a backward pass (dist/halo.py)
+        self.forward_split = None  # optional (n_first, callback): forward launches targets [0, n_first), calls back, then the rest
         if native is None:
             native = sten.is_cuda and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1'
         if native and E > 0 and 2 <= self.R <= 8 and self.F <= 7 and self.F % 2 == 1:
@@ -333,6 +334,7 @@ class SupportGraph:
         g._keep = (supp_edges,)
         g._plans = {}
         g.on_gx = None
+        g.forward_split = None
         g.sten_t = g.sten_s = None
         for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', 'rec_t', 'rec_s', 'runs_t', 'runs_s'):
             setattr(g, name, built[name])

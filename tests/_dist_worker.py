@@ -43,7 +43,10 @@ def main():
     on_gpu = os.environ.get('FC_DIST_TEST_DEVICE', 'cpu') == 'cuda'
     dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
     n_total, k, C, O, B, R = (3000, 12, 24, 16, 2, 6) if on_gpu else (400, 8, 5, 4, 1, 3)
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3)
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3, interior_first=True)
+    n_interior = data.n_interior
+    src, dst = data.supp_edges[:, 0], data.supp_edges[:, 1]
+    assert 0 < n_interior < n_owned and bool((src[dst < n_interior] < n_owned).all())      # interior targets read owned rows only
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     assert edges.shape[0] == n_owned * k
     plan = HaloPlan(n_owned, halo_global, bounds, device=dev)
@@ -54,17 +57,21 @@ def main():
     W = torch.complex(torch.randn(O, C, R, 2 * B + 1, generator=g), torch.randn(O, C, R, 2 * B + 1, generator=g)).requires_grad_(True)
     x_owned = x_all[lo:lo + n_owned].clone().to(dev).requires_grad_(True)
 
-    x_local = halo_exchange(x_owned, plan)
-    # the halo rows must be exactly the owners' rows
-    assert torch.equal(x_local[n_owned:].detach().cpu(), x_all[halo_global])
+    overlap = os.environ.get('FC_DIST_OVERLAP', '1') == '1'
+    x_local = halo_exchange(x_owned, plan, deferred=overlap)
+    if not (on_gpu and overlap):
+        plan.wait_forward()
+        # the halo rows must be exactly the owners' rows
+        assert torch.equal(x_local[n_owned:].detach().cpu(), x_all[halo_global])
     if on_gpu:
         from fieldconv_amd.functional import field_conv
         from fieldconv_amd.graph import SupportGraph
         Wd = W.detach().to(dev).requires_grad_(True)
         graph = SupportGraph(edges.to(dev), sten.to(dev), x_local.shape[0])
-        if os.environ.get('FC_DIST_OVERLAP', '1') == '1':
-            from fieldconv_amd.dist import overlap_backward
+        if overlap:
+            from fieldconv_amd.dist import overlap_backward, overlap_forward
             overlap_backward(graph, plan)           # the gradient exchange starts inside the convolution's backward pass
+            overlap_forward(graph, plan, n_interior)    # interior targets first, boundary targets after the halo rows arrived
         y_owned = field_conv(x_local, Wd, graph)[:n_owned]
         gx, gW = torch.autograd.grad(y_owned, [x_owned, Wd], grad_outputs=gy_all[lo:lo + n_owned].to(dev))
         y_owned, gx, gW = y_owned.cpu(), gx.cpu(), gW.cpu()
@@ -79,7 +86,7 @@ def main():
     # its own targets), mapped back to global vertex ids
     all_e, all_s = [], []
     for r in range(world):
-        dr, n_r, halo_r, _ = sphere_partition(n_total, world, r, k=k, seed=3)
+        dr, n_r, halo_r, _ = sphere_partition(n_total, world, r, k=k, seed=3, interior_first=True)
         er, sr, _, _ = FCPrecomp(B, R, dr.epsilon)(dr)
         to_global = torch.cat((torch.arange(int(bounds[r]), int(bounds[r]) + n_r), halo_r))
         all_e.append(to_global[er])

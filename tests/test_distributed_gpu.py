@@ -13,8 +13,11 @@ from conftest import ROOT, free_port
 pytestmark = pytest.mark.gpu
 
 
-def test_partitioned_fieldconv_two_ranks_one_gpu():
-    env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda')
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_partitioned_fieldconv_two_ranks_one_gpu(overlap):
+    """overlap=1: interior targets are convolved before the halo rows are waited for (dist.overlap_forward) and the gradient
+    exchange starts between the two backward kernels (dist.overlap_backward); overlap=0: exchange, then convolve."""
+    env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda', FC_DIST_OVERLAP=overlap)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)

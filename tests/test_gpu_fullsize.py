@@ -282,3 +282,39 @@ def test_precomp_cache_round_trip(dev, tmp_path):
     with pytest.raises(ValueError):
         torch.save({'format': 'something else'}, path)
         load_precomp(path, dev)
+
+
+@pytest.mark.parametrize('N,k,I,O,B,R,n_first', [
+    (20000, 32, 48, 48, 2, 6, 17000),      # ring-major kernel on the first range, frequency-major on the second
+    (9000, 16, 24, 32, 2, 6, 8200),        # both ranges on one kernel family; ranges not multiples of the 16-vertex tile
+    (700, 12, 16, 16, 1, 3, 5),            # a first range smaller than one tile
+])
+def test_forward_in_two_row_ranges_is_the_same_forward(dev, N, k, I, O, B, R, n_first):
+    """dist.overlap_forward launches the targets [0, n_first) and [n_first, N) separately (the halo exchange completes in
+    between).  Same records, same filter; the kernel variant follows the size of each launch (ring-major from 512 tiles
+    up), so the outputs agree to fp32 rounding rather than bit for bit; with and without the fused residual + modReLU
+    epilogue; the backward pass does not change at all."""
+    from fieldconv_amd.functional import field_conv_act
+    from fieldconv_amd.graph import SupportGraph
+    from fieldconv_amd.nn import FieldConv
+    edges, sten, x, gy, W = precomp_case(N, k, I, O, B, R, seed=4)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    assert graph.factored
+    calls = []
+    y0, gx0, gW0 = run_conv(graph, x, W, gy, dev)
+    graph.forward_split = (n_first, lambda: calls.append(1))
+    y1, gx1, gW1 = run_conv(graph, x, W, gy, dev)
+    assert calls == [1]
+    assert rel_err(H(y1), H(y0)) < 3e-6
+    assert np.array_equal(H(gx0), H(gx1)) and np.array_equal(H(gW0), H(gW1))
+
+    torch.manual_seed(3)
+    conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=1).to(dev)
+    bias = (0.05 * torch.randn(1, O)).to(dev)
+    addend = gy.to(dev)
+    xd = x.to(dev)
+    out = []
+    for split in (None, (n_first, lambda: None)):
+        graph.forward_split = split
+        out.append(field_conv_act(xd, conv.zonal, conv.spherical, conv.phase, conv.ftype, B, graph, bias, addend=addend))
+    assert rel_err(H(out[1]), H(out[0])) < 3e-6
