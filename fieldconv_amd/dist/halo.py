@@ -122,14 +122,23 @@ def overlap_backward(graph, plan):
     graph.on_gx = on_gx
 
 
-def overlap_forward(graph, plan, n_interior):
+def overlap_forward(graph, plan, n_interior, whole_rounds=True):
     """Hide the forward halo exchange under the convolution of the interior targets.  With the owned vertices numbered so
     that the first `n_interior` read owned sources only (data.sphere_partition(..., interior_first=True)), the forward pass
     over this graph becomes two launches: targets [0, n_interior) while the halo rows are still arriving, then -- after the
     stream waited for the exchange -- the boundary targets.  Use with halo_exchange(x, plan, deferred=True); per mesh."""
-    if not 0 <= int(n_interior) <= plan.n_owned:
+    n_first = int(n_interior)
+    if not 0 <= n_first <= plan.n_owned:
         raise ValueError('n_interior must lie in [0, n_owned]')
-    graph.forward_split = (int(n_interior), plan.wait_forward)
+    if whole_rounds and graph.rowptr_t.is_cuda:
+        # The ring-major forward kernel is a persistent grid of two workgroups per CU, 16 targets per tile: a first launch
+        # of whole rounds leaves no thinly filled last round behind (config 2 on one MI355X: +11 us for the second launch
+        # when split at 16 384 = 2 rounds, +40 us when split at the 18 504 interior targets; tools/split_forward_cost.py).
+        # Any prefix of the interior targets is interior.
+        per_round = 16 * 2 * torch.cuda.get_device_properties(graph.rowptr_t.device).multi_processor_count
+        if n_first >= per_round:
+            n_first -= n_first % per_round
+    graph.forward_split = (n_first, plan.wait_forward)
 
 
 def halo_exchange(x_owned, plan, deferred=False):
