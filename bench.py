@@ -199,33 +199,55 @@ def init_dist(dev, backend):
         os.close(saved_stdout)
 
 
-def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None):
-    for _ in range(warmup):
-        step()
+SETTLE_SECONDS = 0.3
+COLD_NOTE = ('the same warmup + steps as the first GPU work of the process, before the untimed clock_settle_steps: inside the clock '
+             "governor's ramp (see timed_loop); `value` is the repeat of the protocol after it")
 
+
+def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, settle=True):
+    """-> (seconds for `steps` steps, max over ranks; info).
+
+    The protocol is run twice.  First literally from a cold device: `warmup` steps, fence, `steps` steps, fence ->
+    info['cold_start'].  The MI355X's clock governor takes ~100 ms of sustained load to reach the clock it then holds
+    (tools/clock_trace.py: 2.0-2.1 GHz during the first 20 ms of work with a dip to 1.9 GHz after ~3 ms, 2.4 GHz from ~80 ms
+    on), so a 25-step run of 0.4 ms steps lies entirely inside that ramp.  Then the same steps keep the device busy for
+    SETTLE_SECONDS (untimed, reported as info['settle_steps']) and the protocol runs again at the sustained clock a training
+    run lives at: that second measurement is the return value.  settle=False: the cold run only."""
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-    fence()
-    if before_timed is not None:
-        before_timed()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+
+    def protocol(hook):
+        for _ in range(warmup):
+            step()
+        fence()
+        if hook is not None:
+            hook()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            if backend == 'gloo':
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    if not settle:
+        return protocol(before_timed), {'cold_start': None, 'settle_steps': 0}
+    cold = protocol(None)
+    n_settle = max(1, int(SETTLE_SECONDS / (cold / steps)))          # the same count on every rank (cold is the max over ranks)
+    for _ in range(n_settle):
         step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        if backend == 'gloo':
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+    return protocol(before_timed), {'cold_start': cold, 'settle_steps': n_settle}
 
 
 def sum_over_ranks(value, use_dist, dev, backend):
@@ -288,11 +310,14 @@ def run_dp(args, world, rank, dev, use_dist, backend):
 
     edges0 = pre(data)[0]
     E = int(edges0.shape[0])
-    elapsed = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend)
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, settle=not args.cold)
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     if rank != 0:
         return None
     n_params = sum(p.numel() for p in params)
+    cold = None if info['cold_start'] is None else {
+        'ms_per_step': info['cold_start'] / args.steps * 1e3, 'value': E_total * n_convs / (info['cold_start'] / args.steps) / 1e6,
+        'note': COLD_NOTE}
     return {
         'metric': 'FieldConv fwd+bwd Medges/s (config 5: correspondence-net replicas, one mesh per GPU, C=64, M=3)',
         'value': E_total * n_convs / (elapsed / args.steps) / 1e6, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps,
@@ -306,7 +331,7 @@ def run_dp(args, world, rank, dev, use_dist, backend):
                    'parallelism': 'single GPU (replica)' if world == 1 and not use_dist else
                                   f'data-parallel x{world}: one mesh per GPU, one bucketed all-reduce of {4 * buckets.flat.numel()} gradient '
                                   f'bytes per step over RCCL'},
-        'roofline': None, 'cpu_baseline': None,
+        'roofline': None, 'cpu_baseline': None, 'clock_settle_steps': info['settle_steps'], 'cold_start': cold,
     }
 
 
@@ -359,7 +384,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     if overlap:
         overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel
         overlap_forward(mesh_graph, plan, n_interior)       # interior targets are convolved while the halo rows travel
-    split_fwd = overlap and 0 < n_interior < n_local        # two forward launches per step
+    split_fwd = mesh_graph.forward_split is not None and 0 < mesh_graph.forward_split[0] < n_local      # two forward launches per step
 
     def step():
         xl = halo_exchange(x, plan, deferred=overlap) if plan is not None else x
@@ -380,7 +405,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         # is two launches per step, so that interior and boundary launches are sampled alternately)
         kernel_timer.stride = 3 if split_fwd else 4
         kernel_timer.enabled = True
-    elapsed = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer)
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, settle=not args.cold)
     kernel_timer.enabled = False
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     ms_per_step = elapsed / args.steps * 1e3
@@ -441,6 +466,9 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
         'mesh_preprocessing_ms': prep_ms,
+        'clock_settle_steps': info['settle_steps'],
+        'cold_start': None if info['cold_start'] is None else {
+            'ms_per_step': info['cold_start'] / args.steps * 1e3, 'value': E_total / (info['cold_start'] / args.steps) / 1e6, 'note': COLD_NOTE},
     }
     y_def = gx_def = None
     if args.dump or (world == 1 and not use_dist and not args.no_extras):
@@ -512,6 +540,7 @@ def main():
                     help="support radius: 'p95' = 95-percentile of the k-NN distances (SURVEY 8(d) G-geo: FCPrecomp drops 5 %% of the "
                          "edges, every ring populated); 'all' = above every k-NN distance (round-1 mesh: E = N*k, outer rings empty)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cold', action='store_true', help='no clock-settling steps before the measurement (see timed_loop)')
     ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the child runs)')
     ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (child runs)')
     args = ap.parse_args()
