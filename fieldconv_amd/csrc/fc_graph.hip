@@ -6,9 +6,14 @@
 // The torch version of this (fieldconv_amd/graph.py) is ~100 small launches and two host synchronisations, 1.5-2.5 ms
 // per mesh -- as long as a whole training step of the segmentation network, and paid on every step of an epoch over
 // different meshes.  Here: one analysis kernel per edge (factorisation + verification + keys + bucket counts), one
-// kernel per vertex (ring-run offsets, degrees), two scans and two radix sorts (rocPRIM through hipCUB: plumbing), and
-// one placement kernel per side.  Slots are ordered by (vertex, lower ring q, original edge index): the sorts are
-// stable, the counts are integer atomics, so the result is deterministic.
+// kernel per vertex (ring-run offsets, degrees), two scans (rocPRIM through hipCUB: plumbing), a counting sort (below) and
+// one placement kernel per side.  Slots are ordered by (vertex, lower ring q, original edge index).  That order used to
+// come from two stable radix sorts of E (key, edge) pairs -- 20 merge passes each at E = 600 k, 240 us of the 510 us
+// a config-2 mesh took -- although the bucket counts the analysis kernel takes anyway already say where every
+// (vertex, ring) run starts: the atomic that counts an edge into its bucket returns its arrival index, which scatters
+// the edge into its run (graph_scatter_kernel), and the runs -- a handful of edges each -- are then put into ascending
+// edge order by rank (graph_order_kernel).  Integer atomics decide only the arrival order, which the ranking removes:
+// the result is deterministic and identical to the sorted one.
 #include <hipcub/hipcub.hpp>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
@@ -32,8 +37,8 @@ __device__ __forceinline__ float cabs2(float2 z) { return z.x * z.x + z.y * z.y;
 constexpr int kAnalyzeEdges = 128;
 __global__ __launch_bounds__(kAnalyzeEdges) void graph_analyze_kernel(
     const int64_t* __restrict__ edges, const float2* __restrict__ sten, float* __restrict__ rec, float* __restrict__ geo,
-    uint32_t* __restrict__ key_t, uint32_t* __restrict__ key_s, uint32_t* __restrict__ val, int32_t* __restrict__ cnt_t,
-    int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags, const GraphArgs a) {
+    uint32_t* __restrict__ key_t, uint32_t* __restrict__ key_s, uint32_t* __restrict__ arr_t, uint32_t* __restrict__ arr_s,
+    int32_t* __restrict__ cnt_t, int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags, const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* const rows = reinterpret_cast<float2*>(smem);              // [kAnalyzeEdges][R*F + 1]
     const int R = a.R, F = a.F, B = (F - 1) / 2;
@@ -152,9 +157,8 @@ __global__ __launch_bounds__(kAnalyzeEdges) void graph_analyze_kernel(
     const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
     key_t[e] = kt;
     key_s[e] = ks;
-    val[e] = (uint32_t)e;
-    atomicAdd(cnt_t + kt, 1);
-    atomicAdd(cnt_s + ks, 1);
+    arr_t[e] = (uint32_t)atomicAdd(cnt_t + kt, 1);          // arrival index inside the (vertex, ring) run
+    arr_s[e] = (uint32_t)atomicAdd(cnt_s + ks, 1);
 }
 
 // ---- per input edge, straight from FCPrecomp's inputs (reference transforms/fc_precomp.py:53-97): what graph_analyze_kernel
@@ -180,8 +184,9 @@ struct FactorArgs {
 };
 
 __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec, float* __restrict__ geo, uint32_t* __restrict__ key_t,
-                                    uint32_t* __restrict__ key_s, uint32_t* __restrict__ val, int32_t* __restrict__ cnt_t,
-                                    int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags, const GraphArgs a) {
+                                    uint32_t* __restrict__ key_s, uint32_t* __restrict__ arr_t, uint32_t* __restrict__ arr_s,
+                                    int32_t* __restrict__ cnt_t, int32_t* __restrict__ cnt_s, int32_t* __restrict__ flags,
+                                    const GraphArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.E_in || !p.keep[e]) return;
     const int slot = p.pos[e];
@@ -193,6 +198,14 @@ __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec,
         dst = min(max(dst, (int64_t)0), (int64_t)a.N - 1);
     }
     const float r = p.log_mag[e] / p.eps, theta = p.log_ang[e];
+    // upper knot: the first knot >= r, never knot 0 (csrc/fc_precomp.hip: precomp_stencil_kernel)
+    int hi = R - 1;
+    for (int k = R - 1; k >= 1; --k)
+        if (sqrtf((float)k / (float)(R - 1)) >= r) hi = k;
+    const int q = hi - 1;
+    // bucket counts first: the returning atomics' latency passes under the record arithmetic below
+    const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
+    const uint32_t at = (uint32_t)atomicAdd(cnt_t + kt, 1), as = (uint32_t)atomicAdd(cnt_s + ks, 1);
     float sn, cs;
     sincosf(theta, &sn, &cs);
     p.ln[slot] = make_float2(r * cs, r * sn);
@@ -202,13 +215,8 @@ __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec,
     p.wxp[slot] = c;
     p.edges_out[2 * (size_t)slot] = src;
     p.edges_out[2 * (size_t)slot + 1] = dst;
-    // upper knot: the first knot >= r, never knot 0 (csrc/fc_precomp.hip: precomp_stencil_kernel)
-    int hi = R - 1;
-    for (int k = R - 1; k >= 1; --k)
-        if (sqrtf((float)k / (float)(R - 1)) >= r) hi = k;
     const float k_lo = sqrtf((float)(hi - 1) / (float)(R - 1)), k_hi = sqrtf((float)hi / (float)(R - 1));
     const float w1 = (r - k_lo) / (k_hi - k_lo), w0 = 1.f - w1;
-    const int q = hi - 1;
     const float4 head = make_float4(__int_as_float(q), w0, w1, 0.f);
     const float4 cg = make_float4(c.x, c.y, cs, sn);
     float4* fp = reinterpret_cast<float4*>(p.factors + (size_t)slot * 8);
@@ -229,12 +237,10 @@ __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec,
         rp[5 + 2 * f] = ph.y;
     }
     for (int k = 4 + 2 * F; k < a.recf; ++k) rp[k] = 0.f;
-    const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
     key_t[slot] = kt;
     key_s[slot] = ks;
-    val[slot] = (uint32_t)slot;
-    atomicAdd(cnt_t + kt, 1);
-    atomicAdd(cnt_s + ks, 1);
+    arr_t[slot] = at;          // arrival index inside the (vertex, ring) run
+    arr_s[slot] = as;
 }
 
 // ---- per vertex: ring-run offsets (exclusive over q) and the degree, both sides
@@ -254,6 +260,73 @@ __global__ void graph_runs_kernel(const int32_t* __restrict__ cnt_t, const int32
     }
     deg_t[v] = at;
     deg_s[v] = as;
+}
+
+// ---- counting sort, step 1: every edge into its (vertex, ring) run, in arrival order
+__global__ void graph_scatter_kernel(const uint32_t* __restrict__ key_t, const uint32_t* __restrict__ key_s,
+                                     const uint32_t* __restrict__ arr_t, const uint32_t* __restrict__ arr_s,
+                                     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ rowptr_s,
+                                     const int32_t* __restrict__ runs_t, const int32_t* __restrict__ runs_s,
+                                     uint32_t* __restrict__ raw_t, uint32_t* __restrict__ raw_s, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint32_t kt = key_t[e], ks = key_s[e];
+    raw_t[(uint32_t)rowptr_t[kt >> 3] + (uint32_t)runs_t[kt] + arr_t[e]] = (uint32_t)e;
+    raw_s[(uint32_t)rowptr_s[ks >> 3] + (uint32_t)runs_s[ks] + arr_s[e]] = (uint32_t)e;
+}
+
+// ---- counting sort, step 2: every run into ascending edge order.  The edge ids of a run are distinct, so an id's place is
+// the number of smaller ids in the run.  One thread per run of up to kShortRun edges (a k-NN support has ~k/R per run);
+// longer runs (a vertex that collects thousands of edges in one ring) are listed and ranked by a whole workgroup each.
+constexpr int kShortRun = 32;
+__global__ void graph_order_kernel(const int32_t* __restrict__ cnt_t, const int32_t* __restrict__ cnt_s,
+                                   const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ rowptr_s,
+                                   const int32_t* __restrict__ runs_t, const int32_t* __restrict__ runs_s,
+                                   const uint32_t* __restrict__ raw_t, const uint32_t* __restrict__ raw_s,
+                                   uint32_t* __restrict__ ids_t, uint32_t* __restrict__ ids_s, int32_t* __restrict__ long_runs, int N) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;        // side * 8N + key
+    if (idx >= (long)N * 16) return;
+    const bool side_s = idx >= (long)N * 8;
+    const uint32_t key = (uint32_t)(idx - (side_s ? (long)N * 8 : 0));
+    const int len = (side_s ? cnt_s : cnt_t)[key];
+    if (len == 0) return;
+    const uint32_t beg = (uint32_t)(side_s ? rowptr_s : rowptr_t)[key >> 3] + (uint32_t)(side_s ? runs_s : runs_t)[key];
+    const uint32_t* in = (side_s ? raw_s : raw_t) + beg;
+    uint32_t* out = (side_s ? ids_s : ids_t) + beg;
+    if (len > kShortRun) {
+        const int at = atomicAdd(long_runs, 1);
+        long_runs[1 + at] = (int32_t)idx;                               // at most 16 N entries; ranked by graph_order_long_kernel
+        return;
+    }
+    for (int i = 0; i < len; ++i) {
+        const uint32_t mine = in[i];
+        int rank = 0;
+        for (int j = 0; j < len; ++j) rank += in[j] < mine ? 1 : 0;
+        out[rank] = mine;
+    }
+}
+
+__global__ __launch_bounds__(256) void graph_order_long_kernel(
+    const int32_t* __restrict__ cnt_t, const int32_t* __restrict__ cnt_s, const int32_t* __restrict__ rowptr_t,
+    const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ runs_t, const int32_t* __restrict__ runs_s,
+    const uint32_t* __restrict__ raw_t, const uint32_t* __restrict__ raw_s, uint32_t* __restrict__ ids_t, uint32_t* __restrict__ ids_s,
+    const int32_t* __restrict__ long_runs, int N) {
+    const int n_long = long_runs[0];
+    for (int l = blockIdx.x; l < n_long; l += gridDim.x) {
+        const long idx = long_runs[1 + l];
+        const bool side_s = idx >= (long)N * 8;
+        const uint32_t key = (uint32_t)(idx - (side_s ? (long)N * 8 : 0));
+        const int len = (side_s ? cnt_s : cnt_t)[key];
+        const uint32_t beg = (uint32_t)(side_s ? rowptr_s : rowptr_t)[key >> 3] + (uint32_t)(side_s ? runs_s : runs_t)[key];
+        const uint32_t* in = (side_s ? raw_s : raw_t) + beg;
+        uint32_t* out = (side_s ? ids_s : ids_t) + beg;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint32_t mine = in[i];
+            int rank = 0;
+            for (int j = 0; j < len; ++j) rank += in[j] < mine ? 1 : 0;
+            out[rank] = mine;
+        }
+    }
 }
 
 // ---- per slot: the other endpoint, the slot -> edge permutation and the records in slot order
@@ -288,28 +361,24 @@ __global__ __launch_bounds__(256) void graph_place_kernel(
 static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct GraphPlan {
-    size_t cnt, deg, keys, vals, rec, geo, cub, total;
+    size_t cnt, deg, keys, ids, longs, rec, geo, cub, total;
     size_t cub_bytes;
-    int bits;
 };
 
 static GraphPlan plan_graph(int N, int E, int recf, bool with_sten) {
     GraphPlan p;
-    p.bits = 3;
-    while (p.bits < 32 && ((uint64_t)1 << p.bits) < (uint64_t)N * 8) ++p.bits;
-    size_t sort_bytes = 0, scan_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, E, 0, p.bits);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1);
-    p.cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    size_t scan_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1);
+    p.cub_bytes = scan_bytes;
     size_t off = 0;
-    p.cnt = off;  off += align256((size_t)N * 8 * 4 * 2);             // cnt_t | cnt_s
-    p.deg = off;  off += align256((size_t)(N + 1) * 4 * 2);           // deg_t | deg_s
-    p.keys = off; off += align256((size_t)E * 4) * 3;                 // key_t | key_s | sorted keys (scratch)
-    p.vals = off; off += align256((size_t)E * 4) * 2;                 // val | sorted val
-    p.rec = off;  off += with_sten ? align256((size_t)E * recf * 4) : 0;
-    p.geo = off;  off += with_sten ? align256((size_t)E * 8 * 4) : 0;
-    p.cub = off;  off += align256(p.cub_bytes);
+    p.longs = off; off += align256(((size_t)N * 16 + 1) * 4);          // count + list of the runs longer than kShortRun
+    p.cnt = off;   off += align256((size_t)N * 8 * 4 * 2);             // cnt_t | cnt_s
+    p.deg = off;   off += align256((size_t)(N + 1) * 4 * 2);           // deg_t | deg_s
+    p.keys = off;  off += align256((size_t)E * 4) * 2;                 // key_t | key_s
+    p.ids = off;   off += align256((size_t)E * 4) * 4;                 // arrival index, later ordered ids: t | s; ids in arrival order: t | s
+    p.rec = off;   off += with_sten ? align256((size_t)E * recf * 4) : 0;
+    p.geo = off;   off += with_sten ? align256((size_t)E * 8 * 4) : 0;
+    p.cub = off;   off += align256(p.cub_bytes);
     p.total = off + 256;
     return p;
 }
@@ -330,7 +399,7 @@ static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, c
                             void* workspace, size_t workspace_bytes, void* stream) {
     if (N <= 0 || E < 0 || !rowptr_t || !rowptr_s || !runs_t || !runs_s || !flags || !workspace) return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!supp_edges || !nbr_t || !nbr_s || !perm_t || !perm_s)) return FC_ERR_BAD_ARGUMENT;
-    if ((uint64_t)N * 8 >= ((uint64_t)1 << 32)) return FC_ERR_UNSUPPORTED;
+    if ((uint64_t)N * 16 >= ((uint64_t)1 << 31)) return FC_ERR_UNSUPPORTED;
     const bool with_sten = supp_sten != nullptr || factors != nullptr;
     if (with_sten && (R < 2 || R > fc::kGraphMaxR || F < 1 || F > fc::kGraphMaxF || (F & 1) == 0 || !rec_t || !rec_s)) return FC_ERR_UNSUPPORTED;
     const int recf = (4 + 2 * F + 3) / 4 * 4;
@@ -345,42 +414,47 @@ static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, c
     const size_t ke = (((size_t)E * 4 + 255) / 256 * 256) / 4;
     uint32_t* key_t = reinterpret_cast<uint32_t*>(w + p.keys);
     uint32_t* key_s = key_t + ke;
-    uint32_t* key_sorted = key_s + ke;
-    uint32_t* val = reinterpret_cast<uint32_t*>(w + p.vals);
-    uint32_t* val_sorted = val + ke;
+    uint32_t* arr_t = reinterpret_cast<uint32_t*>(w + p.ids);         // arrival indices; the ordered ids take their place
+    uint32_t* arr_s = arr_t + ke;
+    uint32_t* raw_t = arr_s + ke;
+    uint32_t* raw_s = raw_t + ke;
+    int32_t* long_runs = reinterpret_cast<int32_t*>(w + p.longs);
     float* rec = with_sten ? reinterpret_cast<float*>(w + p.rec) : nullptr;
     float* geo = (with_sten && geo_t) ? reinterpret_cast<float*>(w + p.geo) : nullptr;
     void* cub = w + p.cub;
     size_t cub_bytes = p.cub_bytes;
     const fc::GraphArgs a{N, E, R, F, recf};
 
-    if (hipMemsetAsync(cnt_t, 0, (size_t)N * 8 * 4 * 2, s) != hipSuccess) return FC_ERR_LAUNCH;
+    // one fill: the long-run list (its counter is what matters) and the bucket counts are adjacent
+    if (hipMemsetAsync(w + p.longs, 0, (p.cnt - p.longs) + (size_t)N * 8 * 4 * 2, s) != hipSuccess) return FC_ERR_LAUNCH;
     if (hipMemsetAsync(flags, 0, 4, s) != hipSuccess) return FC_ERR_LAUNCH;
     if (factors) {
         if (factors->E_in > 0)
             hipLaunchKernelGGL(fc::graph_factor_kernel, dim3((factors->E_in + 255) / 256), dim3(256), 0, s, *factors, rec, geo, key_t, key_s,
-                               val, cnt_t, cnt_s, flags, a);
+                               arr_t, arr_s, cnt_t, cnt_s, flags, a);
     } else if (E > 0) {
         hipLaunchKernelGGL(fc::graph_analyze_kernel, dim3((E + fc::kAnalyzeEdges - 1) / fc::kAnalyzeEdges), dim3(fc::kAnalyzeEdges),
                            with_sten ? (size_t)fc::kAnalyzeEdges * (R * F + 1) * sizeof(float2) : 0, s, supp_edges,
-                           reinterpret_cast<const float2*>(supp_sten), rec, geo, key_t, key_s, val, cnt_t, cnt_s, flags, a);
+                           reinterpret_cast<const float2*>(supp_sten), rec, geo, key_t, key_s, arr_t, arr_s, cnt_t, cnt_s, flags, a);
     }
     hipLaunchKernelGGL(fc::graph_runs_kernel, dim3((N + 1 + 255) / 256), dim3(256), 0, s, cnt_t, cnt_s, runs_t, runs_s, deg_t, deg_s, N);
     if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, deg_t, rowptr_t, N + 1, s) != hipSuccess) return FC_ERR_LAUNCH;
     cub_bytes = p.cub_bytes;
     if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, deg_s, rowptr_s, N + 1, s) != hipSuccess) return FC_ERR_LAUNCH;
     if (E > 0) {
+        hipLaunchKernelGGL(fc::graph_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, s, key_t, key_s, arr_t, arr_s, rowptr_t, rowptr_s,
+                           runs_t, runs_s, raw_t, raw_s, E);
+        uint32_t* ids_t = arr_t;
+        uint32_t* ids_s = arr_s;
+        hipLaunchKernelGGL(fc::graph_order_kernel, dim3((unsigned)(((size_t)N * 16 + 255) / 256)), dim3(256), 0, s, cnt_t, cnt_s, rowptr_t,
+                           rowptr_s, runs_t, runs_s, raw_t, raw_s, ids_t, ids_s, long_runs, N);
+        hipLaunchKernelGGL(fc::graph_order_long_kernel, dim3(256), dim3(256), 0, s, cnt_t, cnt_s, rowptr_t, rowptr_s, runs_t, runs_s, raw_t,
+                           raw_s, ids_t, ids_s, long_runs, N);
         const size_t threads = (size_t)E * (recf / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
-        cub_bytes = p.cub_bytes;
-        if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, key_t, key_sorted, val, val_sorted, E, 0, p.bits, s) != hipSuccess)
-            return FC_ERR_LAUNCH;
-        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, val_sorted, supp_edges, 0, rec, geo, nbr_t, perm_t,
+        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, ids_t, supp_edges, 0, rec, geo, nbr_t, perm_t,
                            with_sten ? rec_t : nullptr, geo ? geo_t : nullptr, a);
-        cub_bytes = p.cub_bytes;
-        if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, key_s, key_sorted, val, val_sorted, E, 0, p.bits, s) != hipSuccess)
-            return FC_ERR_LAUNCH;
-        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, val_sorted, supp_edges, 1, rec, nullptr, nbr_s, perm_s,
+        hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, ids_s, supp_edges, 1, rec, nullptr, nbr_s, perm_s,
                            with_sten ? rec_s : nullptr, nullptr, a);
     }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;

@@ -13,7 +13,7 @@ rows in slot order, so this module builds, once per (supp_edges, supp_sten) pair
 Every FieldConv in a network receives the same pair (reference segmentation.ipynb:205), so the
 result is cached and the cost is amortised over all convolutions of a forward+backward.
 Device tensors are processed by the library's own build (csrc/fc_graph.hip through fc_graph_build: one analysis
-kernel, two radix sorts, two scans, two placement kernels, one host synchronisation for the verdict); the torch
+kernel, two scans, a counting sort, two placement kernels, one host synchronisation for the verdict); the torch
 version below (sort / bincount / cumsum / gather, ~100 launches) is what CPU tensors take and what the tests compare
 the native build against.
 """

@@ -718,6 +718,39 @@ def test_native_graph_build_matches_torch_build(dev, N, k, B, R):
         SupportGraph(bad, sten, N, native=True)
 
 
+def test_native_graph_build_hub_vertex(dev):
+    """A hub: every vertex sends an edge to vertex 7 and receives one from it, all at the same radius -- two (vertex, ring)
+    runs of 3 000 edges, far beyond what one thread orders (csrc/fc_graph.hip: graph_order_long_kernel).  Same slot order as
+    the torch build's stable sorts, and the convolution over it matches the oracle."""
+    from fieldconv_amd.data.synthetic import SupportData
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from oracle.torch_composites import FCPrecomp
+    N, B, R, C = 3000, 2, 6, 8
+    g = torch.Generator().manual_seed(5)
+    hub = torch.full((N,), 7)
+    ring = torch.arange(N)
+    edges = torch.cat((torch.stack((ring, hub), 1), torch.stack((hub, ring), 1)))
+    edges = edges[torch.randperm(2 * N, generator=g)]
+    E = edges.shape[0]
+    data = SupportData(supp_edges=edges, logMag=torch.full((E,), 0.55), logAng=(torch.rand(E, generator=g) * 2 - 1) * 3.14159,
+                       xp=torch.polar(torch.ones(E), (torch.rand(E, generator=g) * 2 - 1) * 3.14159), w=torch.ones(N, 1) / N,
+                       epsilon=1.0, num_nodes=N)
+    e2, sten, _, _ = FCPrecomp(B, R, 1.0)(data)
+    assert e2.shape[0] == E
+    a = SupportGraph(e2.to(dev), sten.to(dev), N, native=True)
+    b = SupportGraph(e2.to(dev), sten.to(dev), N, native=False)
+    runs7 = a.runs_t[7].tolist()
+    assert a.factored and int(a.rowptr_t[8] - a.rowptr_t[7]) == N + 1 and max(b_ - a_ for a_, b_ in zip(runs7, runs7[1:])) == N + 1
+    for name in ('rowptr_t', 'nbr_t', 'runs_t', 'perm_t', 'rowptr_s', 'nbr_s', 'runs_s', 'perm_s'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
+    W = torch.complex(torch.randn(C, C, R, 2 * B + 1, generator=g), torch.randn(C, C, R, 2 * B + 1, generator=g))
+    y = field_conv(x.to(dev), W.to(dev), a)
+    y_ref = orc.fieldconv_forward(x.numpy(), e2.numpy(), sten.numpy(), W.numpy())
+    assert rel_err(H(y), y_ref) < TOL
+
+
 @pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4), (60, 10, 130, 2)])
 def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     """ECHO descriptor kernels against the oracle's torch restatement run on the CPU in float64 (pinned to the reference
