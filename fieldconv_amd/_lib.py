@@ -57,7 +57,7 @@ SIGNATURES = {
     'fc_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [_vp]),
     'fc_precomp_workspace_bytes': (_sz, [_c_int32, _c_int32]),
     'fc_precomp_mark': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _c_int32, _c_int32, _vp, _sz, _vp]),
-    'fc_precomp_graph': (ctypes.c_int, [_vp] * 5 + [ctypes.c_float] + [_c_int32] * 5 + [_vp] * 16 + [_vp, _sz, _vp, _sz, _vp]),
+    'fc_precomp_graph': (ctypes.c_int, [_vp] * 5 + [ctypes.c_float] + [_c_int32] * 7 + [_vp] * 16 + [_vp, _sz, _vp, _sz, _vp]),
     'fc_precomp_kept_count_ptr': (_vp, [_vp, _c_int32]),
     'fc_precomp_build': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _c_int32, _c_int32, _c_int32, _c_int32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'fc_graph_workspace_bytes': (_sz, [_c_int32, _c_int32, _c_int32, _c_int32, _c_int32]),

@@ -26,6 +26,7 @@ constexpr float kGraphTol = 2e-6f;          // same acceptance threshold as grap
 
 struct GraphArgs {
     int N, E, R, F, recf;
+    int pad_rec, pad_geo;      // rows behind the E-th record that graph_place_kernel zero-fills (the kernels stream past the end)
 };
 
 __device__ __forceinline__ float cabs2(float2 z) { return z.x * z.x + z.y * z.y; }
@@ -338,7 +339,12 @@ __global__ __launch_bounds__(256) void graph_place_kernel(
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t slot = idx / pieces;
     const int piece = (int)(idx - slot * pieces);
-    if (slot >= (size_t)a.E) return;
+    if (slot >= (size_t)a.E) {                      // padding rows: zeros
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rec_out && slot < (size_t)a.E + a.pad_rec) *reinterpret_cast<float4*>(rec_out + slot * a.recf + 4 * piece) = z;
+        if (geo_out && piece < 2 && slot < (size_t)a.E + a.pad_geo) *reinterpret_cast<float4*>(geo_out + slot * 8 + 4 * piece) = z;
+        return;
+    }
     const uint32_t e = sorted_val[slot];
     int64_t o = edges[2 * (size_t)e + other_col];
     o = min(max(o, (int64_t)0), (int64_t)a.N - 1);
@@ -393,8 +399,9 @@ size_t fc_graph_workspace_bytes(int32_t N, int32_t E, int32_t R, int32_t F, int3
     return fc::plan_graph(N, E, recf, with_stencil != 0).total;
 }
 
+// pad_rec / pad_geo: rows behind the E-th of rec_t, rec_s / geo_t that are zero-filled
 static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, const fc::FactorArgs* factors, int32_t N, int32_t E,
-                            int32_t R, int32_t F, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
+                            int32_t pad_rec, int32_t pad_geo, int32_t R, int32_t F, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
                             int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags,
                             void* workspace, size_t workspace_bytes, void* stream) {
     if (N <= 0 || E < 0 || !rowptr_t || !rowptr_s || !runs_t || !runs_s || !flags || !workspace) return FC_ERR_BAD_ARGUMENT;
@@ -423,7 +430,8 @@ static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, c
     float* geo = (with_sten && geo_t) ? reinterpret_cast<float*>(w + p.geo) : nullptr;
     void* cub = w + p.cub;
     size_t cub_bytes = p.cub_bytes;
-    const fc::GraphArgs a{N, E, R, F, recf};
+    if (pad_rec < 0 || pad_geo < 0) return FC_ERR_BAD_ARGUMENT;
+    const fc::GraphArgs a{N, E, R, F, recf, pad_rec, pad_geo};
 
     // one fill: the long-run list (its counter is what matters) and the bucket counts are adjacent
     if (hipMemsetAsync(w + p.longs, 0, (p.cnt - p.longs) + (size_t)N * 8 * 4 * 2, s) != hipSuccess) return FC_ERR_LAUNCH;
@@ -450,7 +458,7 @@ static int graph_build_impl(const int64_t* supp_edges, const float* supp_sten, c
                            rowptr_s, runs_t, runs_s, raw_t, raw_s, ids_t, ids_s, long_runs, N);
         hipLaunchKernelGGL(fc::graph_order_long_kernel, dim3(256), dim3(256), 0, s, cnt_t, cnt_s, rowptr_t, rowptr_s, runs_t, runs_s, raw_t,
                            raw_s, ids_t, ids_s, long_runs, N);
-        const size_t threads = (size_t)E * (recf / 4);
+        const size_t threads = ((size_t)E + (pad_rec > pad_geo ? pad_rec : pad_geo)) * (recf / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
         hipLaunchKernelGGL(fc::graph_place_kernel, grid, dim3(256), 0, s, ids_t, supp_edges, 0, rec, geo, nbr_t, perm_t,
                            with_sten ? rec_t : nullptr, geo ? geo_t : nullptr, a);
@@ -464,12 +472,13 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
                    int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s, int32_t* nbr_s,
                    int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags, void* workspace,
                    size_t workspace_bytes, void* stream) {
-    return graph_build_impl(supp_edges, supp_sten, nullptr, N, E, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
+    return graph_build_impl(supp_edges, supp_sten, nullptr, N, E, 0, 0, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
                             rec_t, rec_s, geo_t, flags, workspace, workspace_bytes, stream);
 }
 
 int fc_precomp_graph(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
-                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int64_t* supp_edges_out, float* ln,
+                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int32_t rec_pad_rows,
+                     int32_t geo_pad_rows, int64_t* supp_edges_out, float* ln,
                      float* wxp, float* factors, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t, int32_t* rowptr_s,
                      int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t, int32_t* flags,
                      void* precomp_workspace, size_t precomp_workspace_bytes, void* graph_workspace, size_t graph_workspace_bytes,
@@ -492,7 +501,7 @@ int fc_precomp_graph(const float* log_mag, const float* log_ang, const float* xp
     fa.edges_out = supp_edges_out; fa.ln = reinterpret_cast<float2*>(ln); fa.wxp = reinterpret_cast<float2*>(wxp); fa.factors = factors;
     const int rc = fc::precomp_area_sums(supp_edges, fa.keep, w, total, N, E, s);
     if (rc != FC_OK) return rc;
-    return graph_build_impl(supp_edges_out, nullptr, &fa, N, E_kept, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
+    return graph_build_impl(supp_edges_out, nullptr, &fa, N, E_kept, rec_pad_rows, geo_pad_rows, R, F, rowptr_t, nbr_t, runs_t, perm_t, rowptr_s, nbr_s, runs_s, perm_s,
                             rec_t, rec_s, geo_t, flags, graph_workspace, graph_workspace_bytes, stream);
 }
 

@@ -71,9 +71,9 @@ class FCPrecomp(object):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.fc_precomp_mark(p(r), p(edges), eps, N, E, p(ws), nbytes, st), 'fc_precomp_mark')
             off = lib.fc_precomp_kept_count_ptr(p(ws), E) - ws.data_ptr()
-            kept, bad = ws[off:off + 8].view(torch.int32).tolist()        # the one synchronisation (the reference's `nonzero`)
-            if bad:
-                raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')
+            kept, bad = ws[off:off + 8].view(torch.int32).tolist()        # the one synchronisation (the reference's `nonzero`);
+            if bad:                                                       # early, while little is queued: the host enqueues
+                raise IndexError(f'supp_edges refers to a vertex outside [0, {N})')      # the rest without waiting again
             c64 = dict(dtype=torch.complex64, device=dev)
             edges_out = torch.empty((kept, 2), dtype=torch.int64, device=dev)
             ln, wxp = torch.empty(kept, **c64), torch.empty(kept, **c64)
@@ -89,7 +89,8 @@ class FCPrecomp(object):
             recf = (4 + 2 * F + 3) // 4 * 4
             want_geo = F >= 3 and os.environ.get('FIELDCONV_NO_GEO', '0') != '1'
             # one allocation for everything the build writes (a dozen separate ones cost more host time than the kernels
-            # take on a small mesh); the record arrays get 1 KiB + 16 rows of zeroed padding: the kernels stream past the end
+            # take on a small mesh); the record arrays get 1 KiB + 16 rows of padding, zero-filled by the build: the kernels
+            # stream past the end
             pad_rec, pad_geo = 1024 // (recf * 4) + 16, 1024 // 32 + 16
             sizes = [('rowptr_t', (N + 1,), torch.int32), ('rowptr_s', (N + 1,), torch.int32), ('nbr_t', (kept,), torch.int32),
                      ('nbr_s', (kept,), torch.int32), ('runs_t', (N, 8), torch.int32), ('runs_s', (N, 8), torch.int32),
@@ -108,18 +109,15 @@ class FCPrecomp(object):
                 total += (nb + 255) // 256 * 256
             arena = torch.empty(total + gbytes, dtype=torch.uint8, device=dev)
             b = {name: arena[offs[name][0]:offs[name][0] + offs[name][1]].view(dt).view(shape) for name, shape, dt in sizes}
-            b['rec_t'][kept:].zero_()
-            b['rec_s'][kept:].zero_()
-            if want_geo:
-                b['geo_t'][kept:].zero_()
-            else:
+            if not want_geo:
                 b['geo_t'] = None
-            factors, flags = b['factors'], b['flags']
+            factors = b['factors']
             gws = arena[total:]
-            _lib.check(lib.fc_precomp_graph(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, kept, R, F, p(edges_out), p(ln), p(wxp),
-                                            p(factors), p(b['rowptr_t']), p(b['nbr_t']), p(b['runs_t']), p(b['perm_t']),
-                                            p(b['rowptr_s']), p(b['nbr_s']), p(b['runs_s']), p(b['perm_s']), p(b['rec_t']), p(b['rec_s']),
-                                            p(b['geo_t']), p(flags), p(ws), nbytes, p(gws), gbytes, st), 'fc_precomp_graph')
+            _lib.check(lib.fc_precomp_graph(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, kept, R, F, pad_rec, pad_geo,
+                                            p(edges_out), p(ln), p(wxp), p(factors), p(b['rowptr_t']), p(b['nbr_t']), p(b['runs_t']),
+                                            p(b['perm_t']), p(b['rowptr_s']), p(b['nbr_s']), p(b['runs_s']), p(b['perm_s']),
+                                            p(b['rec_t']), p(b['rec_s']), p(b['geo_t']), p(b['flags']), p(ws), nbytes, p(gws), gbytes, st),
+                       'fc_precomp_graph')
         edges_ret = edges_out.to(supp_edges.dtype)
         graph = SupportGraph.from_precomp(edges_ret, N, R, F, b, want_geo)
         sten = FactoredStencil(factors, R, F, graph)

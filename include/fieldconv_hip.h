@@ -245,7 +245,9 @@ int fc_graph_build(const int64_t* supp_edges, const float* supp_sten, int32_t N,
  *                      (the stencil row is w_r * wxp * e^{i m theta}: anything that wants dense rows builds them from this),
  *                      and every output of fc_graph_build (both groupings, ring-run offsets, permutations, factored and
  *                      geometric records) -- the (E',R,F) stencil is never written or read.  graph_workspace:
- *                      fc_graph_workspace_bytes(N, E', R, F, 1) bytes; flags as for fc_graph_build (bits 0/1 never set). */
+ *                      fc_graph_workspace_bytes(N, E', R, F, 1) bytes; flags as for fc_graph_build (bits 0/1 never set).
+ *                      rec_t / rec_s hold E' + rec_pad_rows rows, geo_t E' + geo_pad_rows: the rows behind the E'-th are
+ *                      zero-filled here (the convolution kernels stream a little past the end of the records). */
 size_t fc_precomp_workspace_bytes(int32_t N, int32_t E);
 int fc_precomp_mark(const float* log_mag, const int64_t* supp_edges, float epsilon, int32_t N, int32_t E, void* workspace,
                     size_t workspace_bytes, void* stream);
@@ -254,8 +256,8 @@ int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp
                      float epsilon, int32_t N, int32_t E, int32_t R, int32_t F, int64_t* supp_edges_out, float* supp_sten,
                      float* ln, float* wxp, void* workspace, size_t workspace_bytes, void* stream);
 int fc_precomp_graph(const float* log_mag, const float* log_ang, const float* xp, const float* w, const int64_t* supp_edges,
-                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int64_t* supp_edges_out, float* ln,
-                     float* wxp, float* factors, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t,
+                     float epsilon, int32_t N, int32_t E, int32_t E_kept, int32_t R, int32_t F, int32_t rec_pad_rows,
+                     int32_t geo_pad_rows, int64_t* supp_edges_out, float* ln, float* wxp, float* factors, int32_t* rowptr_t, int32_t* nbr_t, int32_t* runs_t, int64_t* perm_t,
                      int32_t* rowptr_s, int32_t* nbr_s, int32_t* runs_s, int64_t* perm_s, float* rec_t, float* rec_s, float* geo_t,
                      int32_t* flags, void* precomp_workspace, size_t precomp_workspace_bytes, void* graph_workspace,
                      size_t graph_workspace_bytes, void* stream);
