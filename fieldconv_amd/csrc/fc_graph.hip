@@ -198,28 +198,45 @@ __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec,
         src = min(max(src, (int64_t)0), (int64_t)a.N - 1);
         dst = min(max(dst, (int64_t)0), (int64_t)a.N - 1);
     }
+    // every load first, then the two returning atomics, then the arithmetic, then the stores: memory operations return in
+    // issue order, so a load behind the atomics would wait for them (88 us for this kernel at config 2), while the
+    // arithmetic below does not
     const float r = p.log_mag[e] / p.eps, theta = p.log_ang[e];
+    const float2 x = p.xp[e];
+    const float wsrc = p.w[src], tot = p.total[dst];
     // upper knot: the first knot >= r, never knot 0 (csrc/fc_precomp.hip: precomp_stencil_kernel)
     int hi = R - 1;
     for (int k = R - 1; k >= 1; --k)
         if (sqrtf((float)k / (float)(R - 1)) >= r) hi = k;
     const int q = hi - 1;
-    // bucket counts first: the returning atomics' latency passes under the record arithmetic below
     const uint32_t kt = (uint32_t)dst * 8u + (uint32_t)q, ks = (uint32_t)src * 8u + (uint32_t)q;
     const uint32_t at = (uint32_t)atomicAdd(cnt_t + kt, 1), as = (uint32_t)atomicAdd(cnt_s + ks, 1);
     float sn, cs;
     sincosf(theta, &sn, &cs);
-    p.ln[slot] = make_float2(r * cs, r * sn);
-    const float scale = p.w[src] / (1e-12f + p.total[dst]);
-    const float2 x = p.xp[e];
+    const float scale = wsrc / (1e-12f + tot);
     const float2 c = make_float2(scale * x.x, scale * x.y);
-    p.wxp[slot] = c;
-    p.edges_out[2 * (size_t)slot] = src;
-    p.edges_out[2 * (size_t)slot + 1] = dst;
     const float k_lo = sqrtf((float)(hi - 1) / (float)(R - 1)), k_hi = sqrtf((float)hi / (float)(R - 1));
     const float w1 = (r - k_lo) / (k_hi - k_lo), w0 = 1.f - w1;
     const float4 head = make_float4(__int_as_float(q), w0, w1, 0.f);
     const float4 cg = make_float4(c.x, c.y, cs, sn);
+    float row[4 + 2 * kGraphMaxF + 2];            // the record: head, F phases, zero padding up to recf (<= 20)
+    row[0] = head.x; row[1] = w0; row[2] = w1; row[3] = 0.f;
+#pragma unroll
+    for (int f = 0; f < kGraphMaxF; ++f) {      // ph_f = e^{i (f-B) theta} * c, in the reference's order of operations
+        float2 ph = make_float2(0.f, 0.f);
+        if (f < F) {
+            float s_, c_;
+            sincosf((float)(f - B) * theta, &s_, &c_);
+            ph = cmul(make_float2(c_, s_), c);
+        }
+        row[4 + 2 * f] = ph.x;
+        row[5 + 2 * f] = ph.y;
+    }
+    row[4 + 2 * kGraphMaxF] = row[5 + 2 * kGraphMaxF] = 0.f;
+    p.ln[slot] = make_float2(r * cs, r * sn);
+    p.wxp[slot] = c;
+    p.edges_out[2 * (size_t)slot] = src;
+    p.edges_out[2 * (size_t)slot + 1] = dst;
     float4* fp = reinterpret_cast<float4*>(p.factors + (size_t)slot * 8);
     fp[0] = head;
     fp[1] = cg;
@@ -228,16 +245,10 @@ __global__ void graph_factor_kernel(const FactorArgs p, float* __restrict__ rec,
         gp[0] = head;
         gp[1] = cg;
     }
-    float* rp = rec + (size_t)slot * a.recf;
-    rp[0] = head.x; rp[1] = w0; rp[2] = w1; rp[3] = 0.f;
-    for (int f = 0; f < F; ++f) {          // ph_f = e^{i (f-B) theta} * c, in the reference's order of operations
-        float s_, c_;
-        sincosf((float)(f - B) * theta, &s_, &c_);
-        const float2 ph = cmul(make_float2(c_, s_), c);
-        rp[4 + 2 * f] = ph.x;
-        rp[5 + 2 * f] = ph.y;
-    }
-    for (int k = 4 + 2 * F; k < a.recf; ++k) rp[k] = 0.f;
+    float4* rp = reinterpret_cast<float4*>(rec + (size_t)slot * a.recf);
+#pragma unroll
+    for (int k = 0; k < (4 + 2 * kGraphMaxF + 2) / 4; ++k)
+        if (4 * k < a.recf) rp[k] = make_float4(row[4 * k], row[4 * k + 1], row[4 * k + 2], row[4 * k + 3]);
     key_t[slot] = kt;
     key_s[slot] = ks;
     arr_t[slot] = at;          // arrival index inside the (vertex, ring) run
