@@ -348,7 +348,11 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     F = 2 * B + 1
     n_total = args.verts * world
     overlap = use_dist and os.environ.get('BENCH_NO_OVERLAP', '0') != '1'
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support, interior_first=overlap)
+    # Forward overlap (interior targets under the halo exchange) is opt-in here: at this size the partitioned step is bound by
+    # the host's enqueue rate (tools/dist_overhead.py: 508 us of host time per step against 420 us of GPU work with it,
+    # the second forward launch being 43 us of that), so the exchange it would hide already falls into the GPU's idle time.
+    overlap_fwd = overlap and os.environ.get('BENCH_FORWARD_OVERLAP', '0') == '1'
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support=args.support, interior_first=overlap_fwd)
     n_interior = data.n_interior
     data = data.to(dev)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
@@ -381,16 +385,17 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) / 20 * 1e3
     mesh_graph = get_graph(edges, sten, n_local)            # the instance every convolution will use
+    if plan is not None:
+        mesh_graph.restrict_targets(n_owned)                # halo vertices are sources only: no output rows, no padded gy
     if overlap:
         overlap_backward(mesh_graph, plan)                  # gradient halo exchange under the filter-gradient kernel
+    if overlap_fwd:
         overlap_forward(mesh_graph, plan, n_interior)       # interior targets are convolved while the halo rows travel
     split_fwd = mesh_graph.forward_split is not None and 0 < mesh_graph.forward_split[0] < n_local      # two forward launches per step
 
     def step():
-        xl = halo_exchange(x, plan, deferred=overlap) if plan is not None else x
+        xl = halo_exchange(x, plan, deferred=overlap_fwd) if plan is not None else x
         y = conv(xl, edges, sten)
-        if plan is not None:
-            y = y[:n_owned]
         if buckets is None:
             return torch.autograd.grad(y, [x] + params, grad_outputs=gy)
         buckets.zero()

@@ -67,13 +67,13 @@ size_t fc_packed_filter_floats_bwd(const fc_dims* d, int32_t records) {
 }
 
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
-    if (!w_eff || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!w_eff || !wpk_fwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, records, static_cast<hipStream_t>(stream));
 }
 
 int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype, float* wpk_fwd,
                           float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
-    if (!zonal || !spherical || !wpk_fwd || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!zonal || !spherical || !wpk_fwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (ftype < 0 || ftype > 2 || (ftype == 1 && !phase)) return FC_ERR_BAD_ARGUMENT;
     return fc::pack_filter_params_impl(zonal, spherical, phase, ftype, wpk_fwd, wpk_bwd, dims, records,
                                        static_cast<hipStream_t>(stream));

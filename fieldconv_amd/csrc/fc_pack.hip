@@ -156,7 +156,7 @@ static int launch_pack(const float* w_eff, const float* zonal, const float* sph,
     a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
     a.blocks_f = pack_blocks(a.gf, a.ring_f ? a.R : a.F);
-    const unsigned blocks = a.blocks_f + pack_blocks(a.gb, a.F);
+    const unsigned blocks = a.blocks_f + (wpk_bwd ? pack_blocks(a.gb, a.F) : 0u);        // wpk_bwd == NULL: forward image only
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,
                        reinterpret_cast<const float2*>(w_eff), zonal, sph, phase, wpk_fwd, wpk_bwd, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;

@@ -43,6 +43,11 @@ class HaloPlan:
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_owned):
             raise ValueError('a peer asked for a vertex this rank does not own')
         self._early = {}           # gradient exchanges started by overlap_backward's hook: data_ptr -> (work, send, recv)
+        # per-call constants of the two exchanges (the partitioned step is bound by the host's enqueue rate: every
+        # microsecond of Python per collective counts)
+        self._staged = dist.get_backend(group) == 'gloo'
+        self._kw_fwd = dict(output_split_sizes=list(self.recv_counts), input_split_sizes=list(self.send_counts))
+        self._kw_bwd = dict(output_split_sizes=list(self.send_counts), input_split_sizes=list(self.recv_counts))
         self._pending = None       # forward exchange still in flight (halo_exchange(..., deferred=True)): (work, send, x_local)
 
     def wait_forward(self):
@@ -60,7 +65,7 @@ class _HaloExchange(torch.autograd.Function):
         send = x_owned.index_select(0, plan.send_idx).contiguous()
         x_local = torch.empty((plan.n_owned + plan.n_halo,) + tuple(x_owned.shape[1:]), dtype=x_owned.dtype, device=x_owned.device)
         recv = x_local[plan.n_owned:]                           # the halo rows arrive in place: no concatenation afterwards
-        work = _a2a(recv, send, plan.recv_counts, plan.send_counts, plan.group, async_op=deferred)
+        work = _exchange(plan, recv, send, True, async_op=deferred)
         x_local[: plan.n_owned].copy_(x_owned)
         if deferred:
             plan._pending = (work, send, x_local)
@@ -79,7 +84,7 @@ class _HaloExchange(torch.autograd.Function):
         else:
             send = g_local[plan.n_owned:].contiguous()
             recv = torch.empty((plan.send_idx.numel(),) + tuple(g_local.shape[1:]), dtype=g_local.dtype, device=g_local.device)
-            _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group)
+            _exchange(plan, recv, send, False)
         g_owned.index_add_(0, plan.send_idx, recv)
         return g_owned, None, None
 
@@ -99,10 +104,17 @@ def _all_to_all(recv, send, recv_counts, send_counts, group, async_op=False):
     return dist.all_to_all_single(recv, send, group=group, async_op=async_op, **kw)
 
 
-def _a2a(recv, send, recv_counts, send_counts, group, async_op=False):
+def _exchange(plan, recv, send, forward, async_op=False):
+    """The plan's exchange of complex rows (forward: owners -> halos; else halos -> owners)."""
     r = torch.view_as_real(recv) if recv.is_complex() else recv
     s = torch.view_as_real(send) if send.is_complex() else send
-    return _all_to_all(r, s, recv_counts, send_counts, group, async_op=async_op)
+    kw = plan._kw_fwd if forward else plan._kw_bwd
+    if plan._staged and recv.is_cuda:
+        h = torch.empty(r.shape, dtype=r.dtype)
+        dist.all_to_all_single(h, s.cpu(), group=plan.group, **kw)
+        r.copy_(h)
+        return None
+    return dist.all_to_all_single(r, s, group=plan.group, async_op=async_op, **kw)
 
 
 def overlap_backward(graph, plan):
@@ -116,7 +128,7 @@ def overlap_backward(graph, plan):
             return
         send = gx[plan.n_owned:]                                   # contiguous rows of a contiguous tensor
         recv = torch.empty((plan.send_idx.numel(),) + tuple(gx.shape[1:]), dtype=gx.dtype, device=gx.device)
-        work = _a2a(recv, send, plan.send_counts, plan.recv_counts, plan.group, async_op=True)
+        work = _exchange(plan, recv, send, False, async_op=True)
         plan._early.clear()
         plan._early[gx.data_ptr()] = (work, send, recv)
     graph.on_gx = on_gx

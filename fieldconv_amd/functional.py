@@ -133,7 +133,7 @@ class _FieldConvFn(torch.autograd.Function):
             st = _stream()
 
             def pack(pl, wpk_f, wpk_b):
-                check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b), pl.dref, pl.records, st), 'fc_pack_filter')
+                check(lib.fc_pack_filter(_p(w_eff), _p(wpk_f), _p(wpk_b) if wpk_b is not None else None, pl.dref, pl.records, st), 'fc_pack_filter')
             y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack)
         ctx.save_for_backward(x, wpk_b)
         ctx.graph = graph
@@ -247,22 +247,30 @@ def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None):
     then the rest."""
     dev = x.device
     wpk_b = torch.empty(plan.n_bwd, dtype=torch.float32, device=dev)
-    split = graph.forward_split
-    if split is None or not graph.factored or not (0 < split[0] < graph.N):
+    split, nt = graph.forward_split, graph.n_targets
+    between = split[1] if split is not None else None
+    if split is not None and graph.factored and 0 < split[0] < nt:
+        ranges = ((0, split[0]), (split[0], nt - split[0]))
+    elif nt < graph.N and graph.factored:
+        ranges = ((0, nt),)                       # a partitioned mesh: the rows behind n_targets have no in-edges (halo vertices)
+    else:
+        if nt < graph.N:
+            raise _lib.FieldConvNativeError('restrict_targets needs a graph with factored records')
         wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=dev)
         pack(plan, wpk_f, wpk_b)
-        if split is not None:
-            split[1]()
+        if between is not None:
+            between()
         return _launch_forward(lib, x, graph, wpk_f, plan, O, st, addend=addend, bias=bias), wpk_b
-    n_first, between = split
-    y = torch.empty((graph.N, O), dtype=torch.complex64, device=dev)
+    y = torch.empty((nt, O), dtype=torch.complex64, device=dev)
     act = torch.empty_like(y) if bias is not None else None
-    for row0, nrows in ((0, n_first), (n_first, graph.N - n_first)):
+    if len(ranges) == 1 and between is not None:
+        between()
+    for row0, nrows in ranges:
         sub = _row_plan(lib, graph, plan, row0, nrows)
         wpk_f = torch.empty(sub.n_fwd, dtype=torch.float32, device=dev)
-        pack(sub, wpk_f, wpk_b)
+        pack(sub, wpk_f, wpk_b if row0 == 0 else None)
         _launch_forward(lib, x, graph, wpk_f, sub, O, st, addend=addend, bias=bias, out=(y, act), row0=row0)
-        if row0 == 0:
+        if row0 == 0 and len(ranges) == 2:
             between()
     return (y if bias is None else (y, act)), wpk_b
 
@@ -303,7 +311,7 @@ class _FieldConvParamFn(torch.autograd.Function):
             st = _stream()
 
             def pack(pl, wpk_f, wpk_b):
-                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), pl.dref,
+                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b) if wpk_b is not None else None, pl.dref,
                                                 pl.records, st), 'fc_pack_filter_params')
             y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
@@ -347,7 +355,7 @@ class _FieldConvActFn(torch.autograd.Function):
         with _on(x.device):
             st = _stream()
             def pack(pl, wpk_f, wpk_b):
-                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b), pl.dref,
+                check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b) if wpk_b is not None else None, pl.dref,
                                                 pl.records, st), 'fc_pack_filter_params')
             (pre, act), wpk_b = _run_forward(lib, x, graph, plan, O, st, pack, addend=addend, bias=bias)
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase, bias, pre)
@@ -398,8 +406,8 @@ def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, a
         raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={zonal.shape[2]}, band_limit={band_limit}')
     if bias.numel() != O:
         raise ValueError(f'bias has {bias.numel()} channels, the convolution {O}')
-    if addend is not None and (addend.dtype != torch.complex64 or tuple(addend.shape) != (graph.N, O)):
-        raise ValueError(f'addend must be complex64 of shape ({graph.N}, {O})')
+    if addend is not None and (addend.dtype != torch.complex64 or tuple(addend.shape) != (graph.n_targets, O)):
+        raise ValueError(f'addend must be complex64 of shape ({graph.n_targets}, {O})')
     return _FieldConvActFn.apply(x, zonal, spherical, phase, bias.reshape(-1), addend, int(ftype), int(band_limit), graph)
 
 

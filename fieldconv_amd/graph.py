@@ -233,7 +233,7 @@ class FactoredStencil:
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split', 'n_targets')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -275,6 +275,7 @@ class SupportGraph:
         self._plans = {}           # launch plans per (in, out, band limit): functional._conv_plan
         self.on_gx = None          # optional callback(gx) between the data and filter kernels of a backward pass (dist/halo.py)
         self.forward_split = None  # optional (n_first, callback): forward launches targets [0, n_first), calls back, then the rest
+        self.n_targets = self.N    # rows of the convolution's output (restrict_targets)
         if native is None:
             native = sten.is_cuda and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1'
         if native and E > 0 and 2 <= self.R <= 8 and self.F <= 7 and self.F % 2 == 1:
@@ -335,12 +336,26 @@ class SupportGraph:
         g._plans = {}
         g.on_gx = None
         g.forward_split = None
+        g.n_targets = g.N
         g.sten_t = g.sten_s = None
         for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', 'rec_t', 'rec_s', 'runs_t', 'runs_s'):
             setattr(g, name, built[name])
         g.factored = True
         g.geo_t = built['geo_t'] if geo_ok else None
         return g
+
+    def restrict_targets(self, n):
+        """The vertices from `n` on are sources only (the halo of a partitioned mesh: no edge points at them): the forward
+        pass then computes and returns the first n rows, the backward pass takes an (n, O) output gradient; features and
+        their gradient keep all N rows."""
+        n = int(n)
+        if not 0 < n <= self.N:
+            raise ValueError(f'n_targets must lie in (0, {self.N}]')
+        if int(self.rowptr_t[n]) != self.E:
+            raise ValueError(f'vertices from {n} on still have in-edges')
+        self.n_targets = n
+        self._plans = {k: v for k, v in self._plans.items() if not (isinstance(k[0], str) and k[0] == 'rows')}
+        return self
 
     def _build_native(self, supp_edges, sten, allow_factored):
         """csrc/fc_graph.hip: everything the torch code above does, in ~12 launches."""

@@ -72,6 +72,7 @@ def main():
             from fieldconv_amd.dist import overlap_backward, overlap_forward
             overlap_backward(graph, plan)           # the gradient exchange starts inside the convolution's backward pass
             overlap_forward(graph, plan, n_interior)    # interior targets first, boundary targets after the halo rows arrived
+            graph.restrict_targets(n_owned)             # the halo vertices get no output rows
         y_owned = field_conv(x_local, Wd, graph)[:n_owned]
         gx, gW = torch.autograd.grad(y_owned, [x_owned, Wd], grad_outputs=gy_all[lo:lo + n_owned].to(dev))
         y_owned, gx, gW = y_owned.cpu(), gx.cpu(), gW.cpu()

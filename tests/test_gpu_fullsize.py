@@ -318,3 +318,40 @@ def test_forward_in_two_row_ranges_is_the_same_forward(dev, N, k, I, O, B, R, n_
         graph.forward_split = split
         out.append(field_conv_act(xd, conv.zonal, conv.spherical, conv.phase, conv.ftype, B, graph, bias, addend=addend))
     assert rel_err(H(out[1]), H(out[0])) < 3e-6
+
+
+def test_restricted_targets_of_a_partitioned_mesh(dev):
+    """One patch of a two-way partition: the halo vertices (the last rows) are sources only.  With
+    SupportGraph.restrict_targets the forward pass returns the owned rows only and the backward pass takes the owned rows'
+    gradient; same numbers as the unrestricted graph with the halo rows of gy set to zero -- bit for bit in the backward
+    pass, to rounding in the forward pass (the kernel variant follows the number of rows launched)."""
+    from fieldconv_amd.data import sphere_partition
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from oracle.torch_composites import FCPrecomp
+    B, R, C, O = 2, 6, 24, 16
+    data, n_owned, halo, _ = sphere_partition(9000, 2, 1, k=12, seed=2, interior_first=True)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    n_local = data.num_nodes
+    assert n_local > n_owned
+    g = torch.Generator().manual_seed(8)
+    x = torch.complex(torch.randn(n_local, C, generator=g), torch.randn(n_local, C, generator=g))
+    gy = torch.complex(torch.randn(n_local, O, generator=g), torch.randn(n_local, O, generator=g))
+    gy[n_owned:] = 0
+    W = torch.complex(torch.randn(O, C, R, 2 * B + 1, generator=g), torch.randn(O, C, R, 2 * B + 1, generator=g)) / (C * R) ** 0.5
+    full = SupportGraph(edges.to(dev), sten.to(dev), n_local)
+    y0, gx0, gW0 = run_conv(full, x, W, gy, dev)
+    assert float(y0[n_owned:].abs().max()) == 0.0
+    part = SupportGraph(edges.to(dev), sten.to(dev), n_local).restrict_targets(n_owned)
+    with pytest.raises(ValueError):
+        SupportGraph(edges.to(dev), sten.to(dev), n_local).restrict_targets(n_owned - 1)
+    for split in (None, (data.n_interior, lambda: None)):
+        part.forward_split = split
+        xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+        y = field_conv(xd, Wd, part)
+        assert tuple(y.shape) == (n_owned, O)
+        gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy[:n_owned].to(dev))
+        assert rel_err(H(y), H(y0[:n_owned])) < 3e-6
+        assert np.array_equal(H(gx), H(gx0)) and np.array_equal(H(gW), H(gW0))
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    assert rel_err(H(y), y_ref[:n_owned]) < TOL

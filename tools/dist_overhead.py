@@ -31,23 +31,49 @@ params = list(conv.parameters())
 g = torch.Generator().manual_seed(1)
 x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev).requires_grad_(True)
 gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
-overlap_backward(get_graph(edges, sten, data.num_nodes), plan)
+from fieldconv_amd.dist import GradientBuckets, overlap_forward     # noqa: E402
+graph = get_graph(edges, sten, data.num_nodes)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'dist'
+if mode != 'plain':
+    graph.restrict_targets(n_owned)
+    overlap_backward(graph, plan)
+    if mode == 'dist_fwd_overlap':
+        overlap_forward(graph, plan, data.n_interior)
+buckets = GradientBuckets(params) if mode != 'plain' else None
+acc = {}
+
+
+def lap(name, t):
+    now = time.perf_counter()
+    acc[name] = acc.get(name, 0.0) + (now - t)
+    return now
 
 
 def step():
-    xl = halo_exchange(x, plan) if mode != 'plain' else x
-    y = conv(xl, edges, sten)[:n_owned]
-    grads = torch.autograd.grad(y, [x] + params, grad_outputs=gy)
-    if mode != 'plain':
-        flat = torch.cat([t.reshape(-1) for t in grads[1:]])
-        dist.all_reduce(flat)
-    return grads
+    t = time.perf_counter()
+    if mode == 'plain':
+        y = conv(x, edges, sten)
+        t = lap('forward', t)
+        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+        lap('backward', t)
+        return
+    xl = halo_exchange(x, plan, deferred=mode == 'dist_fwd_overlap')
+    t = lap('halo_exchange', t)
+    y = conv(xl, edges, sten)
+    t = lap('forward', t)
+    buckets.zero()
+    x.grad = None
+    t = lap('zero', t)
+    y.backward(gy)
+    t = lap('backward', t)
+    buckets.all_reduce()
+    lap('all_reduce', t)
 
 
-for _ in range(30):
+for _ in range(300):
     step()
 torch.cuda.synchronize()
+acc.clear()
 n_steps = 200
 t0 = time.perf_counter()
 for _ in range(n_steps):
@@ -55,5 +81,6 @@ for _ in range(n_steps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f'{mode}: host enqueue {(t1 - t0) / n_steps * 1e6:.0f} us/step, wall {(t2 - t0) / n_steps * 1e6:.0f} us/step')
+print(f'{mode}: host enqueue {(t1 - t0) / n_steps * 1e6:.0f} us/step, wall {(t2 - t0) / n_steps * 1e6:.0f} us/step; host by part: '
+      + ', '.join(f'{k} {v / n_steps * 1e6:.0f}' for k, v in acc.items()))
 dist.destroy_process_group()
