@@ -379,11 +379,13 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     for _ in range(20):
         pre_fresh._compute(*inputs)
     torch.cuda.synchronize()
+    mallocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     t0 = time.perf_counter()
     for _ in range(20):
         pre_fresh._compute(*inputs)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) / 20 * 1e3
+    prep_mallocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - mallocs0      # hipMalloc calls inside the timed builds
     mesh_graph = get_graph(edges, sten, n_local)            # the instance every convolution will use
     if plan is not None:
         mesh_graph.restrict_targets(n_owned)                # halo vertices are sources only: no output rows, no padded gy
@@ -470,7 +472,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         'kernels': per_kernel,
         'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
-        'mesh_preprocessing_ms': prep_ms,
+        'mesh_preprocessing_ms': prep_ms, 'mesh_preprocessing_device_mallocs': prep_mallocs,
         'clock_settle_steps': info['settle_steps'],
         'cold_start': None if info['cold_start'] is None else {
             'ms_per_step': info['cold_start'] / args.steps * 1e3, 'value': E_total / (info['cold_start'] / args.steps) / 1e6, 'note': COLD_NOTE},
@@ -500,6 +502,22 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         bms = (time.perf_counter() - tb) / 50 * 1e3
         out['fc_resnet_block'] = {'ms_per_step': bms, 'medges_per_s': 2 * E / (bms * 1e-3) / 1e6,
                                   'note': 'FCResNetBlock fwd+bwd, edges counted once per FieldConv (2 per block)'}
+        try:
+            from fieldconv_amd.utils import StepGraph
+            sg = StepGraph(step)                      # the same step, captured once and replayed as one HIP graph
+            for _ in range(50):
+                sg.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(200):
+                sg.replay()
+            torch.cuda.synchronize()
+            gms = (time.perf_counter() - tg) / 200 * 1e3
+            out['graphed_step'] = {'ms_per_step': gms, 'value': E / (gms * 1e-3) / 1e6, 'unit': 'Medges/s',
+                                   'note': 'the same forward + backward replayed as one HIP graph (fieldconv_amd.utils.StepGraph): '
+                                           'no launch gaps, no host work per step; not the metric of record'}
+        except Exception as exc:                      # noqa: BLE001  (an extra, never the reason for a failed bench)
+            out['graphed_step'] = {'error': repr(exc)[:200]}
         if os.environ.get('FC_MFMA') is None:
             out['fp32_mfma'] = other_mode(args, {'FC_MFMA': 'f32'}, 'v_mfma_f32_16x16x4_f32 on fp32 operands throughout (FC_MFMA=f32)',
                                           y_def, gx_def)
