@@ -64,6 +64,30 @@ def test_bench_single_rank_over_rccl():
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['steps'] == 3
 
 
+@pytest.mark.parametrize('fwd_overlap,mode', [('0', 'layer'), ('1', 'layer'), ('0', 'dp')])
+def test_bench_two_ranks_on_one_gpu(fwd_overlap, mode):
+    """The driver's multi-GPU command line (torch.distributed.run, --gpus 2) with both ranks on this box's one GPU: gloo
+    instead of RCCL (which refuses two ranks per device), otherwise the code bench.py runs with N > 1 -- partition, halo
+    plan, restricted targets on the fused-FCPrecomp graph, halo exchange forward / backward, bucketed all-reduce, the
+    max-over-ranks timing -- with and without the forward overlap; and the data-parallel mode (one mesh and one replica
+    of the correspondence network per rank)."""
+    from conftest import free_port
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--verts', '3000', '--dp-verts', '1500', '--mode', mode, '--no-cpu-baseline', '--no-extras']
+    env = _clean_env({'BENCH_BACKEND': 'gloo', 'BENCH_FORWARD_OVERLAP': fwd_overlap, 'OMP_NUM_THREADS': '4'})
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-1500:]                     # rank 0 prints, nobody else
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    if mode == 'layer':
+        assert line['config']['halo_rows_rank0'] > 0 and line['config']['edges_total'] > 2 * 3000 * 25
+    else:
+        assert 'data-parallel x2' in line['config']['parallelism']
+
+
 def test_bench_data_parallel_mode_single_rank():
     """bench.py --mode dp (BASELINE configs[4]: one mesh per rank, replicated net, one bucketed all-reduce) with a
     single rank over RCCL."""
