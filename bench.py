@@ -522,7 +522,8 @@ def run_layer(args, world, rank, dev, use_dist, backend):
             out['fp32_mfma'] = other_mode(args, {'FC_MFMA': 'f32'}, 'v_mfma_f32_16x16x4_f32 on fp32 operands throughout (FC_MFMA=f32)',
                                           y_def, gx_def)
             out['reduced_precision'] = other_mode(args, {'FC_MFMA': 'f16'}, 'single f16 halves with per-row power-of-two scales, fp32 '
-                                                  'accumulation (FC_MFMA=f16)', y_def, gx_def)
+                                                  'accumulation (FC_MFMA=f16): the bf16-class leg of SURVEY 8(d) -- the MFMA rate of bf16, '
+                                                  'three more mantissa bits, the scales make up for the range', y_def, gx_def)
         if args.support == 'p95':
             try:
                 other, _ = child_run(args, {}, extra_args=['--support', 'all'], dump=False)
