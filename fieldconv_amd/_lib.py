@@ -52,6 +52,7 @@ SIGNATURES = {
     'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
     'fc_echo_hist_dim': (ctypes.c_int, [_c_int32]),
+    'fc_echo_channel_block': (ctypes.c_int, [_c_int32]),
     'fc_echo_forward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_echo_backward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [_vp]),

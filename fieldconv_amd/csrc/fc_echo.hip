@@ -12,7 +12,7 @@ namespace fc {
 
 constexpr int kEchoWaves = 4;                 // vertices per workgroup
 constexpr int kEchoAhead = 4;                 // edges whose gathers are in flight together
-constexpr int kEchoMaxBins = 4;               // n_bins <= 4: (2*4+1)^2 = 81 raster cells
+constexpr int kEchoMaxBins = 8;               // n_bins <= 8: (2*8+1)^2 = 289 raster cells, 213 of them inside the disk
 constexpr int kEchoMaxCells = (2 * kEchoMaxBins + 1) * (2 * kEchoMaxBins + 1);
 
 // Cells of the (2n+1)^2 raster inside the disk of radius n + 0.25, numbered in row-major order; cells outside alias
@@ -248,6 +248,15 @@ static int echo_waves_per_vertex(int N, int E) {
 extern "C" {
 
 int fc_echo_hist_dim(int32_t n_bins) { return (n_bins >= 1 && n_bins <= fc::kEchoMaxBins) ? fc::echo_hist_dim(n_bins) : 0; }
+
+// Channels one launch can take: the forward kernel keeps a workgroup's histograms [vertices][C][dS] in LDS.
+int fc_echo_channel_block(int32_t n_bins) {
+    const int dS = fc_echo_hist_dim(n_bins);
+    if (dS == 0) return 0;
+    const long floats = (long)(fc::kMaxLds / sizeof(float)) - fc::kEchoMaxCells - 3;
+    const long c = floats / ((long)fc::kEchoWaves * dS * 2);
+    return (int)(c > fc::kWave ? fc::kWave : c);
+}
 
 int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const fc_csr* by_target, float* hist, float* desc,
                     int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream) {

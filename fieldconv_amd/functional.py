@@ -584,7 +584,7 @@ class _EchoFn(torch.autograd.Function):
         N, C = x.shape
         dS = lib.fc_echo_hist_dim(n_bins)
         if dS == 0:
-            raise ValueError(f'ECHO: n_bins must be in 1..4, got {n_bins}')
+            raise ValueError(f'ECHO: n_bins must be in 1..8, got {n_bins}')
         with _on(x.device):
             ln_t = ln.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
             wxp_t = wxp.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
@@ -622,9 +622,11 @@ def echo_descriptors(x, supp_edges, ln, wxp, n_bins):
         raise ValueError('echo_descriptors expects complex64 features of shape (N, C)')
     from .graph import get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
-    if x.shape[1] > MAX_CHANNELS:          # the channels are independent: blocks of 64 (one channel per lane)
-        return torch.cat([_EchoFn.apply(x[:, c0:c0 + MAX_CHANNELS], ln, wxp, csr, int(n_bins))
-                          for c0 in range(0, x.shape[1], MAX_CHANNELS)], dim=1)
+    blk = _lib.load().fc_echo_channel_block(int(n_bins))      # one channel per lane, a workgroup's histograms in LDS
+    if blk <= 0:
+        raise ValueError(f'ECHO: n_bins must be in 1..8, got {n_bins}')
+    if x.shape[1] > blk:                   # the channels are independent
+        return torch.cat([_EchoFn.apply(x[:, c0:c0 + blk], ln, wxp, csr, int(n_bins)) for c0 in range(0, x.shape[1], blk)], dim=1)
     return _EchoFn.apply(x, ln, wxp, csr, int(n_bins))
 
 

@@ -188,10 +188,13 @@ int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* g
  * hist[n,c,b] = sum over in-edges e of n of the bilinear votes of the point ln[e] * exp(-i angle(x[src_e,c])) in the
  * rasterised disk of (2*n_bins+1)^2 cells, each vote carrying x[src_e,c] * wxp[e]; zero features do not vote; the
  * descriptor is |hist| (zero-safe).  x (N,C) c64, C <= 64; ln_t / wxp_t (E) c64 in by_target slot order; hist
- * (N,C,dS) c64 and desc (N,C,dS) f32 are overwritten, dS = fc_echo_hist_dim(n_bins), 1 <= n_bins <= 4.
+ * (N,C,dS) c64 and desc (N,C,dS) f32 are overwritten, dS = fc_echo_hist_dim(n_bins), 1 <= n_bins <= 8;
+ * C <= fc_echo_channel_block(n_bins) per call (64 up to n_bins = 4, then 57, 42, 30, 23: the histograms of a workgroup live in LDS;
+ * channels are independent, wider inputs go in blocks).
  * Backward: by_source groups the edges by source (nbr = targets), ln_s / wxp_s in that slot order; g_desc (N,C,dS) f32;
  * gx (N,C) c64 is overwritten; hist_grad_workspace: N*C*dS complex64 values of scratch. */
 int fc_echo_hist_dim(int32_t n_bins);
+int fc_echo_channel_block(int32_t n_bins);
 int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const fc_csr* by_target, float* hist,
                     float* desc, int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream);
 int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, const fc_csr* by_source, const float* hist,

@@ -751,7 +751,8 @@ def test_native_graph_build_hub_vertex(dev):
     assert rel_err(H(y), y_ref) < TOL
 
 
-@pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4), (60, 10, 130, 2)])
+@pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4), (60, 10, 130, 2),
+                                          (80, 30, 48, 6), (50, 24, 30, 8), (64, 20, 64, 5)])   # n_bins > 4: channel blocks by LDS
 def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     """ECHO descriptor kernels against the oracle's torch restatement run on the CPU in float64 (pinned to the reference
     fixtures by the CPU suite), on supports wide enough that 2 or 4 wavefronts share a vertex, with ragged degrees and
