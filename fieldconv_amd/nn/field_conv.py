@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 from torch.nn import Parameter
 
-from ..functional import field_conv, field_conv_act, field_conv_params
+from ..functional import field_conv_act, field_conv_params
 from ..graph import get_graph
 
 

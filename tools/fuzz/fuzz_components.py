@@ -4,7 +4,6 @@ the oracle's restatements.  Not part of the test suite (it imports the oracle: r
     python tools/fuzz/fuzz_components.py [seed] [cases]"""
 import os
 import sys
-import traceback
 
 import numpy as np
 import torch
