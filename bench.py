@@ -200,6 +200,8 @@ def init_dist(dev, backend):
 
 
 SETTLE_SECONDS = 0.3
+PROTOCOL_NOTE = ('warmup + steps are run twice in this process: first as its first GPU work (cold_start), then again after '
+                 'clock_settle_steps further untimed steps of the same workload (value, ms_per_step); --cold: the first run only')
 COLD_NOTE = ('the same warmup + steps as the first GPU work of the process, before the untimed clock_settle_steps: inside the clock '
              "governor's ramp (see timed_loop); `value` is the repeat of the protocol after it")
 
@@ -332,6 +334,7 @@ def run_dp(args, world, rank, dev, use_dist, backend):
                                   f'data-parallel x{world}: one mesh per GPU, one bucketed all-reduce of {4 * buckets.flat.numel()} gradient '
                                   f'bytes per step over RCCL'},
         'roofline': None, 'cpu_baseline': None, 'clock_settle_steps': info['settle_steps'], 'cold_start': cold,
+        'protocol': PROTOCOL_NOTE,
     }
 
 
@@ -473,7 +476,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         'hbm_frac_kernels': (fwd_b + bwd_b) / (sum(v['avg_ms'] for v in per_kernel.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if per_kernel else None,
         'mesh_preprocessing_ms': prep_ms, 'mesh_preprocessing_device_mallocs': prep_mallocs,
-        'clock_settle_steps': info['settle_steps'],
+        'clock_settle_steps': info['settle_steps'], 'protocol': PROTOCOL_NOTE,
         'cold_start': None if info['cold_start'] is None else {
             'ms_per_step': info['cold_start'] / args.steps * 1e3, 'value': E_total / (info['cold_start'] / args.steps) / 1e6, 'note': COLD_NOTE},
     }
