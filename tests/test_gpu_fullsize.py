@@ -355,3 +355,20 @@ def test_restricted_targets_of_a_partitioned_mesh(dev):
         assert np.array_equal(H(gx), H(gx0)) and np.array_equal(H(gW), H(gW0))
     y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
     assert rel_err(H(y), y_ref[:n_owned]) < TOL
+
+
+@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('B', [1, 2, 3])
+def test_every_compiled_shape_on_a_two_round_mesh(dev, R, B):
+    """Every (n_rings, band_limit) pair the library compiles (csrc/fc_kernels.hpp: FC_FOR_EACH_SHAPE), on a mesh of 8 208
+    vertices = 513 tiles: the ring-major forward kernel of that shape runs (two rounds of its persistent grid and a half
+    tile), the backward kernels walk several tiles per workgroup.  Whole outputs against the oracle."""
+    from fieldconv_amd.graph import SupportGraph
+    N, k, I, O = 8208, 5, 8 + 4 * (R % 3), 16 - 4 * (B % 2)
+    edges, sten, x, gy, W = precomp_case(N, k, I, O, B, R, seed=10 * R + B)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    assert graph.factored
+    y, gx, gW = run_conv(graph, x, W, gy, dev)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(y), y_ref) < TOL and rel_err(H(gx), gx_ref) < TOL and rel_err(H(gW), gW_ref) < TOL
