@@ -140,8 +140,16 @@ def sphere_partition(n_total, parts, rank, k=32, seed=0, support='all', interior
         n_interior = int(np.count_nonzero(~boundary[bounds[rank]:bounds[rank + 1]]))
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     e1, e2 = _frames(pts)
-    tree = cKDTree(pts)
-    _, nbr = tree.query(pts[lo:hi], k=k)                        # (n_owned, k) global source ids
+    # neighbours of the owned points: a tree over the points near the patch only (its bounding box grown by three expected
+    # k-NN radii), checked against the distances found -- a rank of a large partitioned mesh never indexes the whole mesh
+    margin = 3.0 * math.sqrt(4.0 * k / n_total)
+    box_lo, box_hi = pts[lo:hi].min(0) - margin, pts[lo:hi].max(0) + margin
+    cand = np.nonzero(((pts >= box_lo) & (pts <= box_hi)).all(1))[0]
+    dist_k, nbr = cKDTree(pts[cand]).query(pts[lo:hi], k=k)     # (n_owned, k) positions in cand
+    if parts > 1 and float(dist_k.max()) >= margin:             # (never on these samplings: a neighbour could lie outside the box)
+        _, nbr = cKDTree(pts).query(pts[lo:hi], k=k)
+    else:
+        nbr = cand[nbr]                                         # global source ids
     n_owned = hi - lo
     dst_g = np.repeat(np.arange(lo, hi), k)
     src_g = nbr.reshape(-1)
