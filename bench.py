@@ -304,8 +304,9 @@ def run_dp(args, world, rank, dev, use_dist, backend):
         h = net['echo'](x, edges, sten, ln, wxp)
         logits = net['lin2'](torch.relu(net['lin1'](h)))
         loss = torch.nn.functional.cross_entropy(logits, labels)
-        buckets.zero()
+        buckets.begin()                                        # autograd assigns the gradients (no add kernel per parameter) ...
         loss.backward()
+        buckets.collect()                                      # ... one multi-tensor copy packs them into the flat buffer
         if use_dist:
             buckets.all_reduce()                               # the one collective of a data-parallel step
         return loss
@@ -403,9 +404,10 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         y = conv(xl, edges, sten)
         if buckets is None:
             return torch.autograd.grad(y, [x] + params, grad_outputs=gy)
-        buckets.zero()
+        buckets.begin()
         x.grad = None
         y.backward(gy)
+        buckets.collect()
         buckets.all_reduce()
         return (x.grad,) + tuple(p.grad for p in params)
 

@@ -16,8 +16,14 @@ class GradientBuckets:
         self.group = group
         self.average = average
         flat = getattr(params_or_optimizer, '_grad', None)          # FusedAdam: gradients already live in one buffer
+        self.params, self.views = [], []
         if flat is not None:
             self.flat = flat
+            for pg in params_or_optimizer.param_groups:
+                for p in pg['params']:
+                    if p.grad is not None and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
+                        self.params.append(p)
+                        self.views.append(p.grad)
         else:
             params = [p for p in params_or_optimizer if p.requires_grad]
             if not params:
@@ -33,11 +39,39 @@ class GradientBuckets:
             self.flat = torch.zeros(total, dtype=dt, device=dev)
             for p, o, n in zip(params, offs, sizes):
                 p.grad = self.flat[o:o + n].view(p.shape)
+                self.params.append(p)
+                self.views.append(p.grad)
         per = max(1, int(bucket_bytes) // self.flat.element_size())
         self.buckets = [self.flat[i:i + per] for i in range(0, self.flat.numel(), per)]
 
     def zero(self):
+        """Gradients accumulate into the flat buffer: zero it, run backward (one small add kernel per parameter)."""
         self.flat.zero_()
+
+    def begin(self):
+        """Alternative to zero(): detach the parameters from the buffer for this backward pass, so that autograd ASSIGNS every
+        gradient instead of adding it to a zeroed view -- no fill and no add kernel per parameter (a hundred launches of a few
+        microseconds each on the networks of this package); collect() then packs them with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self, accumulate=False):
+        """After backward (following begin()): fresh gradients into the flat buffer (added to it with accumulate=True: several
+        backward passes per step), parameters' .grad point into the buffer again."""
+        views, grads = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                if not accumulate:
+                    v.zero_()                          # a parameter the loss does not depend on
+            elif p.grad is not v:
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            if accumulate:
+                torch._foreach_add_(views, grads)
+            else:
+                torch._foreach_copy_(views, grads)
 
     def all_reduce(self, async_op=False):
         """Sum (or average) the gradients over the group; returns the Work handles when async_op (empty on the

@@ -61,6 +61,24 @@ def main():
     grads = local_grads(conv, *mesh(rank, B, R), B, on_gpu, dev)
     for p, g_ in zip(params, grads):
         p.grad.copy_(g_)
+    packed = buckets.flat.clone()
+    # the begin() / collect() path: gradients assigned by autograd (here: by hand) and packed with one multi-tensor copy
+    buckets.begin()
+    assert all(p.grad is None for p in params)
+    grads = [g_.to(p.device) for p, g_ in zip(params, grads)]
+    for p, g_ in zip(params, grads):
+        p.grad = g_.clone()
+    buckets.collect()
+    assert torch.equal(buckets.flat, packed) and all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in params)
+    buckets.begin()
+    params[0].grad = grads[0].clone()                    # a parameter without a gradient reads as zero; accumulate adds
+    buckets.collect()
+    assert float(params[1].grad.abs().max()) == 0.0
+    buckets.begin()
+    for p, g_ in zip(params[1:], grads[1:]):
+        p.grad = g_.clone()
+    buckets.collect(accumulate=True)
+    assert torch.equal(buckets.flat, packed)
     buckets.all_reduce()                                 # the one (bucketed) collective of a data-parallel step
     flat = torch.cat([p.grad.reshape(-1).cpu() for p in params])
     # single-process answer: the sum over all meshes, from the oracle

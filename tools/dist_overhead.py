@@ -61,11 +61,13 @@ def step():
     t = lap('halo_exchange', t)
     y = conv(xl, edges, sten)
     t = lap('forward', t)
-    buckets.zero()
+    buckets.begin()
     x.grad = None
-    t = lap('zero', t)
+    t = lap('begin', t)
     y.backward(gy)
     t = lap('backward', t)
+    buckets.collect()
+    t = lap('collect', t)
     buckets.all_reduce()
     lap('all_reduce', t)
 
