@@ -19,11 +19,8 @@ class GradientBuckets:
         self.params, self.views = [], []
         if flat is not None:
             self.flat = flat
-            for pg in params_or_optimizer.param_groups:
-                for p in pg['params']:
-                    if p.grad is not None and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
-                        self.params.append(p)
-                        self.views.append(p.grad)
+            self.params = list(params_or_optimizer.param_groups[0]['params'])
+            self.views = list(params_or_optimizer._views)
         else:
             params = [p for p in params_or_optimizer if p.requires_grad]
             if not params:
@@ -76,6 +73,7 @@ class GradientBuckets:
     def all_reduce(self, async_op=False):
         """Sum (or average) the gradients over the group; returns the Work handles when async_op (empty on the
         host-staged path, which completes here)."""
+        self.collect()                      # no-op unless gradients were assigned since begin() / zero_grad(set_to_none=True)
         world = dist.get_world_size(self.group)
         works = []
         staged = self.flat.is_cuda and dist.get_backend(self.group) == 'gloo'

@@ -820,9 +820,11 @@ def test_native_fc_precomp_matches_torch(dev, N, k, B, R, shrink):
     assert torch.equal(s1.abs() > tiny, s2.abs() > tiny)
 
 
-def test_fused_adam_matches_torch_adam(dev):
+@pytest.mark.parametrize('set_to_none', [False, True])
+def test_fused_adam_matches_torch_adam(dev, set_to_none):
     """FusedAdam (one flat buffer, fc_adam_step) against torch.optim.Adam on the same block over several steps, with
-    weight decay; also as part of a captured HIP graph (device-side step counter)."""
+    weight decay; also as part of a captured HIP graph (device-side step counter).  set_to_none: gradients assigned by
+    autograd and packed into the flat buffer by step() instead of accumulated into zeroed views."""
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.nn import FCResNetBlock
     from fieldconv_amd.optim import FusedAdam
@@ -844,7 +846,7 @@ def test_fused_adam_matches_torch_adam(dev):
     oc = FusedAdam(mc.parameters(), **kw)
 
     def train_step(m, o):
-        o.zero_grad()
+        o.zero_grad(set_to_none=set_to_none)
         loss = m(x, edges, sten).abs().square().mean()
         loss.backward()
         o.step()

@@ -44,7 +44,7 @@ def step():
     logits = mods['echo'](x, edges, sten, ln, wxp)
     loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
     if OPT:                                             # a complete training step: gradients into .grad, Adam update
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=os.environ.get('SET_TO_NONE', '1') == '1')
         loss.backward()
         opt.step()
         return (loss.detach(),)
