@@ -21,6 +21,12 @@ class FcCsr(ctypes.Structure):
     _fields_ = [('rowptr', _vp), ('nbr', _vp), ('runs', _vp)]
 
 
+class FcFilterParams(ctypes.Structure):
+    """fc_filter_params: module parameters and (backward) where their gradients go"""
+    _fields_ = [('zonal', ctypes.c_void_p), ('spherical', ctypes.c_void_p), ('phase', ctypes.c_void_p), ('ftype', ctypes.c_int32),
+                ('g_zonal', ctypes.c_void_p), ('g_spherical', ctypes.c_void_p), ('g_phase', ctypes.c_void_p)]
+
+
 class FcEpilogue(ctypes.Structure):
     _fields_ = [('addend', _vp), ('modrelu_bias', _vp), ('activated', _vp)]
 
@@ -28,6 +34,7 @@ class FcEpilogue(ctypes.Structure):
 _DP = ctypes.POINTER(FcDims)
 _CP = ctypes.POINTER(FcCsr)
 _EP = ctypes.POINTER(FcEpilogue)
+_FP = ctypes.POINTER(FcFilterParams)
 
 # name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
 SIGNATURES = {
@@ -51,6 +58,8 @@ SIGNATURES = {
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
+    'fc_backward_all': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _FP, _vp, _sz, _DP, _vp]),
+    'fc_forward_params': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _FP, _vp, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
     'fc_echo_hist_dim': (ctypes.c_int, [_c_int32]),
     'fc_echo_channel_block': (ctypes.c_int, [_c_int32]),
     'fc_echo_forward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),

@@ -41,7 +41,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 4; }
+int fc_abi_version(void) { return 5; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -168,6 +168,33 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
     if (!gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+}
+
+int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
+                    const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
+                    size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!gw_eff) return FC_ERR_BAD_ARGUMENT;
+    int rc = records ? fc_backward_data_factored(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, stream)
+                     : fc_backward_data(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, stream);
+    if (rc != FC_OK) return rc;
+    rc = fc_backward_filter(x, workspace, workspace_bytes, dims, stream);
+    if (rc != FC_OK) return rc;
+    rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, stream);
+    if (rc != FC_OK || !params) return rc;
+    return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
+                                 params->g_spherical, params->g_phase, dims, stream);
+}
+
+int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,
+                      const fc_filter_params* params, float* wpk_fwd, float* wpk_bwd, float* y, void* workspace,
+                      size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream) {
+    if (!params || kind < 0 || kind > 2) return FC_ERR_BAD_ARGUMENT;
+    const int rc = fc_pack_filter_params(params->zonal, params->spherical, params->phase, params->ftype, wpk_fwd, wpk_bwd, dims,
+                                         kind != 0, stream);
+    if (rc != FC_OK) return rc;
+    if (kind == 2) return fc_forward_geometric(x, sten_or_records, by_target, wpk_fwd, y, workspace, workspace_bytes, dims, epilogue, stream);
+    if (kind == 1) return fc_forward_factored(x, sten_or_records, by_target, wpk_fwd, y, workspace, workspace_bytes, dims, epilogue, stream);
+    return fc_forward(x, sten_or_records, by_target, wpk_fwd, y, dims, epilogue, stream);
 }
 
 }  // extern "C"

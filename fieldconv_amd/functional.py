@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import FcCsr, FcDims, FcEpilogue, check
+from ._lib import FcCsr, FcDims, FcEpilogue, FcFilterParams, check
 
 
 class KernelTimer:
@@ -39,6 +39,7 @@ class KernelTimer:
 
 
 kernel_timer = KernelTimer()
+_ONE_CALL = os.environ.get('FIELDCONV_SEPARATE_CALLS', '0') != '1'      # development: one foreign call per kernel instead of per pass
 
 
 class _timed:
@@ -148,7 +149,7 @@ class _FieldConvFn(torch.autograd.Function):
         plan = _conv_plan(lib, ctx.graph, I, O, (F - 1) // 2)
         gy = gy.contiguous()
         with _on(x.device):
-            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, _stream())
+            gx, gw, _ = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, _stream())
         return gx, gw, None
 
 
@@ -240,7 +241,7 @@ def _row_plan(lib, graph, whole, row0, nrows):
     return plan
 
 
-def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None):
+def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None, params=None):
     """Filter images + forward launch(es).  pack(plan, wpk_f, wpk_b) enqueues the packing kernel.  -> (result of
     _launch_forward, wpk_b).  A graph with `forward_split` = (n_first, between) (dist/halo.py: overlap_forward) runs the
     targets [0, n_first) first, calls between() -- the wait for the halo rows of x, which only later targets read -- and
@@ -257,6 +258,22 @@ def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None):
         if nt < graph.N:
             raise _lib.FieldConvNativeError('restrict_targets needs a graph with factored records')
         wpk_f = torch.empty(plan.n_fwd, dtype=torch.float32, device=dev)
+        if params is not None and between is None and _ONE_CALL and not kernel_timer.enabled:
+            # filter images + forward launch in one foreign call (fc_forward_params)
+            zonal, spherical, phase, ftype = params
+            y = torch.empty((graph.N, O), dtype=torch.complex64, device=dev)
+            act = torch.empty_like(y) if bias is not None else None
+            epi = None
+            if addend is not None or bias is not None:
+                epi = ctypes.byref(FcEpilogue(addend.data_ptr() if addend is not None else None,
+                                              bias.data_ptr() if bias is not None else None, act.data_ptr() if act is not None else None))
+            fp = FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, None, None, None)
+            nbytes = plan.ws_fwd
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+            kind, recs = (2, graph.geo_t) if graph.geo_t is not None else ((1, graph.rec_t) if graph.factored else (0, graph.sten_t))
+            check(lib.fc_forward_params(_p(x), _p(recs), plan.cref_t, kind, ctypes.byref(fp), _p(wpk_f), _p(wpk_b), _p(y),
+                                        _p(ws) if ws is not None else None, nbytes, plan.dref, epi, st), 'fc_forward_params')
+            return (y if bias is None else (y, act)), wpk_b
         pack(plan, wpk_f, wpk_b)
         if between is not None:
             between()
@@ -275,15 +292,31 @@ def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None):
     return (y if bias is None else (y, act)), wpk_b
 
 
-def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
+def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
+    """-> (gx, gw_eff, parameter gradients or None).  params = (zonal, spherical, phase, ftype): also the VJP of the filter
+    assembly.  One foreign call for the whole pass (fc_backward_all) unless something has to happen between the kernels: a
+    partitioned mesh's gradient exchange (graph.on_gx) or the benchmark's per-kernel event brackets."""
     O, I, R, F = wshape
     gx = torch.empty_like(x)
     gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
     nbytes = plan.ws_bwd
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     sten = graph.rec_s if graph.factored else graph.sten_s
-    fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
     wsp = _p(ws)
+    pgrads = fp = None
+    if params is not None:
+        zonal, spherical, phase, ftype = params
+        g_z = torch.empty_like(zonal)
+        g_s = torch.empty_like(spherical)
+        g_p = torch.empty_like(phase) if ftype == 1 else None
+        pgrads = (g_z, g_s, g_p)
+        fp = FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, g_z.data_ptr(), g_s.data_ptr(),
+                            g_p.data_ptr() if g_p is not None else None)
+    if graph.on_gx is None and _ONE_CALL and not kernel_timer.enabled:
+        check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, 1 if graph.factored else 0, _p(wpk_b), _p(gx), _p(gw),
+                                  ctypes.byref(fp) if fp is not None else None, wsp, nbytes, plan.dref, st), 'fc_backward_all')
+        return gx, gw, pgrads
+    fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
     with _timed('fc_backward_data'):
         check(fn(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_data')
     if graph.on_gx is not None:         # gx is complete (in stream order): a partitioned mesh starts returning its halo rows
@@ -291,7 +324,10 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st):
     with _timed('fc_backward_filter'):
         check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, st), 'fc_backward_filter')
     check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, st), 'fc_backward_finish')
-    return gx, gw
+    if fp is not None:
+        check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ftype, _p(g_z), _p(g_s),
+                                        _p(g_p) if g_p is not None else None, plan.dref, st), 'fc_filter_param_grads')
+    return gx, gw, pgrads
 
 
 class _FieldConvParamFn(torch.autograd.Function):
@@ -313,7 +349,7 @@ class _FieldConvParamFn(torch.autograd.Function):
             def pack(pl, wpk_f, wpk_b):
                 check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b) if wpk_b is not None else None, pl.dref,
                                                 pl.records, st), 'fc_pack_filter_params')
-            y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack)
+            y, wpk_b = _run_forward(lib, x, graph, plan, O, st, pack, params=(zonal, spherical, phase, ftype))
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase)
         ctx.graph, ctx.ftype, ctx.wshape = graph, ftype, (O, I, R, F)
         return y
@@ -324,16 +360,11 @@ class _FieldConvParamFn(torch.autograd.Function):
         x, wpk_b, zonal, spherical, phase = ctx.saved_tensors
         O, I, R, F = ctx.wshape
         plan = _conv_plan(lib, ctx.graph, I, O, (F - 1) // 2)
-        dims = plan.dims
         gy = gy.contiguous()
         with _on(x.device):
             st = _stream()
-            gx, gw = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, st)
-            g_z = torch.empty_like(zonal)
-            g_s = torch.empty_like(spherical)
-            g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
-            check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ctx.ftype, _p(g_z), _p(g_s),
-                                            _p(g_p) if g_p is not None else None, ctypes.byref(dims), st), 'fc_filter_param_grads')
+            gx, _, (g_z, g_s, g_p) = _launch_backward(lib, x, gy, ctx.graph, wpk_b, plan, ctx.wshape, st,
+                                                      params=(zonal, spherical, phase, ctx.ftype))
         return gx, g_z, g_s, g_p, None, None, None
 
 
@@ -357,7 +388,8 @@ class _FieldConvActFn(torch.autograd.Function):
             def pack(pl, wpk_f, wpk_b):
                 check(lib.fc_pack_filter_params(_p(zonal), _p(spherical), _p(phase), ftype, _p(wpk_f), _p(wpk_b) if wpk_b is not None else None, pl.dref,
                                                 pl.records, st), 'fc_pack_filter_params')
-            (pre, act), wpk_b = _run_forward(lib, x, graph, plan, O, st, pack, addend=addend, bias=bias)
+            (pre, act), wpk_b = _run_forward(lib, x, graph, plan, O, st, pack, addend=addend, bias=bias,
+                                             params=(zonal, spherical, phase, ftype))
         ctx.save_for_backward(x, wpk_b, zonal, spherical, phase, bias, pre)
         ctx.graph, ctx.ftype, ctx.wshape, ctx.has_addend = graph, ftype, (O, I, R, F), addend is not None
         return act
@@ -378,12 +410,8 @@ class _FieldConvActFn(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             check(lib.fc_tangent_nonlin_backward(_p(pre), _p(bias), _p(g_act), _p(g_pre), _p(g_bias), _p(ws), nbytes, N, O, st),
                   'fc_tangent_nonlin_backward')
-            gx, gw = _launch_backward(lib, x, g_pre, ctx.graph, wpk_b, plan, ctx.wshape, st)
-            g_z = torch.empty_like(zonal)
-            g_s = torch.empty_like(spherical)
-            g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
-            check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ctx.ftype, _p(g_z), _p(g_s),
-                                            _p(g_p) if g_p is not None else None, plan.dref, st), 'fc_filter_param_grads')
+            gx, _, (g_z, g_s, g_p) = _launch_backward(lib, x, g_pre, ctx.graph, wpk_b, plan, ctx.wshape, st,
+                                                      params=(zonal, spherical, phase, ctx.ftype))
         return gx, g_z, g_s, g_p, g_bias, (g_pre if ctx.has_addend else None), None, None, None
 
 

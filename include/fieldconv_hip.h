@@ -164,6 +164,30 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
 int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
 int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
 
+/* ---- one call per pass: the same kernels, enqueued by one entry point (a binding that pays microseconds per foreign call --
+ * ctypes -- spends more time on six calls per convolution than the GPU needs for a small mesh) ---------------------------- *
+ * fc_filter_params: the module parameters as fc_pack_filter_params takes them and, for the backward pass, where their
+ * gradients go (g_* are ignored by fc_forward_params; g_phase / phase may be NULL unless ftype == 1).
+ * fc_forward_params = fc_pack_filter_params (wpk_bwd may be NULL) + fc_forward (kind 0) / fc_forward_factored (1) /
+ *                     fc_forward_geometric (2), same arguments;
+ * fc_backward_all   = fc_backward_data (records 0) or fc_backward_data_factored (1) + fc_backward_filter +
+ *                     fc_backward_finish into gw_eff (required) + fc_filter_param_grads when params is not NULL. */
+typedef struct fc_filter_params {
+    const float* zonal;
+    const float* spherical;
+    const float* phase;
+    int32_t ftype;
+    float* g_zonal;
+    float* g_spherical;
+    float* g_phase;
+} fc_filter_params;
+int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,
+                      const fc_filter_params* params, float* wpk_fwd, float* wpk_bwd, float* y, void* workspace,
+                      size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream);
+int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
+                    const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
+                    size_t workspace_bytes, const fc_dims* dims, void* stream);
+
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */
 int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w, float* y,
