@@ -372,3 +372,19 @@ def test_every_compiled_shape_on_a_two_round_mesh(dev, R, B):
     y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
     gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
     assert rel_err(H(y), y_ref) < TOL and rel_err(H(gx), gx_ref) < TOL and rel_err(H(gW), gW_ref) < TOL
+
+
+def test_ring_major_forward_with_empty_outer_rings(dev):
+    """Round 1's benchmark mesh: the support radius lies above every k-NN distance, so FCPrecomp drops no edge and the two
+    outermost rings of the radial interpolant stay empty (`--support all`).  The ring-major forward then flushes and
+    contracts slabs nobody gathered into; whole outputs against the oracle on a two-round mesh."""
+    from fieldconv_amd.graph import SupportGraph
+    N, k, I, O, B, R = 8208, 6, 24, 24, 2, 6
+    edges, sten, x, gy, W = precomp_case(N, k, I, O, B, R, seed=3, support='all')
+    assert edges.shape[0] == N * k
+    assert float(sten[:, R - 1].abs().max()) == 0.0                 # nothing reaches the outermost ring
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    y, gx, gW = run_conv(graph, x, W, gy, dev)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(y), y_ref) < TOL and rel_err(H(gx), gx_ref) < TOL and rel_err(H(gW), gW_ref) < TOL
