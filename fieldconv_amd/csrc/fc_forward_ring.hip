@@ -12,12 +12,15 @@ bool ring_enabled() {
     return on && split_mode() == 2;
 }
 
-// Meshes of fewer than 2 x 256 tiles (8192 vertices) cannot give every CU its two workgroups: they keep the frequency-major
-// kernels (with the edge split for the smallest ones); FC_RING=2 forces the ring-major kernels for any size (tests).
+// Meshes of up to 256 tiles (4096 vertices) are one round of the frequency-major kernels (one 16-vertex tile per CU, with
+// the edge split for the smallest ones), which they keep: 41 against 46 us at C = 48, k = 32.  From 257 tiles on the
+// frequency-major grid needs a second round while the ring-major one (two workgroups per CU) still takes one: 59 against
+// 66 us between 4097 and 8192 vertices, 91 against 94 up to 12288 (tools/ring_threshold.py).  FC_RING=2 forces the
+// ring-major kernels for any size (tests).
 bool forward_ring_fits(const fc_dims* d) {
     static const bool force = [] { const char* e = getenv("FC_RING"); return e && atoi(e) == 2; }();
     if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
-    return force || (d->N + kTile - 1) / kTile >= 2 * kNumCUs;
+    return force || (d->N + kTile - 1) / kTile > kNumCUs;
 }
 
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {

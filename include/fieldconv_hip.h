@@ -79,8 +79,8 @@ int fc_supported(const fc_dims* dims);
  * fc_backward_data), 1: the record-driven ones (fc_forward_factored, fc_forward_geometric, fc_backward_data_factored).
  * In the default mode the record-driven forward image is RING-major: OP inverse row scales, then
  * R x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves with k = f*ceil8(I) + i, KP = ceil32(F * ceil8(I))
- * (csrc/fc_forward_ring.hpp) whenever the forward launch with these dims takes the ring-major kernel (meshes of two rounds
- * of its persistent grid or more): the layout follows dims->N, so an image is packed with the dims of the launch it is for
+ * (csrc/fc_forward_ring.hpp) whenever the forward launch with these dims takes the ring-major kernel (meshes of more than
+ * 256 tiles of 16 vertices): the layout follows dims->N, so an image is packed with the dims of the launch it is for
  * (a forward pass launched in two row ranges packs one image per range).  Sizes differ between the two families, ask with
  * the same `records`.  wpk_bwd may be NULL: only the forward image is written. */
 size_t fc_packed_filter_floats_fwd(const fc_dims* dims, int32_t records);

@@ -291,7 +291,7 @@ def test_precomp_cache_round_trip(dev, tmp_path):
 ])
 def test_forward_in_two_row_ranges_is_the_same_forward(dev, N, k, I, O, B, R, n_first):
     """dist.overlap_forward launches the targets [0, n_first) and [n_first, N) separately (the halo exchange completes in
-    between).  Same records, same filter; the kernel variant follows the size of each launch (ring-major from 512 tiles
+    between).  Same records, same filter; the kernel variant follows the size of each launch (ring-major from 257 tiles
     up), so the outputs agree to fp32 rounding rather than bit for bit; with and without the fused residual + modReLU
     epilogue; the backward pass does not change at all."""
     from fieldconv_amd.functional import field_conv_act

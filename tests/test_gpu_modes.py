@@ -30,7 +30,7 @@ MODES = {
     'separate_pointwise_operators': {'FIELDCONV_NO_FUSED_EPILOGUE': '1'},   # no residual / modReLU epilogue in the convolutions
     'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
-    'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes below 8192 vertices
+    'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
     'one_call_per_kernel': {'FIELDCONV_SEPARATE_CALLS': '1'},   # the per-kernel entry points instead of fc_forward_params / fc_backward_all
 }
 
