@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ('test_fused_precomp_graph or test_fieldconv_golden or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
-          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or N4200_k9 or N5000_k7_I64 or '
+          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or '
           'test_config2_record_kernels')
 
 MODES = {
