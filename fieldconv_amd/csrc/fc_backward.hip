@@ -570,6 +570,7 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
     }
     if (need <= 2) return launch_backward_filter<2>(x2, hdump, gwp, a, p, d, stream);
     if (need <= 4) return launch_backward_filter<4>(x2, hdump, gwp, a, p, d, stream);
+    if (need <= 6) return launch_backward_filter<6>(x2, hdump, gwp, a, p, d, stream);      // 64 channels x 6 rings: 24 row tiles over 4 wavefronts per column
     if (need <= kMaxGwTiles) return launch_backward_filter<kMaxGwTiles>(x2, hdump, gwp, a, p, d, stream);
     return FC_ERR_UNSUPPORTED;
 }

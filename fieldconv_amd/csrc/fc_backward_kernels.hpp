@@ -434,11 +434,14 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     // filter kernel on half-precision operands (fc_backward.hip) when its image fits beside the two fp32 slabs
     const int stride_tails = round_up(p.slab_floats + 2 * kTile + 2 * p.IP, 256);
     const size_t lds_half = (size_t)(2 * stride_tails + (kTile * filter_image_stride(p.KP) + 6 * p.IP * kXbStride) / 2 + 4) * sizeof(float);
-    p.fhalf = (halves != 0 && p.IP <= 64 && p.KP <= 512 && lds_half <= kMaxLds) ? 1 : 0;
+    // (the register-fed half2 kernel needs two images and no fp32 slab in LDS; FC_FILTER2=0 selects the LDS-staged one)
+    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    const size_t lds_half2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
+    p.fhalf = (halves != 0 && p.IP <= 64 && p.KP <= 512 && (staged ? lds_half : lds_half2) <= kMaxLds) ? 1 : 0;
     p.slab_stride = p.fhalf ? stride_tails : round_up(p.slab_floats, 256);
     p.lds_data = (size_t)(slab_floats(p.gd) + partial_floats(p.gd.NKP, p.IP) + 4 * kTile + (p.fhalf ? kTile * 64 : 0)) * sizeof(float);
     p.lds_data_factored = p.lds_data + (size_t)kWaves * kRingChunks * 1024;
-    p.lds_filter = p.fhalf ? lds_half : (size_t)(2 * p.slab_stride + 3 * p.IP * kXtStride) * sizeof(float);
+    p.lds_filter = p.fhalf ? (staged ? lds_half : lds_half2) : (size_t)(2 * p.slab_stride + 3 * p.IP * kXtStride) * sizeof(float);
     p.hdump_bytes = ((size_t)p.ntiles * p.F * p.slab_stride + 256) * sizeof(float);
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
     p.ok = p.lds_data <= kMaxLds && p.lds_filter <= kMaxLds && p.ngw <= kMaxGwTiles * kWaves && p.g.NMT <= kWaves &&
