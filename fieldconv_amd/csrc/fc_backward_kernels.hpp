@@ -425,7 +425,7 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.gx_part_stride = part_stride((size_t)d->N * d->I);
     p.gxp_bytes = p.parts_log2 ? (p.gx_part_stride << p.parts_log2) * sizeof(float2) : 0;
     p.ngw = p.g.KST * p.g.NMT;
-    int P = kNumCUs / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
+    int P = num_cus() / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
     if (P < 1) P = 1;
     if (P > p.ntiles) P = p.ntiles;
     p.P = P;
@@ -476,7 +476,7 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
     const size_t lds = FACTORED ? p.lds_data_factored : p.lds_data;
     static bool lds_ok[kMaxDevices] = {};        // per kernel instantiation (this function is a template)
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
-    const int grid = FACTORED ? (p.ntiles < kNumCUs ? p.ntiles : kNumCUs) : p.ntiles;
+    const int grid = FACTORED ? (p.ntiles < num_cus() ? p.ntiles : num_cus()) : p.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, gx,
                        hdump, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;

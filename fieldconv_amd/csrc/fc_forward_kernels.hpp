@@ -527,7 +527,7 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
     const int nvt = a.ntiles << a.parts_log2;
-    const int grid = factored ? (nvt < kNumCUs ? nvt : kNumCUs) : a.ntiles;
+    const int grid = factored ? (nvt < num_cus() ? nvt : num_cus()) : a.ntiles;
     // With two slab buffers the epilogue parks its fp32 k-partials in the idle one.  A workgroup that walks several
     // tiles would then read those bits back as halves in the k padding [R*KI, KP) of the next tile's slab rows (the
     // padding is zeroed once, before the tile loop), and 0 x NaN poisons the accumulators: shapes with k padding

@@ -20,7 +20,7 @@ bool ring_enabled() {
 bool forward_ring_fits(const fc_dims* d) {
     static const bool force = [] { const char* e = getenv("FC_RING"); return e && atoi(e) == 2; }();
     if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
-    return force || (d->N + kTile - 1) / kTile > kNumCUs;
+    return force || (d->N + kTile - 1) / kTile > num_cus();
 }
 
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {
@@ -57,7 +57,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
     const int nvt = a.ntiles << a.parts_log2;
-    const int grid = nvt < 2 * kNumCUs ? nvt : 2 * kNumCUs;      // persistent: two workgroups per CU
+    const int grid = nvt < 2 * num_cus() ? nvt : 2 * num_cus();      // persistent: two workgroups per CU
     // the last, partly filled round: as half tiles when those still fit one round
     const int rem = nvt % grid;
     a.nv_full = nvt;

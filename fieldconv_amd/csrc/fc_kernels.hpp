@@ -14,7 +14,20 @@
 namespace fc {
 
 constexpr size_t kMaxLds = 160 * 1024;
-constexpr int kNumCUs = 256;         // MI355X: 8 XCDs x 32 CUs; persistent grids launch one workgroup per CU
+constexpr int kDefaultCUs = 256;     // MI355X: 8 XCDs x 32 CUs (used when no device can be queried, e.g. size queries on a CPU-only box)
+constexpr int kMaxDevices = 16;
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount; a partitioned or partial-CU device reports
+// fewer than 256): sizes the persistent grids, the edge split and the ring-major threshold.  Queried once per device.
+inline int num_cus() {
+    static int cached[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return kDefaultCUs;
+    if (dev < kMaxDevices && cached[dev] > 0) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = kDefaultCUs;
+    if (dev < kMaxDevices) cached[dev] = n;
+    return n;
+}
 constexpr int kMaxChannels = 64;     // one channel per lane in the gather phases
 
 // kind: 0 dense stencil rows, 1 factored records, 2 geometric-phase records
@@ -54,7 +67,6 @@ unsigned long long* debug_stamp_buffer();
 // Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised -- once per
 // function and device, not per launch (the call costs a few microseconds of host time).  `done`: a static flag array of
 // the calling launcher (one per kernel instantiation).
-constexpr int kMaxDevices = 16;
 inline bool allow_full_lds(const void* fn, size_t lds_bytes, bool (&done)[kMaxDevices]) {
     if (lds_bytes <= 64 * 1024) return true;
     int dev = 0;

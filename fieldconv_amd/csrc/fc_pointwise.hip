@@ -300,7 +300,7 @@ extern "C" {
 namespace {
 int lin_grid(int N) {
     const int groups = ((N + 15) / 16 + fc::kLinWaves - 1) / fc::kLinWaves;
-    return groups < 4 * fc::kNumCUs ? groups : 4 * fc::kNumCUs;
+    return groups < 4 * fc::num_cus() ? groups : 4 * fc::num_cus();
 }
 int lin_gw_groups(int N) {
     const int nblocks = (N + 15) / 16;

@@ -362,7 +362,7 @@ inline int edge_parts_log2(const fc_dims* d) {
     const long deg = (long)d->E / d->N;
     static const int cap = [] { const char* e = getenv("FC_EDGE_PARTS_MAX"); return e ? atoi(e) : 3; }();       // read once per process
     int pl = 0;
-    while (pl < cap && (ntiles << (pl + 1)) <= kNumCUs && (deg >> (pl + 1)) >= 8) ++pl;
+    while (pl < cap && (ntiles << (pl + 1)) <= num_cus() && (deg >> (pl + 1)) >= 8) ++pl;
     return pl;
 }
 

@@ -90,6 +90,34 @@ def test_bench_two_ranks_on_one_gpu(fwd_overlap, mode):
         assert 'data-parallel x2' in line['config']['parallelism']
 
 
+def test_bench_starts_its_own_ranks_from_the_plain_command_line():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent never touches the GPU, starts the two ranks
+    through torch.distributed.run itself and relays rank 0's JSON line as its last stdout line (both ranks on this box's one
+    GPU, hence gloo)."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--verts', '3000',
+           '--no-cpu-baseline', '--no-extras']
+    env = _clean_env({'BENCH_BACKEND': 'gloo', 'OMP_NUM_THREADS': '4'})
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['warmup'] == 1 and line['steps'] == 3
+    assert line['config']['halo_rows_rank0'] > 0
+
+
+def test_bench_line_is_the_literal_protocol():
+    """value / ms_per_step come from the first warmup + steps of the process; the sustained-clock repeat is the `settled` extra."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '2', '--verts', '3000', '--no-cpu-baseline',
+           '--no-extras']
+    res = subprocess.run(cmd, cwd=ROOT, env=_clean_env({}), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['warmup'] == 2 and line['steps'] == 4 and line['value'] > 0
+    assert line['settled']['extra_untimed_steps'] >= 2 + 4 + 1 and line['settled']['value'] > 0
+    assert line['roofline']['frac'] > 0 and line['roofline']['avg_launch_ms'] > 0
+
+
 def test_bench_data_parallel_mode_single_rank():
     """bench.py --mode dp (BASELINE configs[4]: one mesh per rank, replicated net, one bucketed all-reduce) with a
     single rank over RCCL."""
@@ -101,3 +129,4 @@ def test_bench_data_parallel_mode_single_rank():
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and 'data-parallel' in line['config']['parallelism']
+    assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1 and line['roofline']['kernel'].startswith('fc_')

@@ -292,3 +292,20 @@ def test_factored_stencil_stands_in_for_the_tensor():
     assert float((s.materialize() - sten).abs().max()) < 2e-6 * float(sten.abs().max())
     assert torch.allclose(torch.abs(s), sten.abs(), atol=1e-6) and torch.allclose(s.abs(), sten.abs(), atol=1e-6)
     assert tuple(s[3:7].shape) == (4, R, 2 * B + 1) and s.contiguous().is_contiguous()
+
+
+def test_bench_refuses_debug_switches_and_explains_missing_gpus():
+    """bench.py never reports a line taken with a library debug switch set, and `--gpus N` from a plain shell is handled by
+    the script itself (here: no GPU, so it says so and exits non-zero without touching a device)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if not k.startswith('FC_') and k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    res = subprocess.run([sys.executable, bench], env=dict(env, FC_DEBUG_BWD='2'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and 'FC_DEBUG_BWD' in res.stderr and res.stdout.strip() == ''
+    import torch
+    if torch.cuda.device_count() == 0:
+        res = subprocess.run([sys.executable, bench, '--gpus', '2'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             timeout=300)
+        assert res.returncode == 2 and 'GPU(s) visible' in res.stderr

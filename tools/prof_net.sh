@@ -2,6 +2,7 @@
 # Per-kernel GPU time of the config-3 network step: rocprofv3 kernel trace of tools/bench_net.py, summary csv copied to
 # gpurun_out/net_prof/.  Usage (on the GPU box): bash tools/prof_net.sh
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__; __graft_entry__.build()" || exit 1   # never build under the profiler
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/net_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/net_prof -o net -- python3 "$ROOT/tools/bench_net.py" 2>&1 | grep "segmentation net"

@@ -3,6 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SCRIPT=$1; ROWS=${2:-30}
 NAME=$(basename "$SCRIPT" .py)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__; __graft_entry__.build()" || exit 1   # never build under the profiler
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$NAME
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -o p -- python3 "$ROOT/$SCRIPT" 2>&1 | grep -v "rocprofv3\|amdgpu.ids" | tail -4

@@ -9,6 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-prof}
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
+# build first, from a process no profiler has touched (see tools/pmc_fwd.sh; bench.py refuses to build under rocprofv3)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__; __graft_entry__.build()" || exit 1
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 10"
 rm -rf /tmp/pb_*
