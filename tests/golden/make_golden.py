@@ -269,6 +269,75 @@ def net_cases(out):
     out['segmentation_net'] = rec
 
 
+def correspondence_net_case(out):
+    """The correspondence network's topology (reference correspondence.ipynb, class Net): LiftBlock(3 -> 16), eight
+    FCResNetBlocks with TangentPerceptron meta-residuals (the last one frontload=True, nf -> 16), ECHOBlock, two linear
+    layers -- at the width BASELINE configs[4] names (nf = 64, band_limit 3), on a small synthetic log-map that goes through
+    the REFERENCE's FCPrecomp (as the notebook's organizeEdges does).  The dropout layer of the notebook is left out
+    (evaluation mode: identity).  2.9 M parameters: filled from tests/golden/param_fill.py on both sides, the fixture keeps
+    FCPrecomp's inputs, logits, loss and a subsample + norm of every parameter gradient."""
+    sys.path.insert(0, HERE)
+    from param_fill import fill_params, grad_sample
+    B, R, nf, n_classes, n_des, n_bins = 3, 6, 64, 24, 12, 2
+    N, k, eps = 208, 9, 0.2
+    g = torch.Generator().manual_seed(4242)
+    edges, logMag, logAng, xp, w = synthetic_logmap(g, N, k, eps)
+    d = _Data()
+    d.logMag, d.logAng, d.w, d.supp_edges, d.xp = logMag, logAng, w, edges, xp
+    supp_edges, supp_sten, ln, wxp = ref_fc_precomp.FCPrecomp(B, R, eps)(d)
+    pos = torch.randn(N, 3, generator=g)
+    labels = torch.randint(0, n_classes, (N,), generator=g)
+    kw = dict(band_limit=B, n_rings=R, ftype=1)
+    mods = torch.nn.ModuleDict(dict(
+        lift=refnn.LiftBlock(3, 16, n_rings=R, ftype=1),
+        resnet1=refnn.FCResNetBlock(16, nf, **kw), resnet2=refnn.FCResNetBlock(nf, nf, **kw),
+        resnet3=refnn.FCResNetBlock(nf, nf, **kw), resnet4=refnn.FCResNetBlock(nf, nf, **kw),
+        resnet5=refnn.FCResNetBlock(nf, nf, **kw), resnet6=refnn.FCResNetBlock(nf, nf, **kw),
+        resnet7=refnn.FCResNetBlock(nf, nf, **kw), resnet8=refnn.FCResNetBlock(nf, 16, frontload=True, **kw),
+        echo=refnn.ECHOBlock(16, nf, n_des=n_des, n_bins=n_bins, **kw),
+        res1=refnn.TangentPerceptron(16, nf), res2=refnn.TangentPerceptron(nf, nf), res3=refnn.TangentPerceptron(nf, nf),
+        res4=refnn.TangentPerceptron(nf, 16), lin1=torch.nn.Linear(nf, 256), lin2=torch.nn.Linear(256, n_classes)))
+    fill_params(mods)
+
+    def run(mods, pos, supp_edges, supp_sten, ln, wxp, trunk_only=False):
+        conv = (supp_edges, supp_sten)
+        x1 = mods['lift'](pos, supp_edges, supp_sten[..., B:B + 2])
+        x = mods['resnet1'](x1, *conv)
+        x2 = mods['resnet2'](x, *conv) + mods['res1'](x1)
+        x = mods['resnet3'](x2, *conv)
+        x3 = mods['resnet4'](x, *conv) + mods['res2'](x2)
+        x = mods['resnet5'](x3, *conv)
+        x4 = mods['resnet6'](x, *conv) + mods['res3'](x3)
+        x = mods['resnet7'](x4, *conv)
+        x = mods['resnet8'](x, *conv) + mods['res4'](x4)
+        if trunk_only:
+            return x
+        h = mods['echo'](x, supp_edges, supp_sten, ln, wxp)
+        logits = mods['lin2'](torch.relu(mods['lin1'](h)))
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        params = dict(mods.named_parameters())
+        grads = torch.autograd.grad(loss, list(params.values()))
+        return x, logits, loss, params, grads
+
+    x, logits, loss, params, grads = run(mods, pos, supp_edges, supp_sten, ln, wxp)
+    # the convolutional trunk again in float64 (same parameter values; the reference's FCPrecomp and ECHO are float32-only,
+    # so the stencil is cast and the run stops in front of the ECHOBlock): how far the reference's own fp32 rounding
+    # carries through the 8 blocks -- the GPU test's gate for the trunk output is a small multiple of it
+    x64 = run(mods.double(), pos.double(), supp_edges, supp_sten.to(torch.cdouble), None, None, trunk_only=True)
+    rec = dict(edges=np_(edges), logMag=np_(logMag), logAng=np_(logAng), xp=np_(xp), w=np_(w), eps=eps, pos=np_(pos),
+               labels=np_(labels), logits=np_(logits), loss=np_(loss), x_last64=np_(x64), B=B, R=R,
+               nf=nf, n_classes=n_classes, n_des=n_des, n_bins=n_bins, kept_edges=supp_edges.shape[0], x_last=np_(x),
+               n_params=sum(p.numel() for p in params.values()))
+    # probes of the parameter fill: the test's fill must reproduce the generator's bit for bit
+    rec['pfill_probe'] = np.concatenate([np_(params[n]).reshape(-1)[:: max(1, params[n].numel() // 64)][:64]
+                                          for n in ('resnet2.conv1.spherical', 'res3.lin.Im', 'lin2.weight')])
+    for (name, _), gval in zip(params.items(), grads):
+        sub, stats = grad_sample(np_(gval))
+        rec['g_' + name] = sub
+        rec['gstat_' + name] = stats
+    out['correspondence_net'] = rec
+
+
 def main():
     groups = {
         'fieldconv.npz': fieldconv_cases,
@@ -277,8 +346,12 @@ def main():
         'pointwise.npz': pointwise_cases,
         'echo_lift.npz': echo_lift_cases,
         'net.npz': net_cases,
+        'net_correspondence.npz': correspondence_net_case,
     }
+    only = sys.argv[1:]
     for fname, fn in groups.items():
+        if only and fname not in only:
+            continue
         cases = {}
         fn(cases)
         flat = {}

@@ -249,6 +249,72 @@ def test_fused_precomp_graph(dev, monkeypatch, N, k, B, R):
         FCPrecomp(B, R, data.epsilon)(dd)
 
 
+def test_config2_on_the_graph_the_benchmark_builds(dev):
+    """BASELINE configs[1] on the support graph bench.py itself convolves over: the one fieldconv_amd.transforms.FCPrecomp
+    returns at 20 000 vertices (fc_precomp_mark + fc_precomp_graph: selection, both groupings and the per-edge records
+    straight from (logMag, logAng, w, supp_edges, xp) -- no dense stencil anywhere).  Checked against the oracle, whose
+    stencil comes from its own FCPrecomp on the CPU: kept edges / ln / wxp, 150 random rows of y and gx on the sub-edge-lists
+    that determine them, the filter gradient through the adjoint identity with the ORACLE evaluating the left-hand side
+    (linear in the filter: a few probe filters on the sub-mesh), and the grouping arrays against a stable sort."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import FactoredStencil, get_graph
+    from fieldconv_amd.transforms import FCPrecomp
+    from oracle.torch_composites import FCPrecomp as FCPrecompRef
+    if os.environ.get('FIELDCONV_DENSE') == '1' or os.environ.get('FIELDCONV_EAGER_STENCIL') == '1':
+        pytest.skip('the fused build is switched off in this mode')
+    N, k, I, O, B, R = 20000, 32, 48, 48, 2, 6
+    data = sphere_support(N, k, seed=0, support='p95')
+    e_dev, s_dev, ln_dev, wxp_dev = FCPrecomp(B, R, data.epsilon)(data.to(dev))
+    assert isinstance(s_dev, FactoredStencil) and s_dev._dense is None
+    graph = get_graph(e_dev, s_dev, N)
+    assert graph is s_dev.graph and graph.factored and graph.geo_t is not None
+    edges, sten, ln, wxp = FCPrecompRef(B, R, data.epsilon)(data)
+    assert torch.equal(e_dev.cpu(), edges)
+    assert rel_err(H(ln_dev), H(ln)) < 1e-6 and rel_err(H(wxp_dev), H(wxp)) < 1e-6
+    # groupings: CSR by target / by source of the kept edges, slots ordered by (vertex, lower ring, edge id)
+    E = edges.shape[0]
+    for col, rowptr, perm in ((1, graph.rowptr_t, graph.perm_t), (0, graph.rowptr_s, graph.perm_s)):
+        deg = torch.bincount(edges[:, col], minlength=N)
+        assert torch.equal(rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]))
+        pc = perm.cpu().long()
+        assert torch.equal(torch.sort(pc).values, torch.arange(E))           # a permutation of the kept edges
+        assert torch.equal(edges[pc, col], torch.repeat_interleave(torch.arange(N), deg))   # grouped by that endpoint
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    x[torch.rand(N, I, generator=g) < 0.01] = 0
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    y, gx, gW = run_conv(graph, x, W, gy, dev)
+    sub = torch.randperm(N, generator=g)[:150]
+    idx = sub.numpy()
+    m_in = torch.isin(edges[:, 1], sub)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges[m_in].numpy(), sten[m_in].numpy(), W.numpy())[idx]
+    m_out = torch.isin(edges[:, 0], sub)
+    gx_ref = orc.fieldconv_backward(x.numpy(), edges[m_out].numpy(), sten[m_out].numpy(), W.numpy(), gy.numpy())[0][idx]
+    assert rel_err(H(y)[idx], y_ref) < TOL
+    assert rel_err(H(gx)[idx], gx_ref) < TOL
+    # filter gradient: Re<gy, conv(x; V)> = Re<gW, V> with gy supported on `sub`, so that the ORACLE can evaluate the left-hand
+    # side on the sub-edge-list; gW of that cotangent comes from the kernels on the whole mesh
+    gy_sub = torch.zeros_like(gy)
+    gy_sub[sub] = gy[sub]
+    _, _, gW_sub = run_conv(graph, x, W, gy_sub, dev)
+    for trial in range(3):
+        V = torch.complex(torch.randn(W.shape, generator=g), torch.randn(W.shape, generator=g)) * 0.1
+        yv = orc.fieldconv_forward(x.numpy(), edges[m_in].numpy(), sten[m_in].numpy(), V.numpy())
+        lhs = float(np.sum(np.conj(gy_sub.numpy()) * yv).real)
+        rhs = float(torch.sum(torch.conj(gW_sub.cpu()) * V).real)
+        assert abs(lhs - rhs) <= max(2e-4, TOL) * max(abs(lhs), abs(rhs), 1.0), trial
+    # and on the whole mesh against the kernels' own forward pass
+    Vd = (torch.complex(torch.randn(W.shape, generator=g), torch.randn(W.shape, generator=g)) * 0.1).to(dev)
+    with torch.no_grad():
+        yv = field_conv(x.to(dev), Vd, graph)
+    lhs = torch.sum(torch.conj(gy.to(dev)) * yv).real.item()
+    rhs = torch.sum(torch.conj(gW) * Vd).real.item()
+    assert abs(lhs - rhs) <= max(2e-4, TOL) * max(abs(lhs), abs(rhs), 1.0)
+
+
 def test_precomp_cache_round_trip(dev, tmp_path):
     """Cached per-mesh preprocessing (transforms/precomp_cache.py): what the fused FCPrecomp produced is written to a file
     and read back; the loaded (supp_edges, supp_sten, ln, wxp) drive a FCResNetBlock and an ECHOBlock to bit-identical

@@ -3,6 +3,7 @@ reference modules, the CPU oracle on seeded inputs, and size-independent propert
 benchmark size.  Tolerance: max|delta| <= 1e-5 * max|ref| in fp32 (the
 reference's own fp32-vs-fp64 error is ~2e-7)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -258,6 +259,78 @@ def test_segmentation_net_golden(dev):
     worst = max((rel_err(H(g), c['g_' + name]), name) for (name, _), g in zip(params.items(), grads))
     print('logits err %.2e, worst gradient err %.2e (%s)' % (rel_err(H(logits), c['logits']), worst[0], worst[1]))
     assert worst[0] < 5 * TOL, worst        # measured 4e-6 through eleven layers
+
+
+@pytest.mark.skipif(REDUCED, reason='twenty-five layers deep: checks the fp32-grade path')
+def test_correspondence_net_golden(dev):
+    """BASELINE configs[4]'s network (reference correspondence.ipynb, class Net) at its width -- 64 channels, band limit 3,
+    frontload=True in the last block, TangentPerceptron meta-residuals -- through the PRODUCT path end to end: our FCPrecomp
+    on the raw log-map (fused graph build, FactoredStencil), the strided lift slice, eight FCResNetBlocks, ECHOBlock, two
+    linear layers, cross-entropy, every parameter gradient.  Reference run captured in net_correspondence.npz
+    (tests/golden/make_golden.py; parameters from tests/golden/param_fill.py on both sides).
+
+    Gate.  The reference's own float32 run is 4.5e-4 away from its float64 run at the trunk output (modReLU and angle()
+    amplify rounding where |x| is small), so 1e-5 against the float32 capture would test luck, not kernels.  The trunk output
+    must be no further from the float64 run than 3x the reference's float32 run is; logits, loss and the gradient samples
+    must agree with the float32 capture to a small multiple of that same figure."""
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock, TangentPerceptron
+    from fieldconv_amd.transforms import FCPrecomp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from param_fill import fill_params, grad_sample
+    c = load_golden('net_correspondence.npz')['correspondence_net']
+    B, R, nf = int(c['B']), int(c['R']), int(c['nf'])
+    kw = dict(band_limit=B, n_rings=R, ftype=1)
+    mods = torch.nn.ModuleDict(dict(
+        lift=LiftBlock(3, 16, n_rings=R, ftype=1),
+        resnet1=FCResNetBlock(16, nf, **kw), resnet2=FCResNetBlock(nf, nf, **kw), resnet3=FCResNetBlock(nf, nf, **kw),
+        resnet4=FCResNetBlock(nf, nf, **kw), resnet5=FCResNetBlock(nf, nf, **kw), resnet6=FCResNetBlock(nf, nf, **kw),
+        resnet7=FCResNetBlock(nf, nf, **kw), resnet8=FCResNetBlock(nf, 16, frontload=True, **kw),
+        echo=ECHOBlock(16, nf, n_des=int(c['n_des']), n_bins=int(c['n_bins']), **kw),
+        res1=TangentPerceptron(16, nf), res2=TangentPerceptron(nf, nf), res3=TangentPerceptron(nf, nf),
+        res4=TangentPerceptron(nf, 16), lin1=torch.nn.Linear(nf, 256), lin2=torch.nn.Linear(256, int(c['n_classes']))))
+    assert sum(p.numel() for p in mods.parameters()) == int(c['n_params'])
+    mods = fill_params(mods)
+    pr = dict(mods.named_parameters())
+    probe = np.concatenate([H(pr[n]).reshape(-1)[:: max(1, pr[n].numel() // 64)][:64] for n in ('resnet2.conv1.spherical', 'res3.lin.Im', 'lin2.weight')])
+    assert np.array_equal(probe, c['pfill_probe'])          # same parameter values as the generator's reference modules
+    mods = mods.to(dev)
+
+    class Mesh:
+        pass
+    d = Mesh()
+    d.logMag, d.logAng, d.w, d.supp_edges, d.xp = (D(c[k], dev) for k in ('logMag', 'logAng', 'w', 'edges', 'xp'))
+    edges, sten, ln, wxp = FCPrecomp(B, R, float(c['eps']))(d)
+    assert edges.shape[0] == int(c['kept_edges'])
+    conv = (edges, sten)
+    x1 = mods['lift'](D(c['pos'], dev), edges, sten[..., B:B + 2])
+    x = mods['resnet1'](x1, *conv)
+    x2 = mods['resnet2'](x, *conv) + mods['res1'](x1)
+    x = mods['resnet3'](x2, *conv)
+    x3 = mods['resnet4'](x, *conv) + mods['res2'](x2)
+    x = mods['resnet5'](x3, *conv)
+    x4 = mods['resnet6'](x, *conv) + mods['res3'](x3)
+    x = mods['resnet7'](x4, *conv)
+    x = mods['resnet8'](x, *conv) + mods['res4'](x4)
+    h = mods['echo'](x, edges, sten, ln, wxp)
+    logits = mods['lin2'](torch.relu(mods['lin1'](h)))
+    loss = torch.nn.functional.cross_entropy(logits, D(c['labels'], dev))
+    ref_own = rel_err(c['x_last'], c['x_last64'])                 # the reference's float32 run against its float64 run
+    ours = rel_err(H(x), c['x_last64'])
+    print('trunk output vs float64: ours %.2e, reference float32 %.2e; logits vs float32 capture %.2e' % (
+        ours, ref_own, rel_err(H(logits), c['logits'])))
+    assert ours < 3 * ref_own
+    assert rel_err(H(logits), c['logits']) < 4 * ref_own
+    assert abs(float(loss.detach()) - float(c['loss'])) < 4 * ref_own * max(1.0, abs(float(c['loss'])))
+    params = dict(mods.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()))
+    worst = (0.0, None)
+    for (name, _), g in zip(params.items(), grads):
+        sub, stats = grad_sample(H(g))
+        e = rel_err(sub, c['g_' + name])
+        worst = max(worst, (e, name))
+        assert abs(stats[0] - c['gstat_' + name][0]) < 0.02 * c['gstat_' + name][0] + 1e-12, name          # 2-norm of the whole tensor
+    print('worst gradient sample err %.2e (%s)' % worst)
+    assert worst[0] < 20 * ref_own, worst            # ~1e-2: gradients pass the same amplifying points twice
 
 
 # ---------------------------------------------------------------- seeded inputs vs the oracle

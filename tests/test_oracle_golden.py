@@ -96,3 +96,28 @@ def test_reference_port_torch(tag):
     gx, gz = torch.autograd.grad(y, [x, z], grad_outputs=torch.from_numpy(c['gy']))
     assert rel_err(gx.numpy(), c['gx']) < TOL32 * 5
     assert rel_err(gz.numpy(), c['g_zonal']) < TOL32 * 5
+
+
+def test_correspondence_fixture_parameter_fill_is_reproducible():
+    """net_correspondence.npz keeps no parameters: generator and GPU test fill them from tests/golden/param_fill.py.  The
+    fill must give the generator's values bit for bit (probes stored in the fixture), here through our own module classes
+    -- which also pins parameter names and shapes of the correspondence topology to the reference's."""
+    import os
+    import sys
+    import torch
+    from conftest import GOLDEN, load_golden
+    sys.path.insert(0, GOLDEN)
+    from param_fill import fill_params
+    from fieldconv_amd.nn import FCResNetBlock, TangentPerceptron
+    c = load_golden('net_correspondence.npz')['correspondence_net']
+    B, R, nf = int(c['B']), int(c['R']), int(c['nf'])
+    mods = torch.nn.ModuleDict(dict(resnet2=FCResNetBlock(nf, nf, band_limit=B, n_rings=R, ftype=1), res3=TangentPerceptron(nf, nf),
+                                    lin2=torch.nn.Linear(256, int(c['n_classes']))))
+    fill_params(mods)
+    pr = dict(mods.named_parameters())
+    probe = np.concatenate([pr[n].detach().numpy().reshape(-1)[:: max(1, pr[n].numel() // 64)][:64]
+                            for n in ('resnet2.conv1.spherical', 'res3.lin.Im', 'lin2.weight')])
+    assert np.array_equal(probe, c['pfill_probe'])
+    assert np.isfinite(c['logits']).all() and c['logits'].shape == (c['pos'].shape[0], int(c['n_classes']))
+    # every parameter of the full topology has a gradient sample in the fixture
+    assert sum(1 for k in c if k.startswith('g_')) == sum(1 for k in c if k.startswith('gstat_')) >= 100
