@@ -53,13 +53,14 @@ SIGNATURES = {
     'fc_forward_factored': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
     'fc_geometric_record_floats': (ctypes.c_int, []),
     'fc_forward_geometric': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
-    'fc_backward_workspace_bytes': (_sz, [_DP]),
+    'fc_records_flags': (_c_int32, [_DP, _c_int32]),
+    'fc_backward_workspace_bytes': (_sz, [_DP, _c_int32]),
     'fc_backward_data': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
-    'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
-    'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
-    'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _vp]),
+    'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _c_int32, _vp]),
+    'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
+    'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_all': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _FP, _vp, _sz, _DP, _vp]),
-    'fc_forward_params': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _FP, _vp, _vp, _vp, _vp, _sz, _DP, _EP, _vp]),
+    'fc_forward_params': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _FP, _vp, _vp, _vp, _vp, _sz, _DP, _c_int32, _EP, _vp]),
     'fc_echo_hist_dim': (ctypes.c_int, [_c_int32]),
     'fc_echo_channel_block': (ctypes.c_int, [_c_int32]),
     'fc_echo_forward': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),

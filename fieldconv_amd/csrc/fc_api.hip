@@ -41,7 +41,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 5; }
+int fc_abi_version(void) { return 6; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -67,13 +67,13 @@ size_t fc_packed_filter_floats_bwd(const fc_dims* d, int32_t records) {
 }
 
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
-    if (!w_eff || !wpk_fwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!w_eff || (!wpk_fwd && !wpk_bwd) || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     return fc::pack_filter_impl(w_eff, wpk_fwd, wpk_bwd, dims, records, static_cast<hipStream_t>(stream));
 }
 
 int fc_pack_filter_params(const float* zonal, const float* spherical, const float* phase, int32_t ftype, float* wpk_fwd,
                           float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream) {
-    if (!zonal || !spherical || !wpk_fwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!zonal || !spherical || (!wpk_fwd && !wpk_bwd) || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (ftype < 0 || ftype > 2 || (ftype == 1 && !phase)) return FC_ERR_BAD_ARGUMENT;
     return fc::pack_filter_params_impl(zonal, spherical, phase, ftype, wpk_fwd, wpk_bwd, dims, records,
                                        static_cast<hipStream_t>(stream));
@@ -125,9 +125,15 @@ int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_ta
     return fc::forward_impl(x, geo_t, by_target, wpk_fwd, y, dims, 2, workspace, workspace_bytes, epilogue, static_cast<hipStream_t>(stream));
 }
 
-size_t fc_backward_workspace_bytes(const fc_dims* dims) {
+int32_t fc_records_flags(const fc_dims* dims, int32_t record_driven) {
+    if (!record_driven) return 0;
+    if (!fc::dims_valid(dims) || !fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return 1;
+    return fc::backward_ring_fits(dims) ? 3 : 1;
+}
+
+size_t fc_backward_workspace_bytes(const fc_dims* dims, int32_t records) {
     if (!fc::dims_supported(dims)) return 0;
-    return fc::backward_workspace_bytes(dims);
+    return (records & 2) ? fc::backward_ring_workspace_bytes(dims) : fc::backward_workspace_bytes(dims);
 }
 
 static int check_bwd(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
@@ -149,24 +155,29 @@ int fc_backward_data(const float* x, const float* gy, const float* sten_s, const
 
 int fc_backward_data_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
                               const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
-                              const fc_dims* dims, void* stream) {
+                              const fc_dims* dims, int32_t records, void* stream) {
     const int rc = check_bwd(x, gy, rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;
     if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
     if (dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
+    if (records & 2)
+        return fc::backward_ring_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims,
+                                           static_cast<hipStream_t>(stream));
     return fc::backward_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, true,
                                   static_cast<hipStream_t>(stream));
 }
 
-int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!x || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    if (records & 2) return fc::backward_ring_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
     return fc::backward_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
-int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream) {
+int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    if (records & 2) return fc::backward_ring_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
@@ -174,12 +185,12 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream) {
     if (!gw_eff) return FC_ERR_BAD_ARGUMENT;
-    int rc = records ? fc_backward_data_factored(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, stream)
+    int rc = records ? fc_backward_data_factored(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, records, stream)
                      : fc_backward_data(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, stream);
     if (rc != FC_OK) return rc;
-    rc = fc_backward_filter(x, workspace, workspace_bytes, dims, stream);
+    rc = fc_backward_filter(x, workspace, workspace_bytes, dims, records, stream);
     if (rc != FC_OK) return rc;
-    rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, stream);
+    rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
     if (rc != FC_OK || !params) return rc;
     return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
                                  params->g_spherical, params->g_phase, dims, stream);
@@ -187,10 +198,10 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
 
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,
                       const fc_filter_params* params, float* wpk_fwd, float* wpk_bwd, float* y, void* workspace,
-                      size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream) {
-    if (!params || kind < 0 || kind > 2) return FC_ERR_BAD_ARGUMENT;
+                      size_t workspace_bytes, const fc_dims* dims, int32_t records, const fc_epilogue* epilogue, void* stream) {
+    if (!params || kind < 0 || kind > 2 || ((kind != 0) != ((records & 1) != 0))) return FC_ERR_BAD_ARGUMENT;
     const int rc = fc_pack_filter_params(params->zonal, params->spherical, params->phase, params->ftype, wpk_fwd, wpk_bwd, dims,
-                                         kind != 0, stream);
+                                         records, stream);
     if (rc != FC_OK) return rc;
     if (kind == 2) return fc_forward_geometric(x, sten_or_records, by_target, wpk_fwd, y, workspace, workspace_bytes, dims, epilogue, stream);
     if (kind == 1) return fc_forward_factored(x, sten_or_records, by_target, wpk_fwd, y, workspace, workspace_bytes, dims, epilogue, stream);

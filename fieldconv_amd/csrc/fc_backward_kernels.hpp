@@ -276,6 +276,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         if (f0 + ff < F) mx = fmaxf(mx, fmaxf(fabsf(h[r][ff].x), fabsf(h[r][ff].y)));
                 mx = wave_max_nonneg(mx);
                 split_scale(mx, scale, inv_scale);
+                // an all-zero row (a source without out-edges, or with a zero cotangent on all of them) drops out of the filter
+                // kernel's second operand x~ / s_v and of its column scales: inverse scale 0 instead of 1
+                if (mx == 0.f) inv_scale = 0.f;
                 if (lane == 0) { vs[wave] = scale; vs[kTile + wave] = inv_scale; }     // read after the slab barrier below
             }
 #pragma unroll

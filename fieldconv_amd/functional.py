@@ -171,10 +171,11 @@ def _conv_plan(lib, graph, I, O, B):
         raise _lib.FieldConvNativeError(
             f'FieldConv(in={I}, out={O}, n_rings={graph.R}, band_limit={B}) is outside the compiled HIP kernels '
             '(channels <= 64; (n_rings, band_limit) as listed in csrc/fc_kernels.hpp)')
-    plan.records = 1 if graph.factored else 0      # which entry-point family the packed filter images are for
+    # which entry-point family the packed filter images are for (bit 0: record-driven; bit 1: the ring-major backward kernels)
+    plan.records = lib.fc_records_flags(plan.dref, 1 if graph.factored else 0)
     plan.n_fwd = lib.fc_packed_filter_floats_fwd(plan.dref, plan.records)
     plan.n_bwd = lib.fc_packed_filter_floats_bwd(plan.dref, plan.records)
-    plan.ws_bwd = lib.fc_backward_workspace_bytes(plan.dref)
+    plan.ws_bwd = lib.fc_backward_workspace_bytes(plan.dref, plan.records)
     plan.ws_fwd = 0
     if graph.factored and os.environ.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1':
         plan.ws_fwd = lib.fc_forward_workspace_bytes(plan.dref)      # non-zero on small meshes with wide supports
@@ -272,7 +273,7 @@ def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None, param
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
             kind, recs = (2, graph.geo_t) if graph.geo_t is not None else ((1, graph.rec_t) if graph.factored else (0, graph.sten_t))
             check(lib.fc_forward_params(_p(x), _p(recs), plan.cref_t, kind, ctypes.byref(fp), _p(wpk_f), _p(wpk_b), _p(y),
-                                        _p(ws) if ws is not None else None, nbytes, plan.dref, epi, st), 'fc_forward_params')
+                                        _p(ws) if ws is not None else None, nbytes, plan.dref, plan.records, epi, st), 'fc_forward_params')
             return (y if bias is None else (y, act)), wpk_b
         pack(plan, wpk_f, wpk_b)
         if between is not None:
@@ -313,17 +314,21 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
         fp = FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, g_z.data_ptr(), g_s.data_ptr(),
                             g_p.data_ptr() if g_p is not None else None)
     if graph.on_gx is None and _ONE_CALL and not kernel_timer.enabled:
-        check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, 1 if graph.factored else 0, _p(wpk_b), _p(gx), _p(gw),
+        check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, plan.records, _p(wpk_b), _p(gx), _p(gw),
                                   ctypes.byref(fp) if fp is not None else None, wsp, nbytes, plan.dref, st), 'fc_backward_all')
         return gx, gw, pgrads
-    fn = lib.fc_backward_data_factored if graph.factored else lib.fc_backward_data
     with _timed('fc_backward_data'):
-        check(fn(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_data')
+        if graph.factored:
+            check(lib.fc_backward_data_factored(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref,
+                                                plan.records, st), 'fc_backward_data_factored')
+        else:
+            check(lib.fc_backward_data(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st),
+                  'fc_backward_data')
     if graph.on_gx is not None:         # gx is complete (in stream order): a partitioned mesh starts returning its halo rows
         graph.on_gx(gx)                 # now, under the filter-gradient kernel
     with _timed('fc_backward_filter'):
-        check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, st), 'fc_backward_filter')
-    check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, st), 'fc_backward_finish')
+        check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_filter')
+    check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_finish')
     if fp is not None:
         check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ftype, _p(g_z), _p(g_s),
                                         _p(g_p) if g_p is not None else None, plan.dref, st), 'fc_filter_param_grads')

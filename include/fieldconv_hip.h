@@ -83,6 +83,14 @@ int fc_supported(const fc_dims* dims);
  * 256 tiles of 16 vertices): the layout follows dims->N, so an image is packed with the dims of the launch it is for
  * (a forward pass launched in two row ranges packs one image per range).  Sizes differ between the two families, ask with
  * the same `records`.  wpk_bwd may be NULL: only the forward image is written. */
+/* `records` for every call below that takes one: 0 for the dense-stencil entry points; for the record-driven ones the value
+ * fc_records_flags(dims, 1) returns for the dims of the BACKWARD launch (the whole mesh): 1, or 3 when that launch takes the
+ * ring-major backward kernels (csrc/fc_backward_ring.hpp: default mode, meshes of more than 256 tiles of 16 vertices, shapes
+ * whose (input-channel tile, frequency) pairs fit sixteen wavefronts) -- bit 1 selects their backward image
+ *   IP inverse row scales, then R x {re_hi, re_lo, im_hi, im_lo} x BT blocks x IP x 32 halves, conjugated, k = f*ceil8(O) + o,
+ * their workspace layout and their kernels in fc_backward_workspace_bytes / _data_factored / _filter / _finish / _all.
+ * Either image pointer of the packing calls may be NULL (not both): only the other image is written. */
+int32_t fc_records_flags(const fc_dims* dims, int32_t record_driven);
 size_t fc_packed_filter_floats_fwd(const fc_dims* dims, int32_t records);
 size_t fc_packed_filter_floats_bwd(const fc_dims* dims, int32_t records);
 int fc_pack_filter(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* dims, int32_t records, void* stream);
@@ -154,21 +162,21 @@ int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_ta
  *                                gx (N,I) c64 and leaves H in the workspace
  *   fc_backward_filter           one kernel: filter-gradient partials from the stored H and x
  *   fc_backward_finish           fixed-order sum of the partials into gw_eff (O,I,R,F) c64 */
-size_t fc_backward_workspace_bytes(const fc_dims* dims);
+size_t fc_backward_workspace_bytes(const fc_dims* dims, int32_t records);
 int fc_backward_data(const float* x, const float* gy, const float* sten_s, const fc_csr* by_source,
                      const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
                      const fc_dims* dims, void* stream);
 int fc_backward_data_factored(const float* x, const float* gy, const float* rec_s, const fc_csr* by_source,
                               const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes,
-                              const fc_dims* dims, void* stream);
-int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
-int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, void* stream);
+                              const fc_dims* dims, int32_t records, void* stream);
+int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream);
+int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream);
 
 /* ---- one call per pass: the same kernels, enqueued by one entry point (a binding that pays microseconds per foreign call --
  * ctypes -- spends more time on six calls per convolution than the GPU needs for a small mesh) ---------------------------- *
  * fc_filter_params: the module parameters as fc_pack_filter_params takes them and, for the backward pass, where their
  * gradients go (g_* are ignored by fc_forward_params; g_phase / phase may be NULL unless ftype == 1).
- * fc_forward_params = fc_pack_filter_params (wpk_bwd may be NULL) + fc_forward (kind 0) / fc_forward_factored (1) /
+ * fc_forward_params = fc_pack_filter_params (wpk_bwd may be NULL; `records` as above) + fc_forward (kind 0) / fc_forward_factored (1) /
  *                     fc_forward_geometric (2), same arguments;
  * fc_backward_all   = fc_backward_data (records 0) or fc_backward_data_factored (1) + fc_backward_filter +
  *                     fc_backward_finish into gw_eff (required) + fc_filter_param_grads when params is not NULL. */
@@ -183,7 +191,7 @@ typedef struct fc_filter_params {
 } fc_filter_params;
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,
                       const fc_filter_params* params, float* wpk_fwd, float* wpk_bwd, float* y, void* workspace,
-                      size_t workspace_bytes, const fc_dims* dims, const fc_epilogue* epilogue, void* stream);
+                      size_t workspace_bytes, const fc_dims* dims, int32_t records, const fc_epilogue* epilogue, void* stream);
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream);

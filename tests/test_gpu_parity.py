@@ -256,8 +256,9 @@ def test_segmentation_net_golden(dev):
     assert abs(float(loss.detach()) - float(c['loss'])) < 1e-5 * max(1.0, abs(float(c['loss'])))
     params = dict(mods.named_parameters())
     grads = torch.autograd.grad(loss, list(params.values()))
-    worst = max((rel_err(H(g), c['g_' + name]), name) for (name, _), g in zip(params.items(), grads))
-    print('logits err %.2e, worst gradient err %.2e (%s)' % (rel_err(H(logits), c['logits']), worst[0], worst[1]))
+    errs = sorted(((rel_err(H(g), c['g_' + name]), name) for (name, _), g in zip(params.items(), grads)), reverse=True)
+    worst = errs[0]
+    print('logits err %.2e, worst gradient errs %s' % (rel_err(H(logits), c['logits']), ['%s %.1e' % (n, e) for e, n in errs[:6]] + ['...'] + ['%s %.1e' % (n, e) for e, n in errs[-3:]]))
     assert worst[0] < 5 * TOL, worst        # measured 4e-6 through eleven layers
 
 
@@ -269,10 +270,14 @@ def test_correspondence_net_golden(dev):
     linear layers, cross-entropy, every parameter gradient.  Reference run captured in net_correspondence.npz
     (tests/golden/make_golden.py; parameters from tests/golden/param_fill.py on both sides).
 
-    Gate.  The reference's own float32 run is 4.5e-4 away from its float64 run at the trunk output (modReLU and angle()
-    amplify rounding where |x| is small), so 1e-5 against the float32 capture would test luck, not kernels.  The trunk output
-    must be no further from the float64 run than 3x the reference's float32 run is; logits, loss and the gradient samples
-    must agree with the float32 capture to a small multiple of that same figure."""
+    Gates.  This network amplifies float32 rounding: the reference's own float32 run is 4.5e-4 away from its float64 run at
+    the trunk output, and re-running the reference in float32 with the input positions perturbed by a few ulp (relative 3e-7)
+    moves the trunk output by 6e-4, the logits by 2e-5 and the ECHOBlock's filter gradients by up to 3e-2 (modReLU, angle() and
+    the ECHO rasterisation are discontinuous or ill-conditioned where |x| is small / a vote sits on a cell border).  A float32
+    implementation that rounds differently cannot be closer to the capture than the capture is to that perturbed twin, so
+    every gate is a small multiple of the fixture's own yardsticks (cond_*, gcond_<name>, measured by the generator with
+    the reference itself); the kernels' accuracy proper is tested at 1e-5 against the oracle, layer by layer, elsewhere --
+    tools/check_ring_net.py does it for every convolution of this very step (gW to 5e-7 given its inputs)."""
     from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock, TangentPerceptron
     from fieldconv_amd.transforms import FCPrecomp
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
@@ -314,23 +319,27 @@ def test_correspondence_net_golden(dev):
     h = mods['echo'](x, edges, sten, ln, wxp)
     logits = mods['lin2'](torch.relu(mods['lin1'](h)))
     loss = torch.nn.functional.cross_entropy(logits, D(c['labels'], dev))
-    ref_own = rel_err(c['x_last'], c['x_last64'])                 # the reference's float32 run against its float64 run
+    ref_own = max(rel_err(c['x_last'], c['x_last64']), float(c['cond_x_last']))     # the reference's float32 run against its float64 run / its perturbed twin
     ours = rel_err(H(x), c['x_last64'])
-    print('trunk output vs float64: ours %.2e, reference float32 %.2e; logits vs float32 capture %.2e' % (
-        ours, ref_own, rel_err(H(logits), c['logits'])))
+    e_logits = rel_err(H(logits), c['logits'])
+    print('trunk output vs float64: ours %.2e, reference float32 %.2e; logits vs float32 capture %.2e (perturbed twin %.2e)' % (
+        ours, ref_own, e_logits, float(c['cond_logits'])))
     assert ours < 3 * ref_own
-    assert rel_err(H(logits), c['logits']) < 4 * ref_own
-    assert abs(float(loss.detach()) - float(c['loss'])) < 4 * ref_own * max(1.0, abs(float(c['loss'])))
+    assert e_logits < max(1e-5, 8 * float(c['cond_logits']))
+    assert abs(float(loss.detach()) - float(c['loss'])) < 1e-4 * max(1.0, abs(float(c['loss'])))
     params = dict(mods.named_parameters())
     grads = torch.autograd.grad(loss, list(params.values()))
-    worst = (0.0, None)
+    report = []
     for (name, _), g in zip(params.items(), grads):
         sub, stats = grad_sample(H(g))
         e = rel_err(sub, c['g_' + name])
-        worst = max(worst, (e, name))
-        assert abs(stats[0] - c['gstat_' + name][0]) < 0.02 * c['gstat_' + name][0] + 1e-12, name          # 2-norm of the whole tensor
-    print('worst gradient sample err %.2e (%s)' % worst)
-    assert worst[0] < 20 * ref_own, worst            # ~1e-2: gradients pass the same amplifying points twice
+        cond = float(c['gcond_' + name])
+        report.append((e / max(cond, 5e-6), e, cond, name))
+        assert abs(stats[0] - c['gstat_' + name][0]) < 0.05 * c['gstat_' + name][0] + 1e-12, name          # 2-norm of the whole tensor
+    report.sort(reverse=True)
+    print('gradient samples, worst by (error / perturbed-twin deviation): ' + ', '.join('%s %.1e / %.1e' % (n, e, cd) for _, e, cd, n in report[:5]))
+    for ratio, e, cond, name in report:
+        assert e < max(2e-5, 4 * cond), (name, e, cond)
 
 
 # ---------------------------------------------------------------- seeded inputs vs the oracle

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
-    assert _lib.load(path).fc_abi_version() == 5
+    assert _lib.load(path).fc_abi_version() == 6
 
 
 def test_supported_query_and_sizes_need_no_gpu():
@@ -47,7 +47,8 @@ def test_supported_query_and_sizes_need_no_gpu():
     # split-half image (default mode): 48 row scales + 5 frequencies x 4 half planes x 48 rows x 288 entries
     assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d), 0) == 48 + 5 * 2 * 48 * 288
     assert lib.fc_packed_filter_floats_bwd(ctypes.byref(d), 0) == 48 + 5 * 2 * 48 * 288
-    assert lib.fc_backward_workspace_bytes(ctypes.byref(d)) > 0
+    assert lib.fc_backward_workspace_bytes(ctypes.byref(d), 0) > 0
+    assert lib.fc_records_flags(ctypes.byref(d), 0) == 0 and lib.fc_records_flags(ctypes.byref(d), 1) in (1, 3)
     bad = _lib.FcDims(100, 10, 48, 48, 9, 2)
     assert lib.fc_supported(ctypes.byref(bad)) == 0
     wide = _lib.FcDims(100, 10, 128, 48, 6, 2)

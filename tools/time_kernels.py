@@ -24,13 +24,14 @@ x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
 gy = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
 W = (torch.complex(torch.randn(C, C, R, 2 * B + 1, generator=g), torch.randn(C, C, R, 2 * B + 1, generator=g)) * 0.05).to(dev)
 dims = make_dims(graph, C, C, B)
-wf = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims), 0), device=dev)
-wb = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims), 0), device=dev)
-lib.fc_pack_filter(_p(W), _p(wf), _p(wb), ctypes.byref(dims), 0, _stream())
+REC = lib.fc_records_flags(ctypes.byref(dims), 1 if (os.environ.get('FACT', '1') == '1' and graph.factored) else 0)
+wf = torch.empty(lib.fc_packed_filter_floats_fwd(ctypes.byref(dims), REC), device=dev)
+wb = torch.empty(lib.fc_packed_filter_floats_bwd(ctypes.byref(dims), REC), device=dev)
+lib.fc_pack_filter(_p(W), _p(wf), _p(wb), ctypes.byref(dims), REC, _stream())
 y = torch.empty(N, C, dtype=torch.cfloat, device=dev)
 gx = torch.empty_like(x)
 gw = torch.empty_like(W)
-nb = lib.fc_backward_workspace_bytes(ctypes.byref(dims))
+nb = lib.fc_backward_workspace_bytes(ctypes.byref(dims), REC)
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 ct, cs = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t), _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
 
@@ -46,12 +47,14 @@ def fwd():
 
 
 def bwd_data():
-    fn = lib.fc_backward_data_factored if FACT else lib.fc_backward_data
-    fn(_p(x), _p(gy), _p(graph.rec_s if FACT else graph.sten_s), ctypes.byref(cs), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), _stream())
+    if FACT:
+        lib.fc_backward_data_factored(_p(x), _p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), REC, _stream())
+    else:
+        lib.fc_backward_data(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(cs), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), _stream())
 
 
 def bwd_filter():
-    lib.fc_backward_filter(_p(x), _p(ws), nb, ctypes.byref(dims), _stream())
+    lib.fc_backward_filter(_p(x), _p(ws), nb, ctypes.byref(dims), REC, _stream())
 
 
 def timeit(fn, reps=20):
