@@ -22,6 +22,25 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __host__ __device__ inline int br_image_row_bytes(const BrGeom& g) { return 8 * g.KP + 32; }      // + 32: transposed reads of 8 rows hit distinct banks
 
+// x~_m = x u^m, u = exp(-i angle(x)) = conj(x) / |x| (1 inside the origin box), for a WAVE-UNIFORM m: closed forms instead of
+// unit vector + powers -- x u = |x|, x u^2 = conj(x), x u^3 = conj(x)^2 / |x|, x conj(u) = x^2 / |x|, x conj(u)^2 = x^3 / |x|^2,
+// x conj(u)^3 = x^4 / |x|^3.
+__device__ __forceinline__ float2 rotated_feature(const float2 x, const int m) {
+    if (m == 0 || is_origin(x)) return x;
+    const float n2 = x.x * x.x + x.y * x.y;
+    if (m == 1) return make_float2(sqrtf(n2), 0.f);
+    if (m == 2) return make_float2(x.x, -x.y);
+    const float rn = __frsqrt_rn(n2);
+    if (m == 3) { const float2 c = make_float2(x.x, -x.y); const float2 c2 = cmul(c, c); return make_float2(c2.x * rn, c2.y * rn); }
+    const float2 x2 = cmul(x, x);
+    if (m == -1) return make_float2(x2.x * rn, x2.y * rn);
+    const float2 x3 = cmul(x2, x);
+    if (m == -2) { const float r2 = rn * rn; return make_float2(x3.x * r2, x3.y * r2); }
+    const float2 x4 = cmul(x2, x2);
+    const float r3 = rn * rn * rn;
+    return make_float2(x4.x * r3, x4.y * r3);
+}
+
 template <int OT>
 __global__ __launch_bounds__(kThreads) void fc_backward_ring_filter_kernel(
     const float2* __restrict__ gx_, const char* __restrict__ hdump, float2* __restrict__ ggwp /* [P][R][F][OT*16][IP] */,
@@ -90,6 +109,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_filter_kernel(
     for (int vt = blockIdx.x; vt < a.nv_total; vt += gridDim.x, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my pieces of this slab (and my prefetched registers) have landed
         __syncthreads();                                               // everyone's have; the previous slab's reads are done
+        const int vn = vt + gridDim.x;
+        if (vn < a.nv_total) dma_slab(vn, buf ^ 1);                    // the next slab streams in under this one's arithmetic
         // ---- second operand of my pair in registers: c + i d = x~ / s_j * t_i, halves
         u32x4 c_hi, c_lo, d_hi, d_lo;
         const float it_scale = pit;
@@ -98,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_filter_kernel(
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const float2 xv = xn[jj];
-                const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));
+                const float2 xt = rotated_feature(xv, m);
                 const float sc = sinv[jj >> 2][jj & 3] * pt;
                 split_halves2(f32x2{xt.x, xt.y}, sc, h[jj], lo8[jj]);
             }
@@ -113,11 +134,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_filter_kernel(
         } else {
             c_hi = u32x4{0u, 0u, 0u, 0u}; c_lo = c_hi; d_hi = c_hi; d_lo = c_hi;
         }
-        const int vn = vt + gridDim.x;
-        if (vn < a.nv_total) {
-            dma_slab(vn, buf ^ 1);
-            if (active) prefetch(vn);
-        }
+        if (vn < a.nv_total && active) prefetch(vn);
         if (active && !(a.dbg & 4)) {
             const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
             const u32x4 nd_hi = d_hi ^ sign, nd_lo = d_lo ^ sign;
@@ -232,12 +249,14 @@ static BrPlan plan_br(const fc_dims* d) {
     return p;
 }
 
-// The ring-major backward path: default two-halves mode, record-driven graphs, meshes of more than one round of 16-vertex
-// tiles (smaller ones keep the frequency-major kernels with their edge split), shapes whose (i tile, frequency) pairs fit
-// the sixteen wavefronts and whose 32-row slab fits the CU's LDS.  FC_BWD_RING=0 keeps the frequency-major kernels,
-// FC_BWD_RING=2 takes the ring-major ones for any mesh size (tests).
+// The ring-major backward path: two-halves mode, record-driven graphs, shapes whose (i tile, frequency) pairs fit the
+// sixteen wavefronts and whose 32-row slab fits the CU's LDS.  OPT-IN (FC_BWD_RING=1: meshes of more than one round of
+// 16-vertex tiles; FC_BWD_RING=2: any mesh size, used by the tests): parity-green on the whole suite, but at config 2 it
+// measures 225 + 98 us against 171 + 72 us for the frequency-major pair (with 128 registers per
+// wavefront only two cotangent rows per wavefront are in flight and the gather waits for L2; one 66 KB slab in flight per
+// CU leaves the filter kernel waiting for HBM latency), so the default stays the frequency-major kernels.
 bool backward_ring_fits(const fc_dims* d) {
-    static const int mode = [] { const char* e = getenv("FC_BWD_RING"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char* e = getenv("FC_BWD_RING"); return e ? atoi(e) : 0; }();
     if (mode == 0 || split_mode() != 2) return false;
     if (!plan_br(d).ok) return false;
     return mode == 2 || (d->N + kTile - 1) / kTile > num_cus();
@@ -264,6 +283,7 @@ static BrArgs make_br_args(const fc_dims* d, const BrPlan& p) {
     a.region_bytes = br_region_bytes(p.g);
     static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+    a.stamps = debug_stamp_buffer();
     return a;
 }
 

@@ -29,6 +29,10 @@ namespace fc {
 
 constexpr int kBrMaxF = 7;
 constexpr int kBrRows = 32;        // source vertices per tile
+// Interleaving the slots of a wavefront's two streams (four source rows in flight instead of two) was measured slower: the
+// second set of per-slot temporaries pushes the kernel from 46 to 115 spilled registers (contraction and conversion phases
+// three times as long).
+constexpr bool kBrInterleave = false;
 constexpr int kBrXPad = 2;         // complex numbers of padding per row of the gxt exchange buffer (bank spread)
 
 // Geometry shared by the packed filter image, the data kernel and the filter-gradient kernel.
@@ -118,13 +122,14 @@ struct BrArgs {
     int xs;                     // complex numbers per row of the gxt exchange buffer: F * IP + kBrXPad
     uint32_t region_bytes;      // LDS bytes of the slab / exchange region
     int dbg;                    // development only (FC_DEBUG_BWD): bit0 skip gather, bit1 skip MFMA, bit3 skip the slab copy
+    unsigned long long* stamps; // development only (fc_debug_stamp_buffer): s_memtime stamps of workgroup 0, [16 waves][256]
 };
 
 struct BrLds {
     char* slab;         // [32][KS halves]; after a tile's last contraction: gxt exchange [32][xs] complex
     float* vinv;        // [32] inverse row scales of the current slab
     float* vsc;         // [32] row scales
-    float* colmag;      // [32][64] |x[j][i]| of the tile
+    uint32_t* cmax;     // [2 slab parities][64] column maxima of |x[j][i]| / s_j (bit patterns of non-negative floats)
     int* runs;          // [16 wavefronts][2 streams][2 tile parities][8]
     float* ring;        // [16 wavefronts][2 streams][nr][256]
 };
@@ -134,15 +139,15 @@ __host__ __device__ inline uint32_t br_region_bytes(const BrGeom& g) {
     return round_up((int)(slab > xch ? slab : xch), 16);
 }
 __host__ __device__ inline size_t br_lds_bytes(const BrGeom& g, int nr) {
-    return (size_t)br_region_bytes(g) + (2 * kBrRows + kBrRows * 64) * 4 + kWaves * 32 * 4 + (size_t)kWaves * 2 * nr * 1024;
+    return (size_t)br_region_bytes(g) + (2 * kBrRows + 2 * 64) * 4 + kWaves * 32 * 4 + (size_t)kWaves * 2 * nr * 1024;
 }
 __device__ __forceinline__ BrLds br_lds(char* smem, const BrArgs& a) {
     BrLds l;
     l.slab = smem;
     l.vinv = reinterpret_cast<float*>(smem + a.region_bytes);
     l.vsc = l.vinv + kBrRows;
-    l.colmag = l.vsc + kBrRows;
-    l.runs = reinterpret_cast<int*>(l.colmag + kBrRows * 64);
+    l.cmax = reinterpret_cast<uint32_t*>(l.vsc + kBrRows);
+    l.runs = reinterpret_cast<int*>(l.cmax + 2 * 64);
     l.ring = reinterpret_cast<float*>(l.runs + kWaves * 32);
     return l;
 }
@@ -171,9 +176,23 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
     for (int idx = tid; idx < (int)(a.region_bytes / 16); idx += kThreads)
         reinterpret_cast<f32x4*>(l.slab)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < kBrRows) { l.vinv[tid] = 0.f; l.vsc[tid] = 1.f; }
+    if (tid < 2 * 64) l.cmax[tid] = 0u;
     __syncthreads();
 
     const int ol = lane < O ? lane : 0;          // lanes >= O gather channel 0; lanes >= KI are never stored
+    Stamper stamp{(a.stamps && blockIdx.x == 0) ? a.stamps + wave * 256 : nullptr, 0};
+    // The SIMDs arbitrate by priority, then age: the younger wavefronts of a workgroup (the later ones) otherwise lose every
+    // arbitration to their older partners and everybody waits for them at the slab barriers
+    {
+        static_assert(kWaves == 16, "priorities below assume four wavefronts per SIMD");
+        const int mode = (a.dbg >> 4) & 3;           // development: 0 = two levels (default), 1 = none, 2 = four levels
+        if (mode == 0 && wave >= 8) __builtin_amdgcn_s_setprio(1);
+        if (mode == 2) {
+            if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+            else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+            else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+        }
+    }
     // my (input-channel tile, frequency) pair of the contraction
     const bool mma_active = wave < g.NMT * F;
     const int it = mma_active ? wave % g.NMT : 0;
@@ -320,7 +339,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
         }
     };
     // ring values c[f] of my stream-j source -> row wave + 16 j of the slab
-    auto flush_row = [&](const f32x2 (&c)[F], const int j) {
+    // xmag: |x[row][lane]| of the stream's source (for the column scales of the filter kernel's second operand); sp: slab parity
+    auto flush_row = [&](const f32x2 (&c)[F], const int j, const float xmag, const int sp) {
         const int row_i = wave + 16 * j;
         float mx = 0.f;
 #pragma unroll
@@ -333,6 +353,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
         // (with 1 it would dominate them whenever the other rows' scales are large, i.e. the cotangent is small)
         if (mx == 0.f) inv = 0.f;
         if (lane == 0) { l.vinv[row_i] = inv; l.vsc[row_i] = scale; }
+        // a bound of the modulus of x~[j][i] / s_j is |x[j][i]| / s_j: its column maximum over the tile's rows (non-negative
+        // floats order like their bit patterns; a maximum does not depend on the order of the updates)
+        if (lane < g.IP) atomicMax(l.cmax + sp * 64 + lane, __float_as_uint(xmag * inv));
         if (lane < g.KI) {
             lds_u32* const row = (lds_u32*)l.slab + row_i * (KS / 2);
             int o0 = split_pair_offset(lane, 2);
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
         }
     };
     // after the slab barrier: copy the slab (as it lies in LDS, without the row pads) and its scales to the workspace
-    auto keep_slab = [&](const int vt, const int rq) {
+    auto keep_slab = [&](const int vt, const int rq, const int sp) {
         char* const dst = hdump + ((size_t)vt * R + rq) * a.hs_bytes;
         if (!(a.dbg & 8)) {
             // wavefront w copies rows w and w + 16: 8*KP bytes each, 16 bytes per lane and instruction
@@ -364,28 +387,38 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
             }
         }
         if (wave == kWaves - 1) {
-            // row scales, and the power-of-two column scales of the filter kernel's second operand x~[j][i] / s_j:
-            // a bound of its modulus is |x[j][i]| / s_j
+            // row scales, and the power-of-two column scales of the filter kernel's second operand x~[j][i] / s_j
             float* const tail = reinterpret_cast<float*>(dst + (size_t)kBrRows * 8 * g.KP);
             if (lane < kBrRows) { tail[lane] = l.vsc[lane]; tail[kBrRows + lane] = l.vinv[lane]; }
             if (lane < g.IP) {
-                float cm = 0.f;
-                if (lane < I)
-                    for (int v = 0; v < kBrRows; ++v) cm = fmaxf(cm, l.colmag[v * 64 + lane] * l.vinv[v]);
+                const float cm = __uint_as_float(l.cmax[sp * 64 + lane]);
                 float t, inv_t;
                 split_scale(cm * 1.0000002f, t, inv_t);
                 tail[2 * kBrRows + lane] = t;
                 tail[2 * kBrRows + g.IP + lane] = inv_t;
+                l.cmax[(sp ^ 1) * 64 + lane] = 0u;          // for the next slab (its updates come behind this slab's second barrier)
             }
         }
     };
 
+    stamp.realtime(29);
+    stamp(28);
     for (int vt = first_tile_of_block(); vt < a.nv_total; vt += gridDim.x) {
         const bool half = vt >= a.nv_full;
+        stamp(10);
         int nbeg[2], nend[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) slot_range(vt + gridDim.x, j, par ^ 1, nbeg[j], nend[j]);
 
+        // |x| of my two sources' rows, lane = input channel (used at every flush)
+        float xmag[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int vtx = br_vertex(vt, wave + 16 * j, a.nv_full, a.N);
+            float2 xv = make_float2(0.f, 0.f);
+            if (vtx < a.N && lane < I) xv = gx_[(size_t)vtx * I + lane];
+            xmag[j] = sqrtf(xv.x * xv.x + xv.y * xv.y);
+        }
         f32x2 clo[2][F], chi[2][F];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -393,58 +426,86 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
             for (int f = 0; f < F; ++f) { clo[j][f] = f32x2{0.f, 0.f}; chi[j][f] = clo[j][f]; }
         float2 gq[2][2] = {{px[0][0], px[0][1]}, {px[1][0], px[1][1]}};
 
-        // one run of one stream: lo += w0 z, hi += w1 z with z_f = gy conj(ph_f) over the slots [s, run_end)
-        auto gather_run = [&](const int j, int s, const int run_end, f32x2 (&lo)[F], f32x2 (&hi)[F], float2& ga, float2& gb) {
-            const float* const ring = ring_of(j);
-            const int nslots = end[j] - beg[j];
+        // one slot of stream J: lo += w0 z, hi += w1 z with z_f = gy conj(ph_f)
+        auto slot = [&](auto jc, const int s_, float2& gcur) {
+            constexpr int J = decltype(jc)::value;
+            const float* const ring = ring_of(J);
+            const int nslots = end[J] - beg[J];
             const int nch = (nslots + CR - 1) >> LOG_CR;
-            auto slot = [&](const int s_, float2& gcur) {
-                if ((s_ & (CR - 1)) == 0 && s_ > 0) {
-                    const int ch = s_ >> LOG_CR;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ch - 1 + nr < nch) dma_chunk(j, beg[j], ch - 1 + nr);
-                }
-                if (nr == 2 && ((s_ + 2) & (CR - 1)) < 1)       // the look-ahead below enters a chunk issued at the last chunk entry
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const float* rp = rec_ptr(ring, s_);
-                const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
-                const int d2 = __float_as_int(rec_ptr(ring, min(s_ + 2, nslots - 1))[3]);
-                const f32x2 gv = f32x2{gcur.x, gcur.y};
-                gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
-                const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
-                f32x2 ph[F], z[F];
+            if ((s_ & (CR - 1)) == 0 && s_ > 0) {
+                const int ch = s_ >> LOG_CR;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (ch - 1 + nr < nch) dma_chunk(J, beg[J], ch - 1 + nr);
+            }
+            if (nr == 2 && ((s_ + 2) & (CR - 1)) < 1)       // the look-ahead below enters a chunk issued at the last chunk entry
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float* rp = rec_ptr(ring, s_);
+            const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+            const int d2 = __float_as_int(rec_ptr(ring, min(s_ + 2, nslots - 1))[3]);
+            const f32x2 gv = f32x2{gcur.x, gcur.y};
+            gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
+            const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
+            f32x2 ph[F], z[F];
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    ph[f] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
-                    z[f] = cmul_conj_pk_step1(gv, ph[f]);
-                }
+            for (int f = 0; f < F; ++f) {
+                ph[f] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
+                z[f] = cmul_conj_pk_step1(gv, ph[f]);
+            }
 #pragma unroll
-                for (int f = 0; f < F; ++f) z[f] = cmul_conj_pk_step2(gv, ph[f], z[f]);
+            for (int f = 0; f < F; ++f) z[f] = cmul_conj_pk_step2(gv, ph[f], z[f]);
 #pragma unroll
-                for (int f = 0; f < F; ++f) lo[f] = __builtin_elementwise_fma(w0v, z[f], lo[f]);
+            for (int f = 0; f < F; ++f) clo[J][f] = __builtin_elementwise_fma(w0v, z[f], clo[J][f]);
 #pragma unroll
-                for (int f = 0; f < F; ++f) hi[f] = __builtin_elementwise_fma(w1v, z[f], hi[f]);
-            };
+            for (int f = 0; f < F; ++f) chi[J][f] = __builtin_elementwise_fma(w1v, z[f], chi[J][f]);
+        };
+        // the rest of one stream's run
+        auto gather_rest = [&](auto jc, int s, const int run_end) {
+            constexpr int J = decltype(jc)::value;
             for (; s + 1 < run_end; s += 2) {
-                slot(s, ga);
-                slot(s + 1, gb);
+                slot(jc, s, gq[J][0]);
+                slot(jc, s + 1, gq[J][1]);
             }
-            if (s < run_end) {
-                slot(s, ga);
-                const float2 t = ga; ga = gb; gb = t;
+            if (s < run_end) {      // odd tail: rotate the two prefetch registers
+                slot(jc, s, gq[J][0]);
+                const float2 t = gq[J][0]; gq[J][0] = gq[J][1]; gq[J][1] = t;
             }
+        };
+        // ring run q of BOTH streams, their slots interleaved: four source rows in flight per wavefront instead of two (the
+        // gather waits for L2, not for the vector pipes)
+        auto gather_runs = [&](int s0, const int e0, int s1, const int e1) {
+            constexpr std::integral_constant<int, 0> j0{};
+            constexpr std::integral_constant<int, 1> j1{};
+            for (; s0 + 1 < e0 && s1 + 1 < e1; s0 += 2, s1 += 2) {
+                slot(j0, s0, gq[0][0]);
+                __builtin_amdgcn_sched_barrier(0);       // (keeps the slots' temporaries from overlapping: 128 registers)
+                slot(j1, s1, gq[1][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(j0, s0 + 1, gq[0][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(j1, s1 + 1, gq[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gather_rest(j0, s0, e0);
+            gather_rest(j1, s1, e1);
         };
 
         for (int q = 0; q < R - 1; ++q) {
             if (!(a.dbg & 1)) {
+                int rs[2], re[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int* lro = l.runs + (wave * 2 + j) * 16 + par * 8;
-                    const int s = __builtin_amdgcn_readfirstlane(lro[q]);
-                    const int run_end = (q + 1 < R - 1) ? __builtin_amdgcn_readfirstlane(lro[q + 1]) : end[j] - beg[j];
-                    gather_run(j, s, run_end, clo[j], chi[j], gq[j][0], gq[j][1]);
+                    rs[j] = __builtin_amdgcn_readfirstlane(lro[q]);
+                    re[j] = (q + 1 < R - 1) ? __builtin_amdgcn_readfirstlane(lro[q + 1]) : end[j] - beg[j];
+                }
+                if constexpr (kBrInterleave) {
+                    gather_runs(rs[0], re[0], rs[1], re[1]);
+                } else {
+                    gather_rest(std::integral_constant<int, 0>{}, rs[0], re[0]);
+                    gather_rest(std::integral_constant<int, 1>{}, rs[1], re[1]);
                 }
             }
+            stamp(0);
             if (q == R - 2) {
                 // my sources are done: start streaming the first record chunks of my next tile's sources
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -454,28 +515,25 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
                     for (int ch = 0; ch < min(nnch, nr); ++ch) dma_chunk(j, nbeg[j], ch);
                 }
             }
-            flush_row(clo[0], 0);
-            if (!half) flush_row(clo[1], 1);
+            flush_row(clo[0], 0, xmag[0], q & 1);
+            if (!half) flush_row(clo[1], 1, xmag[1], q & 1);
             prefetch_w(q);                                   // ring q's filter fragments fly during the barrier and the slab copy
-            if (q == 0) {
-                // |x[j][i]| of the tile, for the column scales kept with every slab
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const float2 xv = load_entry(vt, n);
-                    if (e_id[n] >= 0) l.colmag[(e_id[n] >> 8) * 64 + (e_id[n] & 255)] = sqrtf(xv.x * xv.x + xv.y * xv.y);
-                }
-            }
+            stamp(1);
             __syncthreads();
-            keep_slab(vt, q);
+            stamp(2);
+            keep_slab(vt, q, q & 1);
+            stamp(7);
             contract(q, half);
+            stamp(3);
             __syncthreads();
+            stamp(4);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int f = 0; f < F; ++f) { clo[j][f] = chi[j][f]; chi[j][f] = f32x2{0.f, 0.f}; }
         }
-        flush_row(clo[0], 0);
-        if (!half) flush_row(clo[1], 1);
+        flush_row(clo[0], 0, xmag[0], (R - 1) & 1);
+        if (!half) flush_row(clo[1], 1, xmag[1], (R - 1) & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the next tile's first record chunks have landed)
         prefetch_w(R - 1);
         __syncthreads();
@@ -485,9 +543,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
             end[j] = nend[j];
             first_rows(j, end[j] - beg[j], px[j][0], px[j][1]);
         }
-        keep_slab(vt, R - 1);
+        stamp(2);
+        keep_slab(vt, R - 1, (R - 1) & 1);
+        stamp(7);
         contract(R - 1, half);
+        stamp(3);
         __syncthreads();                                     // every read of the slab is done: the region becomes the exchange buffer
+        stamp(4);
         float2 exl[2];                                       // my entries of x (issued here, used behind the next barrier)
 #pragma unroll
         for (int n = 0; n < 2; ++n) exl[n] = load_entry(vt, n);
@@ -504,6 +566,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
             }
         }
         __syncthreads();
+        stamp(5);
+        if (tid < 2 * 64) l.cmax[tid] = 0u;                  // (both parities, for the next tile: R may be odd; ordered by the barrier below)
         // gx[j,i] = sum_f gxt_f conj(u^m) + [x != 0] (i x / |x|^2) sum_f m Im(conj(gxt_f) x u^m),  m = f - B,  u = exp(-i angle(x))
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -540,7 +604,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
                 if (vtx < a.N) ggx[(size_t)vtx * I + e_i] = acc;
             }
         }
+        stamp(6);
         __syncthreads();                                     // the exchange buffer is consumed
+        stamp(8);
         {
             // the region is a slab again: zero what the gathers never write -- the k padding of every row, and for a half
             // tile to come the rows 16..31 (their inverse scales are 0)
@@ -557,10 +623,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_ring_data_kernel(
                 if (tid >= 16 && tid < 32) { l.vinv[tid] = 0.f; l.vsc[tid] = 1.f; }
             }
         }
+        stamp(9);
         par ^= 1;
         // (no barrier here: the next tile's flushes write k < F*KI of rows that are not being zeroed, and the first read of
         //  the zeroed bytes is behind the next slab barrier)
     }
+    stamp(30);
+    stamp.realtime(31);
 }
 
 }  // namespace fc

@@ -79,27 +79,6 @@ __device__ __forceinline__ RingLds ring_lds(char* smem, const MmaGeom& g) {
     return l;
 }
 
-// In-kernel time stamps (development): lane 0 of every wavefront of workgroup 0 appends (label << 56 | s_memtime).
-struct Stamper {
-    unsigned long long* p;      // wave-uniform: this wavefront's 256 slots, or nullptr
-    int n;
-    __device__ __forceinline__ void operator()(int label) {
-        if (p) {
-            if (n < 256 && (threadIdx.x & 63) == 0)
-                p[n] = ((unsigned long long)label << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull);
-            ++n;
-        }
-    }
-    // constant 100 MHz clock: with the shader-cycle stamps around it, the clock the launch actually ran at
-    __device__ __forceinline__ void realtime(int label) {
-        if (p) {
-            if (n < 256 && (threadIdx.x & 63) == 0)
-                p[n] = ((unsigned long long)label << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull);
-            ++n;
-        }
-    }
-};
-
 template <int R, int B, bool GEO>
 __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ grec, const int32_t* __restrict__ growptr,

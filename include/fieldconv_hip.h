@@ -85,8 +85,8 @@ int fc_supported(const fc_dims* dims);
  * the same `records`.  wpk_bwd may be NULL: only the forward image is written. */
 /* `records` for every call below that takes one: 0 for the dense-stencil entry points; for the record-driven ones the value
  * fc_records_flags(dims, 1) returns for the dims of the BACKWARD launch (the whole mesh): 1, or 3 when that launch takes the
- * ring-major backward kernels (csrc/fc_backward_ring.hpp: default mode, meshes of more than 256 tiles of 16 vertices, shapes
- * whose (input-channel tile, frequency) pairs fit sixteen wavefronts) -- bit 1 selects their backward image
+ * ring-major backward kernels (csrc/fc_backward_ring.hpp; opt-in with FC_BWD_RING=1 / 2 in the environment, otherwise
+ * fc_records_flags never sets the bit) -- bit 1 selects their backward image
  *   IP inverse row scales, then R x {re_hi, re_lo, im_hi, im_lo} x BT blocks x IP x 32 halves, conjugated, k = f*ceil8(O) + o,
  * their workspace layout and their kernels in fc_backward_workspace_bytes / _data_factored / _filter / _finish / _all.
  * Either image pointer of the packing calls may be NULL (not both): only the other image is written. */

@@ -320,13 +320,20 @@ def correspondence_net_case(out):
         return x, logits, loss, params, grads
 
     x, logits, loss, params, grads = run(mods, pos, supp_edges, supp_sten, ln, wxp)
-    # Conditioning: the same float32 run with the input positions perturbed by a few ulp (relative 3e-7).  modReLU, angle()
+    # Conditioning: the same float32 run with the input positions perturbed by a few ulp (relative 3e-7), eight times over
+    # (the amplification is heavy-tailed: one cell flip of an ECHO vote or none); kept: the largest deviation per tensor.  modReLU, angle()
     # and the ECHO rasterisation (bilinear votes into integer cells) amplify rounding, so a float32 implementation that
     # rounds differently -- ours -- cannot be closer to this capture than the capture is to its own perturbed twin; the
     # per-tensor deviations are kept as the yardstick of the GPU test's gates.
-    gp = torch.Generator().manual_seed(99)
-    pos_p = pos * (1 + 3e-7 * (2 * torch.rand(pos.shape, generator=gp) - 1))
-    x_p, logits_p, loss_p, _, grads_p = run(mods, pos_p, supp_edges, supp_sten, ln, wxp)
+    n_twins = 8
+    rel = lambda a, b: float((a.detach() - b.detach()).abs().max() / b.detach().abs().max())
+    cond_x, cond_logits, gcond = 0.0, 0.0, [0.0] * len(grads)
+    for twin in range(n_twins):
+        gp = torch.Generator().manual_seed(99 + twin)
+        pos_p = pos * (1 + 3e-7 * (2 * torch.rand(pos.shape, generator=gp) - 1))
+        x_p, logits_p, _, _, grads_p = run(mods, pos_p, supp_edges, supp_sten, ln, wxp)
+        cond_x, cond_logits = max(cond_x, rel(x_p, x)), max(cond_logits, rel(logits_p, logits))
+        gcond = [max(c0, rel(gpv, gval)) for c0, gpv, gval in zip(gcond, grads_p, grads)]
     # the convolutional trunk again in float64 (same parameter values; the reference's FCPrecomp and ECHO are float32-only,
     # so the stencil is cast and the run stops in front of the ECHOBlock): how far the reference's own fp32 rounding
     # carries through the 8 blocks -- the GPU test's gate for the trunk output is a small multiple of it
@@ -338,14 +345,14 @@ def correspondence_net_case(out):
     # probes of the parameter fill: the test's fill must reproduce the generator's bit for bit
     rec['pfill_probe'] = np.concatenate([np_(params[n]).reshape(-1)[:: max(1, params[n].numel() // 64)][:64]
                                           for n in ('resnet2.conv1.spherical', 'res3.lin.Im', 'lin2.weight')])
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    rec['cond_x_last'] = rel(x_p, x)
-    rec['cond_logits'] = rel(logits_p, logits)
-    for (name, _), gval, gpv in zip(params.items(), grads, grads_p):
+    rec['cond_x_last'] = cond_x
+    rec['cond_logits'] = cond_logits
+    rec['n_twins'] = n_twins
+    for (name, _), gval, gcv in zip(params.items(), grads, gcond):
         sub, stats = grad_sample(np_(gval))
         rec['g_' + name] = sub
         rec['gstat_' + name] = stats
-        rec['gcond_' + name] = rel(gpv, gval)
+        rec['gcond_' + name] = gcv
     out['correspondence_net'] = rec
 
 

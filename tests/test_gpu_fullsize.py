@@ -98,6 +98,27 @@ def test_multi_tile_workgroups_whole_tensors(shape, dev, monkeypatch):
         assert rel_err(H(gW), gW_ref) < TOL, name
 
 
+@pytest.mark.parametrize('scale', [1e-5, 1.0, 1e4])
+def test_small_cotangent_and_sources_without_edges(scale, dev):
+    """Filter gradient with a cotangent of any magnitude on a mesh where every tenth vertex has no out-edges.  The split-halves
+    filter-gradient kernels scale their second operand x~[j][i] / s_j by the column maximum over a tile; a source row whose H
+    is all zero used to enter that maximum with scale 1 and -- when the other rows' scales are large, i.e. the cotangent is
+    small -- pushed them into the half-precision denormals (round 3: 4e-3 instead of 4e-7 on the segmentation-net step,
+    where the cotangents are 1e-4).  Such rows now carry the inverse scale 0."""
+    from fieldconv_amd.graph import SupportGraph
+    N, k, I, O, B, R = 1500, 10, 24, 16, 2, 6
+    edges, sten, x, gy, W = precomp_case(N, k, I, O, B, R, seed=77)
+    keep = (edges[:, 0] % 10) != 3                       # vertices 3, 13, 23, ... are sources of nothing
+    edges, sten = edges[keep].contiguous(), sten[keep].contiguous()
+    gy = gy * scale
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    assert graph.factored or os.environ.get('FIELDCONV_DENSE', '0') == '1'
+    y, gx, gW = run_conv(graph, x, W, gy, dev)
+    assert rel_err(H(gx), gx_ref) < TOL
+    assert rel_err(H(gW), gW_ref) < TOL
+
+
 def test_config2_record_kernels_vs_oracle_rows_and_dense(dev, monkeypatch):
     """BASELINE configs[1] on the benchmark's own mesh (sphere, k = 32, 95-percentile support radius, FCPrecomp
     stencil): the geometric and the generic factored kernels, ~5 tiles per workgroup."""

@@ -18,6 +18,10 @@ LABELS_FWD = {0: 'run gathered (2 targets)', 1: 'rows converted', 2: 'barrier: s
               5: 'last slab contracted, partials stored', 6: 'y stored', 10: 'tile start'}
 
 
+LABELS_BWD = {10: 'tile start', 0: 'run gathered', 1: 'rows converted', 2: 'barrier: slab full', 7: 'slab copied', 3: 'contracted',
+              4: 'barrier: slab free', 5: 'gxt exchanged', 6: 'gx stored', 8: 'barrier: x-buf free', 9: 'padding zeroed'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('which', nargs='?', default='fwd')
@@ -46,16 +50,19 @@ def main():
     torch.cuda.synchronize()
     buf = torch.zeros(16 * 256, dtype=torch.int64, device=dev)
     lib = _lib.load()
-    lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     if args.which == 'fwd':
+        lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
         with torch.no_grad():
             conv(x, edges, sten)
     else:
-        step()
+        y = conv(x, edges, sten)
+        torch.cuda.synchronize()
+        lib.fc_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))      # (armed after the forward pass: only the backward kernels stamp)
+        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
     torch.cuda.synchronize()
     lib.fc_debug_stamp_buffer(None)
     st = buf.cpu().view(16, 256)
-    labels = LABELS_FWD
+    labels = LABELS_FWD if args.which == 'fwd' else LABELS_BWD
     t0 = min([int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0])] or [0])
     # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
     import collections
