@@ -59,6 +59,7 @@ SIGNATURES = {
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
+    'fc_backward_finish_params': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _FP, _vp]),
     'fc_backward_all': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _FP, _vp, _sz, _DP, _vp]),
     'fc_forward_params': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _FP, _vp, _vp, _vp, _vp, _sz, _DP, _c_int32, _EP, _vp]),
     'fc_echo_hist_dim': (ctypes.c_int, [_c_int32]),

@@ -1,4 +1,5 @@
 // extern "C" surface of libfieldconv_hip.so; see include/fieldconv_hip.h for the contract.
+#include <stdlib.h>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
 #include "fc_tile.hpp"
@@ -181,6 +182,25 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
+int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
+                              const fc_filter_params* params, void* stream) {
+    if (!gw_eff || !params || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    // the partials' fixed-order sum and the parameter-gradient chain in ONE launch (FC_SPLIT_FINISH=1: the two kernels)
+    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
+    if (params->ftype < 0 || params->ftype > 2 || !params->zonal || !params->spherical || !params->g_zonal || !params->g_spherical ||
+        (params->ftype == 1 && (!params->phase || !params->g_phase)))
+        return FC_ERR_BAD_ARGUMENT;
+    if (split_finish) {
+        const int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
+        if (rc != FC_OK) return rc;
+        return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
+                                     params->g_spherical, params->g_phase, dims, stream);
+    }
+    return (records & 2) ? fc::backward_ring_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream))
+                         : fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream));
+}
+
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream) {
@@ -190,10 +210,8 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     if (rc != FC_OK) return rc;
     rc = fc_backward_filter(x, workspace, workspace_bytes, dims, records, stream);
     if (rc != FC_OK) return rc;
-    rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
-    if (rc != FC_OK || !params) return rc;
-    return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
-                                 params->g_spherical, params->g_phase, dims, stream);
+    if (!params) return fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
+    return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
 }
 
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,

@@ -352,4 +352,17 @@ int backward_ring_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
+int backward_ring_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp,
+                                     hipStream_t stream) {
+    const BrPlan p = plan_br(d);
+    if (!p.ok) return FC_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
+    const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes);
+    const int F = 2 * d->B + 1;
+    const size_t OP = (size_t)p.g.OT * 16, IP = (size_t)p.g.IP;
+    // partial (p, r, f, o, i) at (((p*R + r)*F + f)*OP + o)*IP + i
+    return reduce_param_grads_impl(gwp, (size_t)d->R * F * OP * IP, (size_t)F * OP * IP, OP * IP, IP, p.P, gw_eff, fp->zonal, fp->spherical,
+                                   fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream);
+}
+
 }  // namespace fc

@@ -246,6 +246,49 @@ int split_mode() {
 constexpr int kGradPairs = 32;      // (o,i) pairs per workgroup; blockDim = kGradPairs * R
 constexpr int kMaxB = 3;
 
+// Parameter gradients of ring r of the pair (o, i) from g = gW_eff[o,i,r,:] (F complex numbers, global or LDS); the phase
+// gradient's per-ring pieces go to gph_row[0..B] (summed over the rings by the caller).
+__device__ __forceinline__ void param_grads_entry(const float2* g, const float* __restrict__ zonal, const float* __restrict__ sph,
+                                                  const float* __restrict__ phase, int ftype, float* __restrict__ g_zonal,
+                                                  float* __restrict__ g_sph, float* gph_row, int I, int R, int B, int o, int i, int r) {
+    const size_t oi = (size_t)o * I + i;
+    const size_t oir = oi * R + r;
+    if (ftype == 2) {
+        g_zonal[oir * 2] = g[B].x;
+        g_zonal[oir * 2 + 1] = g[B].y;
+        for (int b = 0; b < 2 * B; ++b) {
+            const float2 v = g[b < B ? b : b + 1];
+            g_sph[(oir * (2 * B) + b) * 2] = v.x;
+            g_sph[(oir * (2 * B) + b) * 2 + 1] = v.y;
+        }
+        return;
+    }
+    // coefficient gradient g_coeff = gW conj(P); phase gradient pieces Im(conj(P) gP), gP = gW conj(coeff)
+    for (int q = 0; q <= B; ++q) {
+        float s = 0.f, co = 1.f;
+        if (ftype == 1) sincosf(phase[oi * (B + 1) + q], &s, &co);
+        const float2 P = make_float2(co, s);
+        const float2 gp = g[B + q];
+        const float2 cp = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B + q);     // without the phase
+        float2 gP = cmul_conj(gp, cp);
+        const float2 gcp = cmul_conj(gp, P);
+        float acc = P.x * gP.y - P.y * gP.x;
+        if (q == 0) {
+            g_zonal[oir] = gcp.x;
+        } else {
+            const float2 gm = g[B - q];
+            const float2 cm = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B - q);
+            gP = cmul_conj(gm, cm);
+            const float2 gcm = cmul_conj(gm, P);
+            acc += P.x * gP.y - P.y * gP.x;
+            // f = B+q reads sph[q-1] directly, f = B-q its conjugate
+            g_sph[(oir * B + (q - 1)) * 2] = gcp.x + gcm.x;
+            g_sph[(oir * B + (q - 1)) * 2 + 1] = gcp.y - gcm.y;
+        }
+        gph_row[q] = acc;
+    }
+}
+
 __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, const float* __restrict__ zonal,
                                              const float* __restrict__ sph, const float* __restrict__ phase, int ftype,
                                              float* __restrict__ g_zonal, float* __restrict__ g_sph,
@@ -256,44 +299,9 @@ __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, cons
     const bool valid = oi < O * I;
     const int F = 2 * B + 1;
     const int o = oi / I, i = oi - o * I;
-    const size_t oir = (size_t)oi * R + r;
-    if (valid) {
-        const float2* g = gw + oir * F;
-        if (ftype == 2) {
-            g_zonal[oir * 2] = g[B].x;
-            g_zonal[oir * 2 + 1] = g[B].y;
-            for (int b = 0; b < 2 * B; ++b) {
-                const float2 v = g[b < B ? b : b + 1];
-                g_sph[(oir * (2 * B) + b) * 2] = v.x;
-                g_sph[(oir * (2 * B) + b) * 2 + 1] = v.y;
-            }
-        } else {
-            // coefficient gradient g_coeff = gW conj(P); phase gradient pieces Im(conj(P) gP), gP = gW conj(coeff)
-            for (int q = 0; q <= B; ++q) {
-                float s = 0.f, co = 1.f;
-                if (ftype == 1) sincosf(phase[(size_t)oi * (B + 1) + q], &s, &co);
-                const float2 P = make_float2(co, s);
-                const float2 gp = g[B + q];
-                const float2 cp = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B + q);     // without the phase
-                float2 gP = cmul_conj(gp, cp);
-                const float2 gcp = cmul_conj(gp, P);
-                float acc = P.x * gP.y - P.y * gP.x;
-                if (q == 0) {
-                    g_zonal[oir] = gcp.x;
-                } else {
-                    const float2 gm = g[B - q];
-                    const float2 cm = filter_entry(zonal, sph, phase, 0, B, R, I, o, i, r, B - q);
-                    gP = cmul_conj(gm, cm);
-                    const float2 gcm = cmul_conj(gm, P);
-                    acc += P.x * gP.y - P.y * gP.x;
-                    // f = B+q reads sph[q-1] directly, f = B-q its conjugate
-                    g_sph[(oir * B + (q - 1)) * 2] = gcp.x + gcm.x;
-                    g_sph[(oir * B + (q - 1)) * 2 + 1] = gcp.y - gcm.y;
-                }
-                gph[(pair * 8 + r) * (kMaxB + 1) + q] = acc;
-            }
-        }
-    }
+    if (valid)
+        param_grads_entry(gw + ((size_t)oi * R + r) * F, zonal, sph, phase, ftype, g_zonal, g_sph, gph + (pair * 8 + r) * (kMaxB + 1), I, R, B,
+                          o, i, r);
     __syncthreads();
     if (valid && ftype == 1 && r == 0) {
         for (int q = 0; q <= B; ++q) {
@@ -302,6 +310,91 @@ __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, cons
             g_phase[(size_t)oi * (B + 1) + q] = acc;
         }
     }
+}
+
+// The fixed-order sum of the filter-gradient kernels' per-workgroup partials AND the parameter-gradient chain in one launch
+// (fewer and fatter small kernels).  Workgroup = (output channel o, 16 input channels): every thread sums
+// the P partials of its (i, r, f) entries -- partial (p, r, f, o, i) lies at gwp[p*sp + r*sr + f*sf + o*so + i], which covers
+// the layouts of both filter-gradient kernel families -- writes gW_eff (when asked for) and leaves it in LDS, from where the
+// workgroup's (pair, ring) threads pull it back to (zonal, spherical, phase) exactly as fc_filter_param_grads_kernel does.
+constexpr int kRpPairs = 16;
+constexpr int kRpThreads = 1024;
+constexpr int kRpGroups = 4;           // an entry's P partials are summed in four consecutive groups, by four threads
+constexpr int kRpMaxPer = 16;          // partials per group held in flight
+struct RpStrides { size_t sp, sr, sf, so; };
+
+__global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
+    const float2* __restrict__ gwp, const RpStrides st, const int P, float2* __restrict__ gw_out, const float* __restrict__ zonal,
+    const float* __restrict__ sph, const float* __restrict__ phase, const int ftype, float* __restrict__ g_zonal,
+    float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B) {
+    __shared__ float2 part[kRpGroups][kRpPairs * 8 * 7];     // [group][(r*F + f)*16 + pair]
+    __shared__ float2 gws[kRpPairs * 8 * 7];                 // [pair][r][f]
+    __shared__ float gph[kRpPairs * 8 * (kMaxB + 1)];        // [pair][r][q]
+    const int F = 2 * B + 1;
+    const int nit = (I + kRpPairs - 1) / kRpPairs;
+    const int o = blockIdx.x / nit, i0 = (blockIdx.x - o * nit) * kRpPairs;
+    const int nent = kRpPairs * R * F;
+    const int per = (P + kRpGroups - 1) / kRpGroups;         // partials per group
+    // every (entry, group) pair sums its partials in order, all loads in flight at once (the sum of 51 partials is latency:
+    // two rounds of loads here instead of seven)
+    for (int idx = threadIdx.x; idx < nent * kRpGroups; idx += kRpThreads) {
+        const int grp = idx / nent, e = idx - grp * nent;
+        const int pi = e % kRpPairs, rf = e / kRpPairs;
+        const int f = rf % F, r = rf / F;
+        const int i = i0 + pi;
+        float2 s = make_float2(0.f, 0.f);
+        if (i < I) {
+            const float2* src = gwp + (size_t)r * st.sr + (size_t)f * st.sf + (size_t)o * st.so + i;
+            const int pend = min((grp + 1) * per, P);
+            for (int p0 = grp * per; p0 < pend; p0 += kRpMaxPer) {
+                float2 v[kRpMaxPer];
+#pragma unroll
+                for (int u = 0; u < kRpMaxPer; ++u) v[u] = (p0 + u < pend) ? src[(size_t)(p0 + u) * st.sp] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < kRpMaxPer; ++u) { s.x += v[u].x; s.y += v[u].y; }
+            }
+        }
+        part[grp][e] = s;
+    }
+    __syncthreads();
+    const float sc = 1.f / (float)F;
+    for (int e = threadIdx.x; e < nent; e += kRpThreads) {
+        const int pi = e % kRpPairs, rf = e / kRpPairs;
+        const int f = rf % F, r = rf / F;
+        float2 s = part[0][e];
+#pragma unroll
+        for (int grp = 1; grp < kRpGroups; ++grp) { s.x += part[grp][e].x; s.y += part[grp][e].y; }      // fixed order
+        s.x *= sc;
+        s.y *= sc;
+        if (gw_out && i0 + pi < I) gw_out[(((size_t)o * I + i0 + pi) * R + r) * F + f] = s;
+        gws[(pi * 8 + r) * 7 + f] = s;
+    }
+    __syncthreads();
+    const int pair = threadIdx.x / R, r = threadIdx.x - pair * R;
+    const bool valid = pair < kRpPairs && i0 + pair < I;
+    if (valid)
+        param_grads_entry(gws + (pair * 8 + r) * 7, zonal, sph, phase, ftype, g_zonal, g_sph, gph + (pair * 8 + r) * (kMaxB + 1), I, R, B, o,
+                          i0 + pair, r);
+    __syncthreads();
+    if (valid && ftype == 1 && r == 0) {
+        for (int q = 0; q <= B; ++q) {
+            float acc = 0.f;
+            for (int rr = 0; rr < R; ++rr) acc += gph[(pair * 8 + rr) * (kMaxB + 1) + q];
+            g_phase[((size_t)o * I + i0 + pair) * (B + 1) + q] = acc;
+        }
+    }
+}
+
+// gwp: the partials, P of them, entry (p, r, f, o, i) at gwp[p*sp + r*sr + f*sf + o*so + i]
+int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
+                            const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
+                            const fc_dims* d, hipStream_t stream) {
+    if (d->R > 8 || d->B > kMaxB || kRpPairs * d->R > kRpThreads) return FC_ERR_UNSUPPORTED;
+    const int nit = (d->I + kRpPairs - 1) / kRpPairs;
+    const RpStrides st{sp, sr, sf, so};
+    hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(d->O * nit), dim3(kRpThreads), 0, stream, reinterpret_cast<const float2*>(gwp), st,
+                       P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I, d->R, d->B);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,

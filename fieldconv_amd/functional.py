@@ -328,10 +328,10 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
         graph.on_gx(gx)                 # now, under the filter-gradient kernel
     with _timed('fc_backward_filter'):
         check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_filter')
-    check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_finish')
-    if fp is not None:
-        check(lib.fc_filter_param_grads(_p(gw), _p(zonal), _p(spherical), _p(phase), ftype, _p(g_z), _p(g_s),
-                                        _p(g_p) if g_p is not None else None, plan.dref, st), 'fc_filter_param_grads')
+    if fp is not None:      # partial sums + parameter gradients in one launch
+        check(lib.fc_backward_finish_params(_p(gw), wsp, nbytes, plan.dref, plan.records, ctypes.byref(fp), st), 'fc_backward_finish_params')
+    else:
+        check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_finish')
     return gx, gw, pgrads
 
 

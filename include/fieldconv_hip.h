@@ -195,6 +195,12 @@ int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream);
+/* fc_backward_finish + fc_filter_param_grads in ONE launch: every workgroup sums the partials of its
+ * (output channel, 16 input channels) block in the fixed order, writes gw_eff and pulls the block back to the parameters.
+ * The partials are summed in four consecutive groups whose sums are then added in order: deterministic, but rounded
+ * differently from fc_backward_finish's single chain.  fc_backward_all uses it when it is given params. */
+int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
+                              const fc_filter_params* params, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */

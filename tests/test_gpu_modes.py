@@ -32,6 +32,7 @@ MODES = {
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
     'ring_major_backward': {'FC_BWD_RING': '2'},         # the opt-in ring-major backward kernels (32-vertex tiles, DMA-fed filter kernel)
+    'separate_finish_kernels': {'FC_SPLIT_FINISH': '1'},   # fc_backward_finish + fc_filter_param_grads instead of the fused launch
     'one_call_per_kernel': {'FIELDCONV_SEPARATE_CALLS': '1'},   # the per-kernel entry points instead of fc_forward_params / fc_backward_all
 }
 
