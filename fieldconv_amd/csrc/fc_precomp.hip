@@ -15,8 +15,7 @@
 namespace fc {
 
 constexpr int kPrecompEdges = 128;          // edges per workgroup of the stencil kernel
-constexpr int kPrecompMaxR = 8;
-constexpr int kPrecompMaxF = 7;
+constexpr int kPrecompMaxRF = 156;        // n_rings * (2 band_limit + 1) of the literal stencil builder: its rows live in LDS
 
 // keep[e] = 1 for the edges inside the support radius; *bad_index is set when a kept edge refers to a vertex outside
 // [0, N) (the reference would raise an IndexError; the kernels that follow clamp such ids)
@@ -79,20 +78,16 @@ __global__ __launch_bounds__(kPrecompEdges) void precomp_stencil_kernel(
         const float k_lo = sqrtf((float)(hi - 1) / (float)(R - 1)), k_hi = sqrtf((float)hi / (float)(R - 1));
         const float w_hi = (r - k_lo) / (k_hi - k_lo), w_lo = 1.f - w_hi;
         float2* row = rows + (slot - first) * RF;
-#pragma unroll
-        for (int q = 0; q < kPrecompMaxR; ++q)
-            if (q < R) {
-                const float rw = q == hi ? w_hi : (q == hi - 1 ? w_lo : 0.f);
-#pragma unroll
-                for (int f = 0; f < kPrecompMaxF; ++f)
-                    if (f < F) {
-                        float s, c;
-                        sincosf((float)(f - B) * theta, &s, &c);
-                        // (ring * freq) * wxp, in the reference's order of operations
-                        const float2 rf = make_float2(rw * c, rw * s);
-                        row[q * F + f] = cmul(rf, wx);
-                    }
+        for (int q = 0; q < R; ++q) {
+            const float rw = q == hi ? w_hi : (q == hi - 1 ? w_lo : 0.f);
+            for (int f = 0; f < F; ++f) {
+                float s, c;
+                sincosf((float)(f - B) * theta, &s, &c);
+                // (ring * freq) * wxp, in the reference's order of operations
+                const float2 rf = make_float2(rw * c, rw * s);
+                row[q * F + f] = cmul(rf, wx);
             }
+        }
     }
     __syncthreads();
     const int count = (last - first) * RF;
@@ -152,7 +147,7 @@ int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp
                      float epsilon, int32_t N, int32_t E, int32_t R, int32_t F, int64_t* supp_edges_out, float* supp_sten, float* ln,
                      float* wxp, void* workspace, size_t workspace_bytes, void* stream) {
     if (!log_mag || !log_ang || !xp || !w || !supp_edges || !workspace || N <= 0 || E < 0) return FC_ERR_BAD_ARGUMENT;
-    if (R < 2 || R > fc::kPrecompMaxR || F < 1 || F > fc::kPrecompMaxF || (F & 1) == 0) return FC_ERR_UNSUPPORTED;
+    if (R < 2 || F < 1 || (F & 1) == 0 || R * F > fc::kPrecompMaxRF) return FC_ERR_UNSUPPORTED;
     if (workspace_bytes < fc_precomp_workspace_bytes(N, E)) return FC_ERR_WORKSPACE;
     if (E == 0) return FC_OK;
     if (!supp_edges_out || !supp_sten || !ln || !wxp) return FC_ERR_BAD_ARGUMENT;
@@ -163,6 +158,9 @@ int fc_precomp_build(const float* log_mag, const float* log_ang, const float* xp
     const int32_t* pos = reinterpret_cast<const int32_t*>(wsp + seg);
     float* total = reinterpret_cast<float*>(wsp + 2 * seg);
     if (fc::precomp_area_sums(supp_edges, keep, w, total, N, E, s) != FC_OK) return FC_ERR_LAUNCH;
+    static bool lds_ok[fc::kMaxDevices] = {};
+    if (!fc::allow_full_lds(reinterpret_cast<const void*>(fc::precomp_stencil_kernel), (size_t)fc::kPrecompEdges * R * F * sizeof(float2), lds_ok))
+        return FC_ERR_LAUNCH;
     hipLaunchKernelGGL(fc::precomp_stencil_kernel, dim3((E + fc::kPrecompEdges - 1) / fc::kPrecompEdges), dim3(fc::kPrecompEdges),
                        (size_t)fc::kPrecompEdges * R * F * sizeof(float2), s, log_mag, log_ang, reinterpret_cast<const float2*>(xp), w,
                        supp_edges, keep, pos, total, epsilon, supp_edges_out, reinterpret_cast<float2*>(supp_sten),

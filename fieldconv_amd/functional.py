@@ -425,6 +425,11 @@ def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, a
     complex64 or None.  Layers wider than the kernels' channel block fall back to the separate operators."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
+    if not _compiled(graph):            # no specialised kernels for this (n_rings, band_limit): run-time path, separate operators
+        h = field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph)
+        if addend is not None:
+            h = h + addend
+        return tangent_nonlin(h, bias)
     blk = _channel_block(graph, I, O, band_limit)
     if I > blk or O > blk or os.environ.get('FIELDCONV_NO_FUSED_EPILOGUE', '0') == '1':
         h = field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph)
@@ -442,6 +447,75 @@ def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, a
     if addend is not None and (addend.dtype != torch.complex64 or tuple(addend.shape) != (graph.n_targets, O)):
         raise ValueError(f'addend must be complex64 of shape ({graph.n_targets}, {O})')
     return _FieldConvActFn.apply(x, zonal, spherical, phase, bias.reshape(-1), addend, int(ftype), int(band_limit), graph)
+
+
+class _GenericFieldConvFn(torch.autograd.Function):
+    """FieldConv for (n_rings, band_limit) pairs without specialised kernels (n_rings > 8, band_limit > 3 or 0): the gather
+    and the scatter are run-time HIP kernels on dense stencil rows (csrc/fc_generic.hip), the three contractions with the
+    filter plain complex GEMMs (rocBLAS through torch.matmul).  Same arithmetic as reference nn/field_conv.py:128-137 and its
+    autograd; any channel count."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, graph):
+        lib = _lib.load()
+        x = x.contiguous()
+        O, I, R, F = w_eff.shape
+        B = (F - 1) // 2
+        nt = graph.n_targets
+        with _on(x.device):
+            contrib = _GenericFieldConvFn._gather(lib, x, graph, I, R, B)
+            y = (contrib.view(nt, -1) @ w_eff.reshape(O, -1).transpose(0, 1)) / F
+        ctx.save_for_backward(x, w_eff)
+        ctx.graph = graph
+        return y
+
+    @staticmethod
+    def _gather(lib, x, graph, I, R, B):
+        F = 2 * B + 1
+        contrib = torch.empty((graph.n_targets, I, R, F), dtype=torch.complex64, device=x.device)
+        by_t = _csr(graph.rowptr_t, graph.nbr_t, None)
+        check(lib.fc_generic_gather(_p(x), _p(graph.sten_t), ctypes.byref(by_t), _p(contrib), graph.n_targets, I, R, B, _stream()),
+              'fc_generic_gather')
+        return contrib
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w_eff = ctx.saved_tensors
+        graph = ctx.graph
+        O, I, R, F = w_eff.shape
+        B = (F - 1) // 2
+        nt = graph.n_targets
+        gy = gy.contiguous()
+        with _on(x.device):
+            contrib = _GenericFieldConvFn._gather(lib, x, graph, I, R, B)      # recomputed, not kept between the passes
+            wm = w_eff.reshape(O, -1)
+            g_contrib = ((gy @ wm.conj()) / F).contiguous()                    # (nt, I*R*F)
+            gw = ((gy.transpose(0, 1) @ contrib.view(nt, -1).conj()) / F).reshape(O, I, R, F)
+            gx = torch.empty_like(x)
+            by_s = _csr(graph.rowptr_s, graph.nbr_s, None)
+            check(lib.fc_generic_scatter(_p(x), _p(g_contrib), _p(graph.sten_s), ctypes.byref(by_s), _p(gx), graph.N, I, R, B, _stream()),
+                  'fc_generic_scatter')
+        return gx, gw, None
+
+
+def _generic_field_conv(x, w_eff, graph):
+    if graph.sten_t is None or graph.sten_s is None:
+        raise _lib.FieldConvNativeError('the run-time FieldConv path needs a support graph with dense stencil rows')
+    if x.dtype != torch.complex64 or w_eff.dtype != torch.complex64:
+        raise ValueError('field_conv expects complex64 features and filters')
+    if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != w_eff.shape[1]:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {w_eff.shape[1]})')
+    if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
+        raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
+    if w_eff.shape[1] * graph.R * graph.F * 8 > 160 * 1024:
+        raise _lib.FieldConvNativeError(f'in_channels * n_rings * (2 band_limit + 1) = {w_eff.shape[1] * graph.R * graph.F} exceeds the '
+                                        'run-time path\'s LDS budget (20480)')
+    return _GenericFieldConvFn.apply(x, w_eff.contiguous(), graph)
+
+
+def _compiled(graph):
+    return bool(_lib.load().fc_shape_compiled(graph.R, (graph.F - 1) // 2)) and graph.F % 2 == 1
 
 
 MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)
@@ -467,6 +541,11 @@ def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
     input channels (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
+    if not _compiled(graph):
+        if zonal.shape[2] != graph.R or 2 * band_limit + 1 != graph.F:
+            raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={zonal.shape[2]}, band_limit={band_limit}')
+        from .nn.field_conv import effective_filter          # the (tiny) assembly and its autograd in torch
+        return _generic_field_conv(x, effective_filter(zonal, spherical, phase, int(ftype), int(band_limit)), graph)
     blk = _channel_block(graph, I, O, band_limit)
     if I > blk or O > blk:
         outs = []
@@ -499,6 +578,8 @@ def field_conv(x, w_eff, graph):
     if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
         raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
     O, I = w_eff.shape[0], w_eff.shape[1]
+    if not _compiled(graph):
+        return _generic_field_conv(x, w_eff, graph)
     blk = _channel_block(graph, I, O, (graph.F - 1) // 2)
     if I > blk or O > blk:              # channel blocks, as in field_conv_params
         outs = []

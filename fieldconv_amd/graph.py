@@ -231,6 +231,11 @@ class FactoredStencil:
         return f'FactoredStencil(shape={tuple(self.shape)}, device={self.device}, dense={self._dense is not None})'
 
 
+def _shape_compiled(R, B):
+    from . import _lib
+    return bool(_lib.load().fc_shape_compiled(int(R), int(B)))
+
+
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
                  'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split', 'n_targets')
@@ -276,6 +281,8 @@ class SupportGraph:
         self.on_gx = None          # optional callback(gx) between the data and filter kernels of a backward pass (dist/halo.py)
         self.forward_split = None  # optional (n_first, callback): forward launches targets [0, n_first), calls back, then the rest
         self.n_targets = self.N    # rows of the convolution's output (restrict_targets)
+        if self.R > 8 or self.F > 7 or self.F % 2 == 0 or not _shape_compiled(self.R, (self.F - 1) // 2):
+            allow_factored = False      # no specialised kernels (or outside the record tables: 8 ring runs, 7 phases): dense rows, the run-time kernels
         if native is None:
             native = sten.is_cuda and os.environ.get('FIELDCONV_TORCH_GRAPH', '0') != '1'
         if native and E > 0 and 2 <= self.R <= 8 and self.F <= 7 and self.F % 2 == 1:

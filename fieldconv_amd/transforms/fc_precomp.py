@@ -47,8 +47,8 @@ class FCPrecomp(object):
         if (r.dtype != torch.float32 or theta.dtype != torch.float32 or w.dtype != torch.float32
                 or xp.dtype != torch.complex64):
             raise ValueError('FCPrecomp expects float32 logMag / logAng / w and complex64 xp')
-        if not (2 <= self.R <= 8 and 1 <= 2 * self.B + 1 <= 7):
-            raise ValueError('FCPrecomp supports n_rings 2..8 and band limits 0..3')
+        if self.R < 2 or self.B < 0 or self.R * (2 * self.B + 1) > 156:
+            raise ValueError('FCPrecomp supports n_rings >= 2 and band limits >= 0 with n_rings * (2 band_limit + 1) <= 156')
         if r.numel() == 0:
             F = 2 * self.B + 1
             return (supp_edges[:0], torch.zeros((0, self.R, F), dtype=torch.complex64, device=r.device),
@@ -79,7 +79,8 @@ class FCPrecomp(object):
             ln, wxp = torch.empty(kept, **c64), torch.empty(kept, **c64)
             if kept == 0:
                 return edges_out.to(supp_edges.dtype), torch.zeros((0, R, F), **c64), ln, wxp
-            if os.environ.get('FIELDCONV_EAGER_STENCIL', '0') == '1' or os.environ.get('FIELDCONV_DENSE', '0') == '1':
+            literal = R > 8 or F > 7 or not lib.fc_shape_compiled(R, self.B)     # no record-driven kernels for this shape: the literal (E',R,F) rows
+            if literal or os.environ.get('FIELDCONV_EAGER_STENCIL', '0') == '1' or os.environ.get('FIELDCONV_DENSE', '0') == '1':
                 sten = torch.empty((kept, R, F), **c64)
                 _lib.check(lib.fc_precomp_build(p(r), p(theta), p(xp), p(wv), p(edges), eps, N, E, R, F, p(edges_out), p(sten), p(ln),
                                                 p(wxp), p(ws), nbytes, st), 'fc_precomp_build')

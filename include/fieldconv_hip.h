@@ -202,6 +202,23 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
 int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
                               const fc_filter_params* params, void* stream);
 
+/* ---- any (n_rings, band_limit): the run-time path for shapes outside the compiled set (reference nn/field_conv.py:62-98
+ * takes any) ---- *
+ * fc_shape_compiled: 1 for n_rings 2..8 x band_limit 1..3 (the specialised kernels above), else 0.  For the others the
+ * operator is evaluated in the reference's own two steps, with dense stencil rows in slot order:
+ *   fc_generic_gather   contrib (n_targets, I, R, F) c64 = the per-target response of :128-134 (by_target CSR with nbr; sten_t
+ *                       (E,R,F) c64 in its slot order); the caller contracts it with W_eff (a plain complex GEMM:
+ *                       y = contrib.view(n, I*R*F) @ W_eff.view(O, I*R*F)^T / F) and forms the two backward GEMMs
+ *                       g_contrib = gy @ conj(W_eff) / F, gW_eff = gy^T @ conj(contrib) / F;
+ *   fc_generic_scatter  gx (N, I) c64 from g_contrib (n_targets, I, R, F) over the out-edges (by_source CSR with nbr = targets,
+ *                       sten_s in its slot order), including the chain rule through the rotation e^{-i m angle(x)}.
+ * I * R * F * 8 bytes (gather) must fit the CU's 160 KB of LDS; any channel count otherwise. */
+int fc_shape_compiled(int32_t n_rings, int32_t band_limit);
+int fc_generic_gather(const float* x, const float* sten_t, const fc_csr* by_target, float* contrib, int32_t n_targets, int32_t I,
+                      int32_t R, int32_t B, void* stream);
+int fc_generic_scatter(const float* x, const float* g_contrib, const float* sten_s, const fc_csr* by_source, float* gx, int32_t N,
+                       int32_t I, int32_t R, int32_t B, void* stream);
+
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */
 int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w, float* y,

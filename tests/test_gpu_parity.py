@@ -565,13 +565,56 @@ def test_empty_graph_and_isolated_vertices(dev):
     assert torch.count_nonzero(gx) == 0
 
 
-def test_unsupported_shapes_fail_loudly(dev):
-    from fieldconv_amd._lib import FieldConvNativeError
-    from fieldconv_amd.nn import FieldConv
-    conv = FieldConv(4, 4, band_limit=1, n_rings=9).to(dev)       # n_rings=9 is not compiled (2..8 are)
-    x = torch.zeros(5, 4, dtype=torch.cfloat, device=dev)
-    with pytest.raises(FieldConvNativeError):
-        conv(x, torch.zeros(3, 2, dtype=torch.long, device=dev), torch.zeros(3, 9, 3, dtype=torch.cfloat, device=dev))
+@pytest.mark.parametrize('shape', [
+    # N,  k,  I,  O, B, R
+    (150, 9, 12, 20, 1, 9),        # nine rings
+    (120, 8, 16, 8, 4, 6),         # band limit 4
+    (90, 6, 7, 5, 4, 2),           # (band limit 0 cannot be constructed in the reference either: xavier on an empty tensor)
+    (60, 5, 70, 66, 2, 12),        # wide and many rings: no channel blocks on this path
+    (40, 4, 6, 6, 5, 11),
+], ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d' % s)
+def test_any_rings_and_band_limit_run_time_path(shape, dev):
+    """(n_rings, band_limit) pairs without specialised kernels -- n_rings > 8 or band_limit > 3 -- take the run-time path
+    (csrc/fc_generic.hip: gather and scatter kernels on dense stencil rows, the contractions as complex GEMMs), as the
+    reference takes any (nn/field_conv.py:62-98): module output, input gradient and every parameter gradient against the
+    oracle, for a dense random stencil and for FCPrecomp's (through our FCPrecomp, which returns literal rows for such shapes);
+    and the same through the FCResNetBlock's fused call path."""
+    from fieldconv_amd import _lib
+    from fieldconv_amd.nn import FCResNetBlock, FieldConv
+    N, k, I, O, B, R = shape
+    assert _lib.load().fc_shape_compiled(R, B) == 0
+    edges, sten, x, gy, W = make_case(N + I, N, k, I, O, B, R)
+    for ftype in (1, 2):
+        torch.manual_seed(ftype)
+        conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=ftype).to(dev)
+        xd = x.to(dev).requires_grad_(True)
+        y = conv(xd, edges.to(dev), sten.to(dev))
+        params = list(conv.parameters())
+        grads = torch.autograd.grad(y, [xd] + params, grad_outputs=gy.to(dev))
+        zon, sph, ph = (H(conv.zonal), H(conv.spherical), H(conv.phase))
+        Wn = orc.effective_filter(zon, sph, ph, ftype, B)
+        y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), Wn)
+        gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), Wn, gy.numpy())
+        pg_ref = orc.effective_filter_vjp(gW_ref, zon, sph, ph, ftype, B)
+        assert rel_err(H(y), y_ref) < TOL and rel_err(H(grads[0]), gx_ref) < TOL
+        for g, r in zip(grads[1:], pg_ref):
+            assert rel_err(H(g), r) < TOL
+    # FCPrecomp for such a shape, and a block on it (modReLU / residual as separate operators on this path)
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.transforms import FCPrecomp
+    from oracle.torch_composites import FCPrecomp as FCPrecompRef
+    data = sphere_support(200, 10, seed=3, support='p95')
+    e1, s1, _, _ = FCPrecomp(B, R, data.epsilon)(data.to(dev))
+    e2, s2, _, _ = FCPrecompRef(B, R, data.epsilon)(data)
+    assert torch.is_tensor(s1) and torch.equal(e1.cpu(), e2) and rel_err(H(s1), H(s2)) < 2e-6
+    torch.manual_seed(5)
+    blk = FCResNetBlock(6, 10, band_limit=B, n_rings=R).to(dev)
+    g = torch.Generator().manual_seed(9)
+    xb = torch.complex(torch.randn(200, 6, generator=g), torch.randn(200, 6, generator=g))
+    yb = blk(xb.to(dev), e1, s1)
+    p = {k_: H(v) for k_, v in blk.state_dict().items()}
+    yb_ref = orc.fc_resnet_block_forward(xb.numpy(), e2.numpy(), s2.numpy(), p, 1, B)
+    assert rel_err(H(yb), yb_ref) < 5 * TOL
 
 
 def test_layers_too_large_for_the_lds_run_in_narrower_blocks(dev):
