@@ -440,7 +440,13 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     x = x.to(dev).requires_grad_(True)
     gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
 
-    mesh_graph = get_graph(edges, sten, n_local)            # the instance every convolution will use
+    mesh_graph = get_graph(edges, sten, n_local)            # the mesh's cached graph
+    if plan is not None:
+        # restriction and exchange hooks go on a per-use view (the cached graph is shared by every user of the mesh); the
+        # convolution gets it through a stand-in for the stencil
+        from fieldconv_amd.graph import FactoredStencil
+        mesh_graph = mesh_graph.view()
+        sten = FactoredStencil.wrap(sten, mesh_graph)
     if plan is not None:
         mesh_graph.restrict_targets(n_owned)                # halo vertices are sources only: no output rows, no padded gy
     if overlap:

@@ -122,7 +122,8 @@ def overlap_backward(graph, plan):
     kernels: the first completes gx (including the rows of the halo vertices, which belong to their owners), the second
     only reads the slabs the first left behind.  With this hook on the mesh's SupportGraph the transposed exchange of
     the halo rows is enqueued between the two (asynchronously, on RCCL's stream) and halo_exchange's backward node later
-    only waits for it.  Per mesh, after get_graph(...) and HaloPlan(...)."""
+    only waits for it.  `graph`: a view of the mesh's graph (SupportGraph.view()) or a graph of the caller's own."""
+    graph._own('overlap_backward')
     def on_gx(gx):
         if gx.shape[0] != plan.n_owned + plan.n_halo:
             return
@@ -139,6 +140,7 @@ def overlap_forward(graph, plan, n_interior, whole_rounds=True):
     that the first `n_interior` read owned sources only (data.sphere_partition(..., interior_first=True)), the forward pass
     over this graph becomes two launches: targets [0, n_interior) while the halo rows are still arriving, then -- after the
     stream waited for the exchange -- the boundary targets.  Use with halo_exchange(x, plan, deferred=True); per mesh."""
+    graph._own('overlap_forward')
     n_first = int(n_interior)
     if not 0 <= n_first <= plan.n_owned:
         raise ValueError('n_interior must lie in [0, n_owned]')

@@ -161,6 +161,31 @@ class FactoredStencil:
         self._dense = None
         self._lift = None
 
+    def bound_to(self, graph):
+        """The same stencil (factor table, materialised columns shared) carrying another SupportGraph -- a per-use VIEW of the
+        mesh's cached graph with its own target restriction / exchange hooks (SupportGraph.view, dist/halo.py)."""
+        other = FactoredStencil.__new__(FactoredStencil)
+        other.__dict__.update(self.__dict__)
+        other.graph = graph
+        return other
+
+    @classmethod
+    def wrap(cls, supp_sten, graph):
+        """A stand-in for `supp_sten` (a FactoredStencil or the dense (E,R,F) tensor) that carries `graph`: what a caller hands
+        to the modules in place of the stencil when the convolution is to use a view of the mesh's graph."""
+        if isinstance(supp_sten, FactoredStencil):
+            return supp_sten.bound_to(graph)
+        other = FactoredStencil.__new__(FactoredStencil)
+        other.factors = None
+        other.R, other.F = int(supp_sten.shape[1]), int(supp_sten.shape[2])
+        other.graph = graph
+        other.shape = supp_sten.shape
+        other.dtype, other.device, other.is_cuda = supp_sten.dtype, supp_sten.device, supp_sten.is_cuda
+        other.requires_grad = False
+        other._dense = supp_sten
+        other._lift = None
+        return other
+
     def dim(self):
         return 3
 
@@ -238,7 +263,7 @@ def _shape_compiled(R, B):
 
 class SupportGraph:
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split', 'n_targets')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split', 'n_targets', '_is_view')
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -281,6 +306,7 @@ class SupportGraph:
         self.on_gx = None          # optional callback(gx) between the data and filter kernels of a backward pass (dist/halo.py)
         self.forward_split = None  # optional (n_first, callback): forward launches targets [0, n_first), calls back, then the rest
         self.n_targets = self.N    # rows of the convolution's output (restrict_targets)
+        self._is_view = False
         if self.R > 8 or self.F > 7 or self.F % 2 == 0 or not _shape_compiled(self.R, (self.F - 1) // 2):
             allow_factored = False      # no specialised kernels (or outside the record tables: 8 ring runs, 7 phases): dense rows, the run-time kernels
         if native is None:
@@ -344,6 +370,7 @@ class SupportGraph:
         g.on_gx = None
         g.forward_split = None
         g.n_targets = g.N
+        g._is_view = False
         g.sten_t = g.sten_s = None
         for name in ('rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', 'rec_t', 'rec_s', 'runs_t', 'runs_s'):
             setattr(g, name, built[name])
@@ -351,10 +378,32 @@ class SupportGraph:
         g.geo_t = built['geo_t'] if geo_ok else None
         return g
 
+    def view(self):
+        """A per-use view of this graph: every array is shared, the target restriction, the exchange hooks and the launch
+        plans are its own.  get_graph hands the SAME cached object to every caller of a mesh (training and evaluation, two
+        partition plans): restrictions and hooks therefore go on a view, which the caller passes to the modules through
+        FactoredStencil.wrap(supp_sten, view) in place of the stencil."""
+        v = SupportGraph.__new__(SupportGraph)
+        for name in SupportGraph.__slots__:
+            if hasattr(self, name):
+                setattr(v, name, getattr(self, name))
+        v._plans = {}
+        v.on_gx = None
+        v.forward_split = None
+        v.n_targets = self.N
+        v._is_view = True
+        return v
+
+    def _own(self, what):
+        if not getattr(self, '_is_view', False) and self in _cache.values():
+            raise ValueError(f'{what} would change the graph every user of this mesh gets from the cache: take graph.view() and hand '
+                             'the modules FactoredStencil.wrap(supp_sten, view)')
+
     def restrict_targets(self, n):
         """The vertices from `n` on are sources only (the halo of a partitioned mesh: no edge points at them): the forward
         pass then computes and returns the first n rows, the backward pass takes an (n, O) output gradient; features and
-        their gradient keep all N rows."""
+        their gradient keep all N rows.  On a view (or a graph of one's own), not on the cached graph of a mesh."""
+        self._own('restrict_targets')
         n = int(n)
         if not 0 < n <= self.N:
             raise ValueError(f'n_targets must lie in (0, {self.N}]')

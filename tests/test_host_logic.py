@@ -310,3 +310,26 @@ def test_bench_refuses_debug_switches_and_explains_missing_gpus():
         res = subprocess.run([sys.executable, bench, '--gpus', '2'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                              timeout=300)
         assert res.returncode == 2 and 'GPU(s) visible' in res.stderr
+
+
+def test_graph_views_keep_the_cached_graph_clean():
+    """get_graph hands every user of a mesh the same cached SupportGraph: target restrictions and exchange hooks go on a view
+    (own hooks and plans, shared arrays), which reaches the modules through FactoredStencil.wrap."""
+    from fieldconv_amd.graph import FactoredStencil, SupportGraph, get_graph
+    g = torch.Generator().manual_seed(0)
+    N, E, R, F = 12, 40, 3, 3
+    edges = torch.stack((torch.randint(0, N, (E,), generator=g), torch.randint(0, 8, (E,), generator=g)), 1)   # targets 0..7 only
+    sten = torch.complex(torch.randn(E, R, F, generator=g), torch.randn(E, R, F, generator=g))
+    cached = get_graph(edges, sten, N)
+    assert get_graph(edges, sten, N) is cached
+    with pytest.raises(ValueError):
+        cached.restrict_targets(8)                       # would change what every other user of the mesh gets
+    view = cached.view()
+    view.restrict_targets(8)
+    view.on_gx = lambda gx: None
+    assert view.n_targets == 8 and cached.n_targets == N and cached.on_gx is None and cached.forward_split is None
+    assert view.rowptr_t is cached.rowptr_t and view._plans is not cached._plans
+    bound = FactoredStencil.wrap(sten, view)
+    assert get_graph(edges, bound, N) is view and tuple(bound.shape) == (E, R, F) and torch.equal(bound.materialize(), sten)
+    own = SupportGraph(edges, sten, N)                   # a graph of one's own may be changed directly
+    assert own.restrict_targets(8).n_targets == 8

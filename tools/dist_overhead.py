@@ -32,7 +32,9 @@ g = torch.Generator().manual_seed(1)
 x = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev).requires_grad_(True)
 gy = torch.complex(torch.randn(n_owned, C, generator=g), torch.randn(n_owned, C, generator=g)).to(dev)
 from fieldconv_amd.dist import GradientBuckets, overlap_forward     # noqa: E402
-graph = get_graph(edges, sten, data.num_nodes)
+from fieldconv_amd.graph import FactoredStencil     # noqa: E402
+graph = get_graph(edges, sten, data.num_nodes).view()      # hooks go on a per-use view
+sten = FactoredStencil.wrap(sten, graph)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'dist'
 if mode != 'plain':
     graph.restrict_targets(n_owned)

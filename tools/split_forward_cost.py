@@ -16,7 +16,9 @@ dev = torch.device('cuda:0')
 N, k, C, B, R = 20000, 32, 48, 2, 6
 data = sphere_support(N, k, seed=0, support='p95').to(dev)
 edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
-graph = get_graph(edges, sten, N)
+from fieldconv_amd.graph import FactoredStencil     # noqa: E402
+graph = get_graph(edges, sten, N).view()
+sten = FactoredStencil.wrap(sten, graph)
 conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
 x = torch.randn(N, C, dtype=torch.complex64, device=dev, requires_grad=True)
 gy = torch.randn(N, C, dtype=torch.complex64, device=dev)
