@@ -467,6 +467,17 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         buckets.all_reduce()
         return (x.grad,) + tuple(p.grad for p in params)
 
+    # Opt-in (BENCH_GRAPH_STEP=1): the whole partitioned step -- both halo exchanges, the convolution's kernels, the bucketed
+    # all-reduce -- captured once in ONE HIP graph and replayed (RCCL's collectives are capturable through torch's NCCL
+    # backend).  One rank over RCCL on one MI355X: 415 us per step against 454 us launched eagerly (the plain step: 389 us;
+    # tools/dist_overhead.py).  Not the default with several ranks: a multi-rank capture has never run on this pool.
+    graph_step = use_dist and os.environ.get('BENCH_GRAPH_STEP', '0') == '1'
+    eager_step = step
+    if graph_step:
+        from fieldconv_amd.utils import StepGraph
+        sg = StepGraph(lambda: eager_step()[0])
+        step = sg.replay
+
     def measure_prep():
         """per-mesh preprocessing, timed AFTER the metric's timed regions (the protocol's warm-up is the first GPU work of the process)"""
         # per-mesh preprocessing = everything between the reference's data object and the first convolution launch: FCPrecomp's
@@ -490,6 +501,8 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     harvested = {}
 
     def arm_timer():
+        if graph_step:
+            return                          # a replayed graph runs no Python: the kernels are timed on eager steps afterwards
         kernel_timer.reset(pairs=4 * (args.steps // 3 + 1))
         # every 4th launch of each kernel inside the timed region carries a HIP-event pair (every 3rd when the forward pass
         # is two launches per step, so that interior and boundary launches are sampled alternately)
@@ -498,10 +511,20 @@ def run_layer(args, world, rank, dev, use_dist, backend):
 
     def harvest(tag):                       # after the fence that ends a timed region
         kernel_timer.enabled = False
-        harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
+        if not graph_step:
+            harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
 
     elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
                                settle=not args.cold)
+    if graph_step:                          # per-kernel times from a few eager steps behind the timed regions
+        kernel_timer.reset(pairs=64)
+        kernel_timer.stride = 1
+        kernel_timer.enabled = True
+        for _ in range(8):
+            eager_step()
+        torch.cuda.synchronize()
+        kernel_timer.enabled = False
+        harvested['literal'] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     ms_per_step = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps) / 1e6
@@ -572,7 +595,8 @@ def run_layer(args, world, rank, dev, use_dist, backend):
                    'support': args.support, 'stencil_path': 'geometric records' if mesh_graph.geo_t is not None else
                    ('factored records' if factored else 'dense rows'),
                    'parallelism': 'single GPU' if world == 1 else f'vertex partition x{world}, one-hop halo over RCCL',
-                   'halo_rows_rank0': 0 if plan is None else plan.n_halo},
+                   'halo_rows_rank0': 0 if plan is None else plan.n_halo,
+                   'step_launch': 'one HIP graph per step (BENCH_GRAPH_STEP=1)' if graph_step else 'eager'},
         'roofline': roofline,
         'kernels': per_kernel,
         'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -55,6 +55,23 @@ def test_parity_subset_in_mode(mode):
     assert ' passed' in tail and 'failed' not in tail, tail
 
 
+def test_bench_partitioned_step_as_one_hip_graph():
+    """BENCH_GRAPH_STEP=1: halo exchanges, convolution kernels and the bucketed all-reduce of the partitioned step captured in
+    one HIP graph (single rank over RCCL) -- the line is produced and the step is not slower than the eager one."""
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5', '--verts', '6000', '--no-cpu-baseline',
+            '--no-extras', '--cold']
+    out = {}
+    for flag in ('0', '1'):
+        env = _clean_env({'BENCH_FORCE_DIST': '1', 'BENCH_GRAPH_STEP': flag, 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '2953' + str(5 + int(flag)),
+                          'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'})
+        res = subprocess.run(base, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        out[flag] = json.loads(res.stdout.strip().splitlines()[-1])
+    assert 'HIP graph' in out['1']['config']['step_launch'] and out['0']['config']['step_launch'] == 'eager'
+    assert out['1']['value'] > 0.9 * out['0']['value']
+    assert out['1']['roofline'] is not None
+
+
 def test_bench_single_rank_over_rccl():
     """bench.py with BENCH_FORCE_DIST=1: one rank, but the partition / halo-exchange / all-reduce code of
     fieldconv_amd.dist runs over the nccl (= RCCL) backend exactly as it does with N > 1."""

@@ -36,6 +36,9 @@ from fieldconv_amd.graph import FactoredStencil     # noqa: E402
 graph = get_graph(edges, sten, data.num_nodes).view()      # hooks go on a per-use view
 sten = FactoredStencil.wrap(sten, graph)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'dist'
+capture = mode == 'dist_graph'          # the partitioned step (both exchanges, bucketed all-reduce) captured in ONE HIP graph
+if capture:
+    mode = 'dist'
 if mode != 'plain':
     graph.restrict_targets(n_owned)
     overlap_backward(graph, plan)
@@ -74,6 +77,21 @@ def step():
     lap('all_reduce', t)
 
 
+if capture:
+    from fieldconv_amd.utils import StepGraph
+
+    def captured():
+        step()
+        return x.grad
+    try:
+        sg = StepGraph(captured)
+    except Exception as exc:                       # noqa: BLE001
+        print(f'dist_graph: capture failed: {type(exc).__name__}: {str(exc)[:300]}')
+        dist.destroy_process_group()
+        sys.exit(0)
+    eager_step = step
+    step = sg.replay
+    mode = 'dist_graph'
 for _ in range(300):
     step()
 torch.cuda.synchronize()
