@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
     if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
     float2 xv = make_float2(0.f, 0.f);
     {
-        const int j = (blockIdx.x >> a.parts_log2) * kTile + wave;
+        const int j = item_vertex(blockIdx.x, wave, a.nv_full, a.parts_log2, a.N);
         if (blockIdx.x < a.ntiles && j < a.N && lane < I) xv = gx_[(size_t)j * I + lane];
     }
     int buf = 0;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
             dma_slab(tn, buf ^ 1);
-            const int jn = (tn >> a.parts_log2) * kTile + wave;
+            const int jn = item_vertex(tn, wave, a.nv_full, a.parts_log2, a.N);
             xv = (jn < a.N && lane < I) ? gx_[(size_t)jn * I + lane] : make_float2(0.f, 0.f);
         }
         // the xt stores must be visible to every wavefront; LDS only, the DMA just issued stays in flight
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
     if (blockIdx.x < a.ntiles) dma_slab(blockIdx.x, 0);
     float2 xv = make_float2(0.f, 0.f);
     {
-        const int j = (blockIdx.x >> a.parts_log2) * kTile + wave;
+        const int j = item_vertex(blockIdx.x, wave, a.nv_full, a.parts_log2, a.N);
         if (blockIdx.x < a.ntiles && j < a.N && lane < I) xv = gx_[(size_t)j * I + lane];
     }
     const int nchunk = KP / 4;                     // chunks of four k entries; a lane converts chunks lane and lane + 64
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
         const int tn = tile + gridDim.x;
         if (tn < a.ntiles) {
             dma_slab(tn, buf ^ 1);
-            const int jn = (tn >> a.parts_log2) * kTile + wave;
+            const int jn = item_vertex(tn, wave, a.nv_full, a.parts_log2, a.N);
             xv = (jn < a.N && lane < I) ? gx_[(size_t)jn * I + lane] : make_float2(0.f, 0.f);
         } else {
             xv = make_float2(0.f, 0.f);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
         pinv = tail[kTile + wave];
         pt = lane < IP ? tail[2 * kTile + lane] : 1.f;
         pit = tail[2 * kTile + IP + i0 + fr];
-        const int j = (tile >> a.parts_log2) * kTile + wave;
+        const int j = item_vertex(tile, wave, a.nv_full, a.parts_log2, a.N);
         xv = (j < a.N && lane < I) ? gx_[(size_t)j * I + lane] : make_float2(0.f, 0.f);
     };
     if (blockIdx.x < a.ntiles) prefetch(blockIdx.x);

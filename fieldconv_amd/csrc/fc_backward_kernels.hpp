@@ -40,7 +40,9 @@ struct BwdArgs {
     MmaGeom g;           // M = I (rows of gxt), K = R*O in fp32 blocking: layout of the H slabs kept for the filter kernel
     MmaGeom gd;          // the same contraction in the data kernel's MFMA mode (fp32 or split)
     uint32_t wpk_bytes;  // size of the packed backward filter image
-    int ntiles;          // VIRTUAL tiles: (N/16 vertex tiles) << parts_log2, one set of H slabs each
+    int ntiles;          // work items (tile_items): (N/16 vertex tiles) << parts_log2, or whole tiles followed by the last round's
+                         // tiles as half tiles; one set of H slabs each
+    int nv_full;         // items below are whole tiles
     int parts_log2;      // 2^parts_log2 workgroups share a vertex tile, each with that share of every source's edges (see
                          // FwdArgs); virtual tile vt covers the vertices of tile vt >> parts_log2
     uint32_t part_stride;   // complex numbers between the parts' partial gx arrays
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         e = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) run[q] = 0;
-        const int j = (vt >> pl) * kTile + wave;
+        const int j = item_vertex(vt, wave, a.nv_full, pl, a.N);
         if (vt < a.ntiles && j < a.N) {
             const int rb = growptr[j];
             const int n = growptr[j + 1] - rb;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
         // my (vertex, channel) entry of x for the gx epilogue: issued now, consumed after the first slab
-        const int ejn = (tile >> pl) * kTile + ev;
+        const int ejn = e_active ? item_vertex(tile, ev, a.nv_full, pl, a.N) : a.N;
         float2 exs = make_float2(0.f, 0.f);
         if (e_active && ejn < a.N) exs = gx_[(size_t)ejn * I + ei];
         float2 gxacc = make_float2(0.f, 0.f);
@@ -411,7 +413,7 @@ __host__ __device__ inline int filter_image_stride(int KP) { return round_up(4 *
 
 struct BwdPlan {
     MmaGeom g, gd;
-    int IP, KP, KD, ntiles, parts_log2, ngw, P, F, slab_floats, slab_stride, fhalf;
+    int IP, KP, KD, ntiles, nv_full, parts_log2, ngw, P, F, slab_floats, slab_stride, fhalf;
     size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes, gxp_bytes, gx_part_stride;
     bool ok, ok_factored;
 };
@@ -424,7 +426,16 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.IP = p.g.MP;
     p.KP = p.g.KP;
     p.parts_log2 = edge_parts_log2(d);
-    p.ntiles = ((d->N + kTile - 1) / kTile) << p.parts_log2;       // virtual tiles
+    {
+        const int nt = (d->N + kTile - 1) / kTile;
+        // Half tiles in the last round (tile_items) pay in the forward kernel only: at 4 999 vertices, C = 64, B = 3 the data
+        // kernel gains 3.6 us and the filter kernel loses 4.9 (57 more, half-empty slabs to stream): FC_HALF_TILES=2 turns them
+        // on here as well.
+        static const bool bwd_halves = getenv("FC_HALF_TILES") && atoi(getenv("FC_HALF_TILES")) == 2;
+        const TileItems items = tile_items(nt, bwd_halves ? num_cus() : 0, p.parts_log2);
+        p.ntiles = items.nv_total;                                             // work items: one set of H slabs each
+        p.nv_full = items.nv_full;
+    }
     p.gx_part_stride = part_stride((size_t)d->N * d->I);
     p.gxp_bytes = p.parts_log2 ? (p.gx_part_stride << p.parts_log2) * sizeof(float2) : 0;
     p.ngw = p.g.KST * p.g.NMT;
@@ -460,6 +471,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.gd = p.gd;
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->I, d->R, d->O, p.F, p.gd.split) * sizeof(float));
     a.ntiles = p.ntiles;
+    a.nv_full = p.nv_full;
     a.parts_log2 = p.parts_log2;
     a.part_stride = (uint32_t)p.gx_part_stride;
     a.ngw = p.ngw;

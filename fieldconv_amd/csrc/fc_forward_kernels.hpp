@@ -35,6 +35,7 @@ struct FwdArgs {
     int N, I, O;
     MmaGeom g;          // M = O, K = R*I
     int ntiles;
+    int nv_full, nv_total;   // work items (tile_items): whole tiles, then the last round's tiles as half tiles
     int parts_log2;     // factored kernels: every tile is processed by 2^parts_log2 workgroups, each taking that share of
                         // every target's slots and writing its own partial output (y + part * part_stride); 0 = whole tiles.
                         // Meshes with few vertices and wide supports would otherwise occupy ntiles of the 256 CUs.
@@ -186,7 +187,7 @@ __device__ __forceinline__ void forward_epilogue(const FwdLds& l, float* part, c
     if (!(a.dbg & 8))
     for (int idx = wave * kWave + lane; idx < kTile * a.O; idx += kThreads) {
         const int v = idx / a.O, o = idx - v * a.O;
-        const int n = tile * kTile + v;
+        const int n = item_vertex(tile, v, a.nv_full, a.parts_log2, a.N);        // (`tile`: the work item)
         float2 s = sum_partials(part, g, v, o);
         if constexpr (SPLIT) {      // undo the slab scale of vertex v and the filter scale of row o (both powers of two)
             const float k = vs[kTile + v] * gwpk[o];
@@ -326,14 +327,13 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
     // A workgroup walks VIRTUAL tiles vt = (tile << parts_log2) + part: part p of 2^parts_log2 takes the slots
     // [n p / parts, n (p+1) / parts) of each of the tile's targets, with the ring-run offsets clipped to that range.
     const int pl = a.parts_log2;
-    const int nvt = a.ntiles << pl;
     auto slot_range = [&](const int vt, int& b, int& e, int (&run)[R]) {
         b = 0;
         e = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) run[q] = 0;
-        const int t = (vt >> pl) * kTile + wave;
-        if (vt < nvt && t < a.N) {
+        const int t = item_vertex(vt, wave, a.nv_full, pl, a.N);
+        if (vt < a.nv_total && t < a.N) {
             const int rb = growptr[t];
             const int n = growptr[t + 1] - rb;
             const int part = vt & ((1 << pl) - 1);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
 
     float* vs = l.vscale;
     int buf = 0;
-    for (int vt = first_tile_of_block(); vt < nvt; vt += gridDim.x) {
+    for (int vt = first_tile_of_block(); vt < a.nv_total; vt += gridDim.x) {
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
 
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             forward_phase_b<R, B, MG, (NG > 1), SPLIT>(c, f0, l, vs, buf, gwpk, a, wave, lane, g == 0, acc_re, acc_im);
         }
         first_rows(nend - nbeg, pxa, pxb);       // the next tile's first source rows fly during the epilogue
-        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, vt >> pl, wave, lane, acc_re,
+        forward_epilogue<SPLIT>(l, a.slabs == 2 ? l.slab + buf * slab_floats(a.g) : l.part, vs, gwpk, a, vt, wave, lane, acc_re,
                                 acc_im, gy_ + (size_t)(vt & ((1 << pl) - 1)) * a.part_stride);
         buf ^= (a.slabs == 2);
         vs = (vs == l.vscale) ? l.vscale + 2 * kTile : l.vscale;
@@ -528,11 +528,14 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     // dense: one tile per workgroup; factored: persistent (the record ring is primed one tile ahead)
     const int nvt = a.ntiles << a.parts_log2;
     const int grid = factored ? (nvt < num_cus() ? nvt : num_cus()) : a.ntiles;
+    const TileItems items = tile_items(a.ntiles, factored ? grid : 0, a.parts_log2);
+    a.nv_full = items.nv_full;
+    a.nv_total = items.nv_total;
     // With two slab buffers the epilogue parks its fp32 k-partials in the idle one.  A workgroup that walks several
     // tiles would then read those bits back as halves in the k padding [R*KI, KP) of the next tile's slab rows (the
     // padding is zeroed once, before the tile loop), and 0 x NaN poisons the accumulators: shapes with k padding
     // keep the partials in their own region whenever a workgroup sees more than one tile.
-    const bool aliasing_hazard = a.g.KP > d->R * a.g.KI && grid < nvt;
+    const bool aliasing_hazard = a.g.KP > d->R * a.g.KI && grid < a.nv_total;
     a.slabs = (SPLIT && !aliasing_hazard && partial_floats(a.g.NKP, a.g.MP) <= slab_floats(a.g) &&
                forward_lds_floats(a.g, 2) * sizeof(float) + ring <= kMaxLds) ? 2 : 1;
     const size_t lds = forward_lds_floats(a.g, a.slabs) * sizeof(float) + ring;

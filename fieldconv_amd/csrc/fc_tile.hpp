@@ -354,6 +354,33 @@ inline int sum_parts_epilogue(const float* part, float* dst, size_t count, size_
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
+// Work items of a persistent tile kernel (no edge split): [0, nv_full) are whole 16-vertex tiles; the tiles of the last,
+// partly filled round follow as HALF tiles -- 8 vertices on wavefronts 0..7, the other wavefronts (and rows 8..15 of the
+// slabs) idle -- so that every workgroup gets a share of that round (313 tiles on 256 workgroups, a 5 000-vertex mesh: one
+// round and a round of half tiles instead of two rounds).  FC_HALF_TILES=0 switches them off.
+struct TileItems {
+    int nv_full, nv_total;
+};
+inline TileItems tile_items(int ntiles, int grid, int parts_log2) {
+    static const bool on = !(getenv("FC_HALF_TILES") && atoi(getenv("FC_HALF_TILES")) == 0);
+    TileItems t;
+    t.nv_full = t.nv_total = ntiles << parts_log2;
+    if (!on || parts_log2 != 0 || grid <= 0) return t;
+    const int rem = ntiles % grid;
+    if (ntiles > grid && rem > 0 && 2 * rem <= grid) {
+        t.nv_full = ntiles - rem;
+        t.nv_total = t.nv_full + 2 * rem;
+    }
+    return t;
+}
+// vertex of row `row` (0..15) of work item `item`, or N for a row without a vertex; parts_log2 != 0: items are
+// (tile << parts_log2) + part
+__host__ __device__ inline int item_vertex(int item, int row, int nv_full, int parts_log2, int N) {
+    if (item < nv_full) return (item >> parts_log2) * kTile + row;
+    const int h = item - nv_full;
+    return row < 8 ? ((nv_full >> parts_log2) + (h >> 1)) * kTile + (h & 1) * 8 + row : N;
+}
+
 // How many workgroups share a tile of 16 vertices (log2): only when the tiles alone leave CUs idle and every part still
 // gets a few edges per vertex.  FC_EDGE_PARTS_MAX (development) caps it.
 inline int edge_parts_log2(const fc_dims* d) {

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ('test_fused_precomp_graph or test_fieldconv_golden or test_segmentation_net_golden or test_small_cotangent or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
-          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or '
+          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or N5000_k7 or '
           'test_config2_record_kernels')
 
 MODES = {
@@ -33,6 +33,8 @@ MODES = {
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
     'ring_major_backward': {'FC_BWD_RING': '2'},         # the opt-in ring-major backward kernels (32-vertex tiles, DMA-fed filter kernel)
     'separate_finish_kernels': {'FC_SPLIT_FINISH': '1'},   # fc_backward_finish + fc_filter_param_grads instead of the fused launch
+    'no_half_tiles': {'FC_HALF_TILES': '0'},
+    'half_tiles_in_the_backward_pass_too': {'FC_HALF_TILES': '2'},
     'one_call_per_kernel': {'FIELDCONV_SEPARATE_CALLS': '1'},   # the per-kernel entry points instead of fc_forward_params / fc_backward_all
 }
 
