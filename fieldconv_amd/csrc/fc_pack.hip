@@ -75,6 +75,46 @@ __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, con
     return make_float2(v.x * sc, (is_bwd ? -v.y : v.y) * sc);
 }
 
+// max over the row of |W_eff|^2 / F^2: forward image row m = o (over i, r, f), backward image row m = i (over o, r, f).
+// From the parameters the scan runs over the UNIQUE coefficients -- |coeff[o,i,r,+-b]| = |spherical[o,i,r,b]|, the phase
+// factor has modulus 1 -- i.e. C*R entries of 1 + B (ftype 2: 1 + 2B) numbers instead of C*R*F assembled filter entries.
+template <bool FROM_PARAMS>
+__device__ __forceinline__ float row_max2(const float2* __restrict__ w, const float* __restrict__ zonal, const float* __restrict__ sph,
+                                          const PackArgs& a, bool is_bwd, int m) {
+    const int M = is_bwd ? a.I : a.O, C = is_bwd ? a.O : a.I;
+    float mx = 0.f;
+    if (m >= M) return mx;
+    if (FROM_PARAMS) {
+        for (int idx = threadIdx.x; idx < C * a.R; idx += kPackThreads) {
+            const int c = idx / a.R, r = idx - c * a.R;
+            const int o = is_bwd ? c : m, i = is_bwd ? m : c;
+            const size_t oir = ((size_t)o * a.I + i) * a.R + r;
+            if (a.ftype == 2) {
+                mx = fmaxf(mx, zonal[oir * 2] * zonal[oir * 2] + zonal[oir * 2 + 1] * zonal[oir * 2 + 1]);
+                for (int b = 0; b < 2 * a.B; ++b) {
+                    const float* p = sph + (oir * (2 * a.B) + b) * 2;
+                    mx = fmaxf(mx, p[0] * p[0] + p[1] * p[1]);
+                }
+            } else {
+                mx = fmaxf(mx, zonal[oir] * zonal[oir]);
+                for (int b = 0; b < a.B; ++b) {
+                    const float* p = sph + (oir * a.B + b) * 2;
+                    mx = fmaxf(mx, p[0] * p[0] + p[1] * p[1]);
+                }
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < C * a.R * a.F; idx += kPackThreads) {
+            const int c = idx / (a.R * a.F), rf = idx - c * (a.R * a.F);
+            const int o = is_bwd ? c : m, i = is_bwd ? m : c;
+            const float2 v = w[((size_t)o * a.I + i) * a.R * a.F + rf];
+            mx = fmaxf(mx, v.x * v.x + v.y * v.y);
+        }
+    }
+    const float sc = 1.f / (float)a.F;
+    return mx * sc * sc;
+}
+
 template <bool FROM_PARAMS>
 __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const float2* __restrict__ w, const float* __restrict__ zonal,
                                                                       const float* __restrict__ sph,
@@ -98,12 +138,7 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
             const float sc = 1.f / (float)a.F;
             return make_float2(v.x * sc, -v.y * sc);
         };
-        float mx = 0.f;
-        for (int idx = threadIdx.x; idx < a.R * a.F * a.O; idx += kPackThreads) {
-            const int o = idx % a.O, rf = idx / a.O;
-            const float2 v = entry(o, rf / a.F, rf % a.F, false);
-            mx = fmaxf(mx, v.x * v.x + v.y * v.y);
-        }
+        float mx = row_max2<FROM_PARAMS>(w, zonal, sph, a, true, i);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
         if ((threadIdx.x & 63) == 0) redb[threadIdx.x >> 6] = mx;
@@ -150,12 +185,7 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
     __shared__ float red[kPackThreads / kWave];
     const int nslab = (!is_bwd && a.ring_f) ? a.R : a.F;     // slabs of planes in the image
     const int m = blk / nslab, f = blk - m * nslab;
-    float mx = 0.f;
-    for (int idx = threadIdx.x; idx < nslab * g.KP; idx += kPackThreads) {
-        const int ff = idx / g.KP, k = idx - ff * g.KP;
-        const float2 v = packed_value<FROM_PARAMS, false>(w, zonal, sph, phase, a, is_bwd, m, k, ff);
-        mx = fmaxf(mx, v.x * v.x + v.y * v.y);
-    }
+    float mx = row_max2<FROM_PARAMS>(w, zonal, sph, a, is_bwd, m);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
