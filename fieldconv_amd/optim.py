@@ -56,7 +56,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         """torch.optim.Adam's layout: per-parameter `step`, `exp_avg`, `exp_avg_sq` (copies of the flat buffers' slices),
-        so that a checkpoint written here resumes under torch.optim.Adam and vice versa."""
+        so that a checkpoint written here resumes under torch.optim.Adam and vice versa -- exactly when every parameter got a
+        gradient in every step (see _pack_grads); every entry carries the shared step count."""
         ps = self.param_groups[0]['params']
         step = self._step.detach().clone().reshape(())
         state = {i: {'step': step.clone(), 'exp_avg': self._m[o:o + n].view(p.shape).clone(),
@@ -103,8 +104,12 @@ class FusedAdam(torch.optim.Optimizer):
             self._grad.zero_()
 
     def _pack_grads(self):
-        """Gradients that autograd assigned (after zero_grad(set_to_none=True)) go into the flat buffer; a parameter without a
-        gradient counts as zero; .grad points into the buffer again."""
+        """Gradients that autograd assigned (after zero_grad(set_to_none=True)) go into the flat buffer; .grad points into the
+        buffer again.  A parameter WITHOUT a gradient counts as having a zero gradient: the one elementwise kernel updates the
+        whole flat buffer with one shared step counter, so its moments decay and weight decay applies, where torch.optim.Adam
+        would skip it (and keep a per-parameter step).  The two agree whenever every parameter handed to the optimizer receives
+        a gradient every step -- true for the networks of this package (the `phase` of ftype 0 / 2 layers is a buffer, not a
+        parameter); frozen or unused parameters should not be given to FusedAdam."""
         lo, hi = self._grad.data_ptr(), self._grad.data_ptr() + 4 * self._n
         views, grads = [], []
         for p, v in zip(self.param_groups[0]['params'], self._views):
