@@ -1,6 +1,6 @@
 // FieldConv backward, ring-major path (fc_backward_ring.hpp): the filter-gradient kernel on the kept slabs, the reduction
 // of its partials, plans and launchers.
-#include "fc_backward_ring.hpp"
+#include "fc_backward_roles.hpp"
 
 namespace fc {
 
@@ -215,6 +215,7 @@ struct BrPlan {
     int nr, P;
     size_t lds_data, lds_filter, hdump_bytes, gwp_bytes;
     bool ok;
+    bool roles;         // the data kernel with gathering and contracting wavefronts (fc_backward_roles.hpp)
 };
 
 static BrPlan plan_br(const fc_dims* d) {
@@ -222,6 +223,7 @@ static BrPlan plan_br(const fc_dims* d) {
     const int F = 2 * d->B + 1;
     p.g = br_geom(d->I, d->O, d->R, F);
     p.ok = false;
+    p.roles = false;
     p.nr = 0;
     p.lds_data = p.lds_filter = p.hdump_bytes = p.gwp_bytes = 0;
     p.P = 1;
@@ -235,6 +237,18 @@ static BrPlan plan_br(const fc_dims* d) {
             p.nr = nr;
             p.lds_data = lds;
             break;
+        }
+    }
+    static const int roles_mode = [] { const char* e = getenv("FC_BWD_ROLES"); return e ? atoi(e) : 0; }();
+    if (roles_mode && br_roles_shape_ok(p.g) && d->N < (1 << 24)) {
+        for (int nr = 4; nr >= 2; nr >>= 1) {
+            const size_t lds = br_roles_lds_bytes(p.g, nr);
+            if (lds <= kMaxLds) {
+                p.roles = true;
+                p.nr = nr;
+                p.lds_data = lds;
+                break;
+            }
         }
     }
     p.lds_filter = (size_t)2 * kBrRows * br_image_row_bytes(p.g);
@@ -290,6 +304,13 @@ static BrArgs make_br_args(const fc_dims* d, const BrPlan& p) {
 template <int R, int B>
 static int launch_br_data(const float2* x, const float2* gy, const float* rec, const fc_csr* g, const float* wpk, float2* gx,
                           char* hdump, const BrArgs& a, const BrPlan& p, hipStream_t stream) {
+    if (p.roles) {
+        auto kern = fc_backward_roles_data_kernel<R, B>;
+        static bool lds_ok[kMaxDevices] = {};
+        if (!allow_full_lds(reinterpret_cast<const void*>(kern), p.lds_data, lds_ok)) return FC_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(p.items.grid), dim3(kRoleThreads), p.lds_data, stream, x, gy, rec, g->rowptr, g->runs, wpk, gx, hdump, a);
+        return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+    }
     auto kern = fc_backward_ring_data_kernel<R, B>;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), p.lds_data, lds_ok)) return FC_ERR_LAUNCH;

@@ -28,7 +28,8 @@ def main():
     ap.add_argument('--wave', type=int, nargs='*', default=[0, 7])
     ap.add_argument('--tiles', type=int, default=2)
     args = ap.parse_args()
-    __graft_entry__.build()
+    if not os.environ.get('FIELDCONV_HIP_LIB'):       # (a development variant built by tools/build_variants.sh)
+        __graft_entry__.build()
     from fieldconv_amd import _lib
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.nn import FieldConv
