@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
-                                if (lane < O && !(a.dbg & 8)) dst2[d0] = make_float2(h[r][ff].x, h[r][ff].y);
+                                if (lane < O && !(a.dbg & 8)) __builtin_nontemporal_store(h[r][ff], reinterpret_cast<f32x2*>(dst2) + d0);
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
                                 split_pair_store(row, o0, hi, lo, lane, mg.split);
