@@ -55,6 +55,9 @@ struct BwdArgs {
     int tails;           // 1: every slab is followed by the scales the half-precision filter kernel needs:
                          // [16] s_v, [16] 1/s_v (the data kernel's vertex scales), [IP] t[i], [IP] 1/t[i] (column scales
                          // of x~[v][i] / s_v over the tile's vertices)
+    int nt_dump;         // 1: the H slabs go out with non-temporal stores (dumps that do not fit the Infinity Cache beside the rest:
+                         // 244 MB at config 2 would sweep the cotangent rows and the filter out of L2 on their way; a dump that
+                         // fits -- 80 MB on a FAUST-sized mesh -- is better left cached for the filter-gradient kernel)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
 };
 
@@ -317,7 +320,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
-                                if (lane < O && !(a.dbg & 8)) __builtin_nontemporal_store(h[r][ff], reinterpret_cast<f32x2*>(dst2) + d0);
+                                if (lane < O && !(a.dbg & 8)) {
+                                    if (a.nt_dump) __builtin_nontemporal_store(h[r][ff], reinterpret_cast<f32x2*>(dst2) + d0);
+                                    else dst2[d0] = make_float2(h[r][ff].x, h[r][ff].y);
+                                }
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
                                 split_pair_store(row, o0, hi, lo, lane, mg.split);
@@ -479,6 +485,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
     a.tails = p.fhalf;
+    a.nt_dump = p.hdump_bytes > ((size_t)192 << 20) ? 1 : 0;
     static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
     return a;
