@@ -187,13 +187,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     gb = gather_row(ggy, d1, 8u * O, 8u * ol);
                 }
                 // one slot with compile-time lower ring Q: z_f = g conj(ph_f); h[Q] += w0 z; h[Q+1] += w1 z
+                // (ga / gb hold the cotangent rows of the next even / odd slot: a slot requests the row of slot + 2 into its own
+                //  registers; the record ring's chunk entries are handled between segments of a run, not in the slots)
                 auto slot = [&](auto qc, const int s, float2& gcur) {
                     constexpr int Q = decltype(qc)::value;
-                    if ((s & (CR - 1)) == 0 && s > 0) {
-                        const int ch = s >> LOG_CR;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
-                    }
                     const float* rp = rec_ptr(s);
                     const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                     const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
@@ -223,13 +220,26 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         constexpr int Q = decltype(qc)::value;
                         int s = ro[Q];
                         const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
-                        for (; s + 1 < run_end; s += 2) {
-                            slot(qc, s, ga);
-                            slot(qc, s + 1, gb);
-                        }
-                        if (s < run_end) {
-                            slot(qc, s, ga);
-                            const float2 t = ga; ga = gb; gb = t;
+                        while (s < run_end) {
+                            const int m = s & (CR - 1);
+                            if (m == 0 && s > 0) {       // entering a chunk: the one before it is consumed, its ring slot refilled
+                                const int ch = s >> LOG_CR;
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                            }
+                            const int stop = min(run_end, s - m + CR);
+                            if ((s & 1) && s < stop) {
+                                slot(qc, s, gb);
+                                ++s;
+                            }
+                            for (; s + 1 < stop; s += 2) {
+                                slot(qc, s, ga);
+                                slot(qc, s + 1, gb);
+                            }
+                            if (s < stop) {
+                                slot(qc, s, ga);
+                                ++s;
+                            }
                         }
                     });
                 }

@@ -403,15 +403,9 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
             // exit.  No scalar memory loads in here (they share lgkmcnt with the LDS reads and return out of
             // order) and only shifts/masks in the address arithmetic: the CU's single scalar ALU serves all
             // 16 wavefronts.
+            // (xa / xb hold the source rows of the next even / odd slot; chunk entries are handled between segments of a run)
             auto slot = [&](auto qc, const int s, float2& xcur) {
                 constexpr int Q = decltype(qc)::value;
-                if ((s & (CR - 1)) == 0 && s > 0) {
-                    // entering a chunk: its DMA (and every older one) must have landed; the ring slot that
-                    // just became free is refilled NR - 1 chunks ahead
-                    const int ch = s >> LOG_CR;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
-                }
                 const float* rp = rec_ptr(s);                                     // wave-uniform -> broadcast reads
                 const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                 const float w0 = head.y, w1 = head.z;
@@ -457,13 +451,28 @@ __global__ __launch_bounds__(kThreads) void fc_forward_factored_kernel(
                     constexpr int Q = decltype(qc)::value;
                     int s = ro[Q];
                     const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
-                    for (; s + 1 < run_end; s += 2) {
-                        slot(qc, s, xa);
-                        slot(qc, s + 1, xb);
-                    }
-                    if (s < run_end) {      // odd tail of the run: rotate the two prefetch registers
-                        slot(qc, s, xa);
-                        const float2 t = xa; xa = xb; xb = t;
+                    while (s < run_end) {
+                        const int m = s & (CR - 1);
+                        if (m == 0 && s > 0) {
+                            // entering a chunk: its DMA (and every older one) must have landed; the ring slot that
+                            // just became free is refilled NR - 1 chunks ahead
+                            const int ch = s >> LOG_CR;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                        }
+                        const int stop = min(run_end, s - m + CR);
+                        if ((s & 1) && s < stop) {
+                            slot(qc, s, xb);
+                            ++s;
+                        }
+                        for (; s + 1 < stop; s += 2) {
+                            slot(qc, s, xa);
+                            slot(qc, s + 1, xb);
+                        }
+                        if (s < stop) {
+                            slot(qc, s, xa);
+                            ++s;
+                        }
                     }
                 });
             }

@@ -283,20 +283,15 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
             for (int f = 0; f < F; ++f) { clo[j][f] = f32x2{0.f, 0.f}; chi[j][f] = clo[j][f]; }
         float2 xq[2][2] = {{px[0][0], px[0][1]}, {px[1][0], px[1][1]}};
 
-        // one run of one stream: lo += w0 z, hi += w1 z with z_f = ph_f * x~_f over the slots [s, run_end)
-        auto gather_run = [&](const int j, int s, const int run_end, f32x2 (&lo)[F], f32x2 (&hi)[F], float2& xa, float2& xb) {
+        // one run of one stream: lo += w0 z, hi += w1 z with z_f = ph_f * x~_f over the slots [s, run_end).  xe / xo hold the source
+        // rows of the next even / odd slot (a slot requests the row of slot + 2 into its own registers: no rotation at odd run
+        // ends).  The record ring's events -- a chunk is entered, the look-ahead is about to leave the chunk -- are handled
+        // between SEGMENTS of the run, so that the slots themselves carry no checks.
+        auto gather_run = [&](const int j, int s, const int run_end, f32x2 (&lo)[F], f32x2 (&hi)[F], float2& xe, float2& xo) {
             const float* const ring = ring_of(j);
             const int nslots = end[j] - beg[j];
             const int nch = (nslots + CR - 1) >> LOG_CR;
             auto slot = [&](const int s_, float2& xcur) {
-                if ((s_ & (CR - 1)) == 0 && s_ > 0) {
-                    // entering a chunk: the chunk before it is consumed, its ring slot is refilled nr - 1 chunks ahead
-                    const int ch = s_ >> LOG_CR;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ch - 1 + nr < nch) dma_chunk(j, beg[j], ch - 1 + nr);
-                }
-                if (nr == 2 && ((s_ + 2) & (CR - 1)) < 1)       // the look-ahead below enters a chunk issued at the last chunk entry
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const float* rp = rec_ptr(ring, s_);
                 const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
                 const int n2 = __float_as_int(rec_ptr(ring, min(s_ + 2, nslots - 1))[3]);
@@ -323,13 +318,32 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
 #pragma unroll
                 for (int f = 0; f < F; ++f) hi[f] = __builtin_elementwise_fma(w1v, z[f], hi[f]);
             };
-            for (; s + 1 < run_end; s += 2) {
-                slot(s, xa);
-                slot(s + 1, xb);
-            }
-            if (s < run_end) {      // odd tail of the run: rotate the two prefetch registers
-                slot(s, xa);
-                const float2 t = xa; xa = xb; xb = t;
+            while (s < run_end) {
+                const int m = s & (CR - 1);
+                if (m == 0 && s > 0) {
+                    // entering a chunk: the chunk before it is consumed, its ring slot is refilled nr - 1 chunks ahead
+                    const int ch = s >> LOG_CR;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ch - 1 + nr < nch) dma_chunk(j, beg[j], ch - 1 + nr);
+                }
+                int stop = min(run_end, s - m + CR);                  // the end of this chunk
+                if (nr == 2) {
+                    // the look-ahead of position CR - 2 enters a chunk requested at the last chunk entry
+                    if (m == CR - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (m < CR - 2) stop = min(stop, s - m + CR - 2);
+                }
+                if ((s & 1) && s < stop) {
+                    slot(s, xo);
+                    ++s;
+                }
+                for (; s + 1 < stop; s += 2) {
+                    slot(s, xe);
+                    slot(s + 1, xo);
+                }
+                if (s < stop) {
+                    slot(s, xe);
+                    ++s;
+                }
             }
         };
 
