@@ -320,7 +320,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half_kernel(
     }
 }
 
-template <int T>
+// HALVES: the kept slabs hold the data kernel's own halves (BwdArgs::dump_halves): the rows are regrouped, not converted, and the
+// registers that frees hold a second slab row in flight.
+template <int T, bool HALVES>
 __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ hdump, float2* __restrict__ ggwp /* [P][F][KP][IP] */,
     const BwdArgs a, const int F, const int B, const int KV /* valid k entries, R*O */) {
@@ -373,65 +375,90 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
 
     const int nchunk = KP / 4;                     // chunks of four k entries; a lane holds chunks lane and lane + 64 of its vertex's row
     // registers one slab ahead: my vertex's row of H (fp32) and the scales behind the slab
-    float4 pv[2][2];
-    float ps = 1.f, pinv = 1.f, pt = 1.f, pit = 1.f;
-    float2 xv = make_float2(0.f, 0.f);
-    auto prefetch = [&](const int tile) {
-        const float* sl = hdump + ((size_t)tile * F + f) * a.slab_stride;
+    // Registers one slab ahead: my vertex's row of H and the scales behind the slab.  (A second set, two slabs ahead, does not
+    // fit the 128 registers -- and would not pay: with the rows of ONE tile re-read from L2 all the time, FC_DEBUG_BWD=16, the
+    // kernel takes 73.0 instead of 74.5 us; it does not wait for HBM.)
+    struct Ahead {
+        float4 pv[2][2];
+        float ps, pinv, pt, pit;
+        float2 xv;
+    };
+    Ahead ahead0;
+    auto prefetch = [&](const int tile, Ahead& q) {
+        const float* sl = hdump + ((size_t)((a.dbg & 16) ? (int)blockIdx.x : tile) * F + f) * a.slab_stride;      // (development: bit 4 -- always my first tile's rows, from L2)
         const float* row = sl + wave * KD;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int c = lane + 64 * cc;
             if (c < nchunk) {
-                pv[cc][0] = *reinterpret_cast<const float4*>(row + 8 * c);          // (re, im) of k = 4c, 4c+1
-                pv[cc][1] = *reinterpret_cast<const float4*>(row + 8 * c + 4);      // k = 4c+2, 4c+3
+                q.pv[cc][0] = *reinterpret_cast<const float4*>(row + 8 * c);          // (re, im) of k = 4c, 4c+1
+                q.pv[cc][1] = *reinterpret_cast<const float4*>(row + 8 * c + 4);      // k = 4c+2, 4c+3
             }
         }
         const float* tail = sl + a.slab_floats;             // [16] s_v, [16] 1/s_v, [IP] t, [IP] 1/t
-        ps = tail[wave];
-        pinv = tail[kTile + wave];
-        pt = lane < IP ? tail[2 * kTile + lane] : 1.f;
-        pit = tail[2 * kTile + IP + i0 + fr];
+        q.ps = tail[wave];
+        q.pinv = tail[kTile + wave];
+        q.pt = lane < IP ? tail[2 * kTile + lane] : 1.f;
+        q.pit = tail[2 * kTile + IP + i0 + fr];
         const int j = item_vertex(tile, wave, a.nv_full, a.parts_log2, a.N);
-        xv = (j < a.N && lane < I) ? gx_[(size_t)j * I + lane] : make_float2(0.f, 0.f);
+        q.xv = (j < a.N && lane < I) ? gx_[(size_t)j * I + lane] : make_float2(0.f, 0.f);
     };
-    if (blockIdx.x < a.ntiles) prefetch(blockIdx.x);
-    int buf = 0;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+    {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) { ahead0.pv[cc][0] = z4; ahead0.pv[cc][1] = z4; }
+        ahead0.ps = ahead0.pinv = ahead0.pt = ahead0.pit = 1.f;
+        ahead0.xv = make_float2(0.f, 0.f);
+    }
+    const int tile_step = gridDim.x;
+    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x, ahead0);
+    auto one_tile = [&](const int tile, Ahead& q, const int buf) {
         lds_f16* const img = img0 + buf * kTile * KSI;
         lds_f16* const xb = xb0 + buf * 6 * xplane;
-        const float2 xt = cmul(xv, unit_power(unit_conj(xv), m));     // rotated feature of my source row
-        const float it = pit;
+        const float2 xt = cmul(q.xv, unit_power(unit_conj(q.xv), m));     // rotated feature of my source row
+        const float it = q.pit;
         {   // ---- my vertex's row of H: scale, split, store plane-major
-            const float s = ps;
+            const float s = q.ps;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const int c = lane + 64 * cc;
                 if (c < nchunk) {
-                    float4 v0 = pv[cc][0], v1 = pv[cc][1];
+                    float4 v0 = q.pv[cc][0], v1 = q.pv[cc][1];
                     // entries past the R*O valid ones were never written by the data kernel
                     if (4 * c + 0 >= KV) { v0.x = 0.f; v0.y = 0.f; }
                     if (4 * c + 1 >= KV) { v0.z = 0.f; v0.w = 0.f; }
                     if (4 * c + 2 >= KV) { v1.x = 0.f; v1.y = 0.f; }
                     if (4 * c + 3 >= KV) { v1.z = 0.f; v1.w = 0.f; }
-                    f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
-                    split_halves2(f32x2{v0.x, v0.y}, s, h0, l0);
-                    split_halves2(f32x2{v0.z, v0.w}, s, h1, l1);
-                    split_halves2(f32x2{v1.x, v1.y}, s, h2, l2);
-                    split_halves2(f32x2{v1.z, v1.w}, s, h3, l3);
                     lds_f16* p = img + wave * KSI + 4 * c;
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    typedef __attribute__((address_space(3))) h4 lds_h4;
-                    *(lds_h4*)(p) = h4{h0.x, h1.x, h2.x, h3.x};                 // re_hi
-                    *(lds_h4*)(p + KP) = h4{l0.x, l1.x, l2.x, l3.x};            // re_lo
-                    *(lds_h4*)(p + 2 * KP) = h4{h0.y, h1.y, h2.y, h3.y};        // im_hi
-                    *(lds_h4*)(p + 3 * KP) = h4{l0.y, l1.y, l2.y, l3.y};        // im_lo
+                    if constexpr (HALVES) {
+                        // the slab holds the data kernel's own halves, (hi.re, hi.im | lo.re, lo.im) per entry: regroup plane-major
+                        const uint32_t k0h = __float_as_uint(v0.x), k0l = __float_as_uint(v0.y), k1h = __float_as_uint(v0.z), k1l = __float_as_uint(v0.w);
+                        const uint32_t k2h = __float_as_uint(v1.x), k2l = __float_as_uint(v1.y), k3h = __float_as_uint(v1.z), k3l = __float_as_uint(v1.w);
+                        constexpr uint32_t kLow = 0x05040100u, kHigh = 0x07060302u;      // (b.lo16, a.lo16) / (b.hi16, a.hi16) of perm(a, b)
+                        typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+                        *(lds_u32x2*)(p) = u32x2{__builtin_amdgcn_perm(k1h, k0h, kLow), __builtin_amdgcn_perm(k3h, k2h, kLow)};                 // re_hi
+                        *(lds_u32x2*)(p + KP) = u32x2{__builtin_amdgcn_perm(k1l, k0l, kLow), __builtin_amdgcn_perm(k3l, k2l, kLow)};            // re_lo
+                        *(lds_u32x2*)(p + 2 * KP) = u32x2{__builtin_amdgcn_perm(k1h, k0h, kHigh), __builtin_amdgcn_perm(k3h, k2h, kHigh)};      // im_hi
+                        *(lds_u32x2*)(p + 3 * KP) = u32x2{__builtin_amdgcn_perm(k1l, k0l, kHigh), __builtin_amdgcn_perm(k3l, k2l, kHigh)};      // im_lo
+                    } else {
+                        f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+                        split_halves2(f32x2{v0.x, v0.y}, s, h0, l0);
+                        split_halves2(f32x2{v0.z, v0.w}, s, h1, l1);
+                        split_halves2(f32x2{v1.x, v1.y}, s, h2, l2);
+                        split_halves2(f32x2{v1.z, v1.w}, s, h3, l3);
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(3))) h4 lds_h4;
+                        *(lds_h4*)(p) = h4{h0.x, h1.x, h2.x, h3.x};                 // re_hi
+                        *(lds_h4*)(p + KP) = h4{l0.x, l1.x, l2.x, l3.x};            // re_lo
+                        *(lds_h4*)(p + 2 * KP) = h4{h0.y, h1.y, h2.y, h3.y};        // im_hi
+                        *(lds_h4*)(p + 3 * KP) = h4{l0.y, l1.y, l2.y, l3.y};        // im_lo
+                    }
                 }
             }
         }
         if (lane < IP) {   // ---- second operand: xt / s_v * t[i], halves, planes [i][vertex]
             f16x2 hi, lo;
-            split_halves2(f32x2{xt.x, xt.y}, pinv * pt, hi, lo);
+            split_halves2(f32x2{xt.x, xt.y}, q.pinv * q.pt, hi, lo);
             lds_f16* p = xb + lane * kXbStride + wave;
             p[0] = hi.x;
             p[xplane] = lo.x;
@@ -440,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
             p[4 * xplane] = -hi.y;
             p[5 * xplane] = -lo.y;
         }
-        if (tile + gridDim.x < a.ntiles) prefetch(tile + gridDim.x);      // the next slab's rows fly during the MFMAs below
+        if (tile + tile_step < a.ntiles) prefetch(tile + tile_step, q);      // the next slab's rows fly during the MFMAs below
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
@@ -479,7 +506,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    
+    };
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += tile_step, buf ^= 1) one_tile(tile, ahead0, buf);
 
     // flush my gW partial
 #pragma unroll
@@ -540,9 +570,16 @@ static int launch_backward_filter(const float2* x, const float* hdump, float2* g
     static bool ok_half2[kMaxDevices] = {}, ok_half[kMaxDevices] = {}, ok_f32[kMaxDevices] = {};      // per T (this function is a template)
     if (p.fhalf && half2) {
         const size_t lds2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
-        if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T>), lds2, ok_half2)) return FC_ERR_LAUNCH;
-        hipLaunchKernelGGL(fc_backward_filter_half2_kernel<T>, dim3(p.P, p.F), dim3(kThreads), lds2, stream, x, hdump, gwp, a, p.F, d->B,
-                           d->R * d->O);
+        static bool ok_half2h[kMaxDevices] = {};
+        if (a.dump_halves) {
+            if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T, true>), lds2, ok_half2h)) return FC_ERR_LAUNCH;
+            hipLaunchKernelGGL((fc_backward_filter_half2_kernel<T, true>), dim3(p.P, p.F), dim3(kThreads), lds2, stream, x, hdump, gwp, a, p.F,
+                               d->B, d->R * d->O);
+        } else {
+            if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half2_kernel<T, false>), lds2, ok_half2)) return FC_ERR_LAUNCH;
+            hipLaunchKernelGGL((fc_backward_filter_half2_kernel<T, false>), dim3(p.P, p.F), dim3(kThreads), lds2, stream, x, hdump, gwp, a, p.F,
+                               d->B, d->R * d->O);
+        }
     } else if (p.fhalf) {
         if (!allow_full_lds(reinterpret_cast<const void*>(fc_backward_filter_half_kernel<T>), p.lds_filter, ok_half)) return FC_ERR_LAUNCH;
         hipLaunchKernelGGL(fc_backward_filter_half_kernel<T>, dim3(p.P, p.F), dim3(kThreads), p.lds_filter, stream, x, hdump, gwp, a,

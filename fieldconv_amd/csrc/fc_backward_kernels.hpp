@@ -55,10 +55,14 @@ struct BwdArgs {
     int tails;           // 1: every slab is followed by the scales the half-precision filter kernel needs:
                          // [16] s_v, [16] 1/s_v (the data kernel's vertex scales), [IP] t[i], [IP] 1/t[i] (column scales
                          // of x~[v][i] / s_v over the tile's vertices)
+    int dump_halves;     // 1: a kept slab holds, per complex entry, the data kernel's own split -- (hi.re, hi.im | lo.re, lo.im) halves,
+                         // 8 bytes like the fp32 pair -- so that the half2 filter-gradient kernel permutes instead of converting;
+                         // 0: fp32 pairs (fp32 and single-half modes, the LDS-staged filter kernel)
     int nt_dump;         // 1: the H slabs go out with non-temporal stores (dumps that do not fit the Infinity Cache beside the rest:
                          // 244 MB at config 2 would sweep the cotangent rows and the filter out of L2 on their way; a dump that
                          // fits -- 80 MB on a FAUST-sized mesh -- is better left cached for the filter-gradient kernel)
-    int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA
+    int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA, bit3 skip the slab dump,
+                         // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump
 };
 
 template <int R, int B>
@@ -330,12 +334,14 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
-                                if (lane < O && !(a.dbg & 8)) {
-                                    if (a.nt_dump) __builtin_nontemporal_store(h[r][ff], reinterpret_cast<f32x2*>(dst2) + d0);
-                                    else dst2[d0] = make_float2(h[r][ff].x, h[r][ff].y);
-                                }
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
+                                if (lane < O && !(a.dbg & 8)) {
+                                    f32x2 kept = h[r][ff];
+                                    if (a.dump_halves) kept = f32x2{__builtin_bit_cast(float, hi), __builtin_bit_cast(float, lo)};
+                                    if (a.nt_dump) __builtin_nontemporal_store(kept, reinterpret_cast<f32x2*>(dst2) + d0);
+                                    else dst2[d0] = make_float2(kept.x, kept.y);
+                                }
                                 split_pair_store(row, o0, hi, lo, lane, mg.split);
                                 o0 += mg.split * mg.KI;
                                 d0 += O;
@@ -495,6 +501,8 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
     a.tails = p.fhalf;
+    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    a.dump_halves = (p.fhalf && p.gd.split == 2 && !staged) ? 1 : 0;
     a.nt_dump = p.hdump_bytes > ((size_t)192 << 20) ? 1 : 0;
     static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
