@@ -411,8 +411,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
         ahead0.xv = make_float2(0.f, 0.f);
     }
     const int tile_step = gridDim.x;
+    Stamper stamp{(a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + wave * 256 : nullptr, 0};
+    stamp.realtime(29);
+    stamp(28);
     if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x, ahead0);
     auto one_tile = [&](const int tile, Ahead& q, const int buf) {
+        stamp(10);
         lds_f16* const img = img0 + buf * kTile * KSI;
         lds_f16* const xb = xb0 + buf * 6 * xplane;
         const float2 xt = cmul(q.xv, unit_power(unit_conj(q.xv), m));     // rotated feature of my source row
@@ -456,6 +460,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
                 }
             }
         }
+        stamp(1);
         if (lane < IP) {   // ---- second operand: xt / s_v * t[i], halves, planes [i][vertex]
             f16x2 hi, lo;
             split_halves2(f32x2{xt.x, xt.y}, q.pinv * q.pt, hi, lo);
@@ -468,8 +473,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
             p[5 * xplane] = -lo.y;
         }
         if (tile + tile_step < a.ntiles) prefetch(tile + tile_step, q);      // the next slab's rows fly during the MFMAs below
+        stamp(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        stamp(2);
 
         if (!(a.dbg & 4)) {
             // second operand, once per tile: [hi; hi] from the hi planes in every lane group, [lo; 0] from the lo planes in
@@ -509,7 +516,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
     
     };
     int buf = 0;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += tile_step, buf ^= 1) one_tile(tile, ahead0, buf);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += tile_step, buf ^= 1) {
+        one_tile(tile, ahead0, buf);
+        stamp(3);
+    }
+    stamp(30);
+    stamp.realtime(31);
 
     // flush my gW partial
 #pragma unroll

@@ -61,6 +61,7 @@ struct BwdArgs {
     int nt_dump;         // 1: the H slabs go out with non-temporal stores (dumps that do not fit the Infinity Cache beside the rest:
                          // 244 MB at config 2 would sweep the cotangent rows and the filter out of L2 on their way; a dump that
                          // fits -- 80 MB on a FAUST-sized mesh -- is better left cached for the filter-gradient kernel)
+    unsigned long long* stamps;   // development only (fc_debug_stamp_buffer): s_memtime stamps of the half2 filter kernel's workgroup (0, 0)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA, bit3 skip the slab dump,
                          // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump
 };
@@ -506,6 +507,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.nt_dump = p.hdump_bytes > ((size_t)192 << 20) ? 1 : 0;
     static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
+    a.stamps = debug_stamp_buffer();
     return a;
 }
 
