@@ -359,13 +359,15 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
         const int rt = my_idx + n * ct_waves;
         gw_h[n] = (rt * 16 < KP) ? rt * 16 : -1;
     }
-    // The MFMA's 32 k entries are the 16 vertices' hi halves followed by their lo halves (first operand) against
-    // [hi; hi] and [lo; 0] of the second: (A_hi | A_lo)(B_hi; B_hi) + (A_hi | A_lo)(B_lo; 0) = hi*hi + lo*hi + hi*lo, two
-    // full-rate v_mfma_f32_16x16x32_f16 per real product.  Lane groups 0/1 carry vertices 0-7 / 8-15 of the hi planes,
-    // groups 2/3 the same vertices of the lo planes.
+    // The MFMA's 32 k entries are the 16 vertices' hi halves followed by their lo halves (first operand) against [hi; hi] of
+    // the second: (A_hi | A_lo)(B_hi; B_hi) = hi*hi + lo*hi; the hi*lo products of the TWO real products that make one
+    // component share a third instruction, (a_hi | b_hi)[c_lo; d_lo] -- three full-rate v_mfma_f32_16x16x32_f16 per component,
+    // every k entry used.  Lane groups 0/1 carry vertices 0-7 / 8-15 of the first block, groups 2/3 the same vertices of the
+    // second.
     // A fragment: lane 4q+p of a lane group addresses vertex (vb + q), entries k0+4p .. +3 of its plane, and receives entry
     // k0 + lane%16 of the vertices vb .. vb+3; two reads (vb = 8*(g&1), +4) make the group's eight k entries.
     const int a_lane = (8 * (fq & 1) + ((lane & 15) >> 2)) * KSI + 4 * (lane & 3) + (fq >= 2 ? KP : 0);
+    const int a_lane_hi = (8 * (fq & 1) + ((lane & 15) >> 2)) * KSI + 4 * (lane & 3) + (fq >= 2 ? 2 * KP : 0);     // (re_hi | im_hi)
     const int b_lane = fr * kXbStride + 8 * (fq & 1);    // B fragment: plane[i = i0 + fr][vertices 8*(g&1) .. +7]
     const bool upper = fq >= 2;
 
@@ -479,34 +481,38 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
         stamp(2);
 
         if (!(a.dbg & 4)) {
-            // second operand, once per tile: [hi; hi] from the hi planes in every lane group, [lo; 0] from the lo planes in
-            // groups 0/1 and from the zero block in groups 2/3
+            // second operand, once per tile.  The MFMA's 32 k entries are two blocks of the 16 vertices; with H = a + ib and
+            // X = c + id in halves, re = a c + b d takes THREE instructions: (a_hi | a_lo)[c_hi; c_hi] + (b_hi | b_lo)[d_hi; d_hi] +
+            // (a_hi | b_hi)[c_lo; d_lo] -- the two hi*lo products share one -- and im = b c - a d likewise with [-d_lo; c_lo].
             const lds_f16* bp = xb + i0 * kXbStride + b_lane;
-            const lds_f16* bl = upper ? zeros : bp + xplane;
-            const int lstep = upper ? 0 : 2 * xplane;
-            const u32x4 c_hh = *reinterpret_cast<lds_u32x4*>(bp), c_l0 = *reinterpret_cast<lds_u32x4*>(bl);
-            const u32x4 d_hh = *reinterpret_cast<lds_u32x4*>(bp + 2 * xplane), d_l0 = *reinterpret_cast<lds_u32x4*>(bl + lstep);
-            const u32x4 nd_hh = *reinterpret_cast<lds_u32x4*>(bp + 4 * xplane), nd_l0 = *reinterpret_cast<lds_u32x4*>(bl + 2 * lstep);
+            const u32x4 c_hh = *reinterpret_cast<lds_u32x4*>(bp);
+            const u32x4 d_hh = *reinterpret_cast<lds_u32x4*>(bp + 2 * xplane);
+            const u32x4 nd_hh = *reinterpret_cast<lds_u32x4*>(bp + 4 * xplane);
+            const u32x4 lo_re = *reinterpret_cast<lds_u32x4*>(bp + (upper ? 3 : 1) * xplane);      // [c_lo; d_lo]
+            const u32x4 lo_im = *reinterpret_cast<lds_u32x4*>(bp + (upper ? 1 : 5) * xplane);      // [-d_lo; c_lo]
 #pragma unroll
             for (int n = 0; n < T; ++n) {
                 if (gw_h[n] >= 0) {
-                    // first operand: (hi | lo) of the real and of the imaginary part of H^T
+                    // first operand: (hi | lo) of the real and of the imaginary part of H^T, and (re_hi | im_hi)
                     const lds_f16* ap = img + a_lane + gw_h[n];
-                    u32x4 are, aim;
+                    const lds_f16* ah = img + a_lane_hi + gw_h[n];
+                    u32x4 are, aim, ahi;
                     {
                         const u32x2 r0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap)));
                         const u32x2 r1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * KSI)));
                         const u32x2 i0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP)));
                         const u32x2 i1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP + 4 * KSI)));
+                        const u32x2 h0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ah)));
+                        const u32x2 h1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ah + 4 * KSI)));
                         are = u32x4{r0.x, r0.y, r1.x, r1.y};
                         aim = u32x4{i0_.x, i0_.y, i1_.x, i1_.y};
+                        ahi = u32x4{h0_.x, h0_.y, h1_.x, h1_.y};
                     }
                     // H conj(X), H = a + ib, X = c + id:  re = a c + b d,  im = b c - a d
                     f32x4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
-                    re = mfma32h(are, c_l0, re);  re = mfma32h(are, c_hh, re);
-                    re = mfma32h(aim, d_l0, re);  re = mfma32h(aim, d_hh, re);
-                    im = mfma32h(aim, c_l0, im);  im = mfma32h(aim, c_hh, im);
-                    im = mfma32h(are, nd_l0, im); im = mfma32h(are, nd_hh, im);
+                    re = mfma32h(ahi, lo_re, re);  im = mfma32h(ahi, lo_im, im);
+                    re = mfma32h(are, c_hh, re);   im = mfma32h(aim, c_hh, im);
+                    re = mfma32h(aim, d_hh, re);   im = mfma32h(are, nd_hh, im);
                     gre[n] += re * it;
                     gim[n] += im * it;
                 }
