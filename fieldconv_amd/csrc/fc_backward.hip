@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
         ahead0.xv = make_float2(0.f, 0.f);
     }
     const int tile_step = gridDim.x;
-    Stamper stamp{(a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + wave * 256 : nullptr, 0};
+    Stamper stamp{(a.stamps && a.stamp_who == 2 && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + wave * 256 : nullptr, 0};
     stamp.realtime(29);
     stamp(28);
     if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x, ahead0);

@@ -61,7 +61,8 @@ struct BwdArgs {
     int nt_dump;         // 1: the H slabs go out with non-temporal stores (dumps that do not fit the Infinity Cache beside the rest:
                          // 244 MB at config 2 would sweep the cotangent rows and the filter out of L2 on their way; a dump that
                          // fits -- 80 MB on a FAUST-sized mesh -- is better left cached for the filter-gradient kernel)
-    unsigned long long* stamps;   // development only (fc_debug_stamp_buffer): s_memtime stamps of the half2 filter kernel's workgroup (0, 0)
+    unsigned long long* stamps;   // development only (fc_debug_stamp_buffer): s_memtime stamps of workgroup 0 of ONE of the two kernels
+    int stamp_who;                // 1: the data kernel stamps, 2: the half2 filter-gradient kernel (FC_STAMP_KERNEL=data|filter)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA, bit3 skip the slab dump,
                          // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump
 };
@@ -150,7 +151,11 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         }
     }
 
+    Stamper stamp{(a.stamps && a.stamp_who == 1 && blockIdx.x == 0) ? a.stamps + wave * 256 : nullptr, 0};       // development: in-kernel timeline
+    stamp.realtime(29);
+    stamp(28);
     for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
+        stamp(10);
         int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
         slot_range(tile + gridDim.x, nbeg, nend, nro);
         const int nslots = end - beg;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                     }
             }
 
+            stamp(0);
             // ---------------------------------------------------------------- slabs -> gxt_f -> gx
             float scale = 1.f, inv_scale = 1.f;
             if constexpr (SPLIT) {
@@ -353,7 +359,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             dst[a.slab_floats + wave] = scale;
                             dst[a.slab_floats + kTile + wave] = inv_scale;
                         }
+                        stamp(1);
                         __syncthreads();
+                        stamp(2);
                         if (a.tails && ff == 0 && e_active)     // bound of the filter kernel's second operand: |x[v][i]| / s_v
                             colmag[ev * 64 + ei] = sqrtf(exs.x * exs.x + exs.y * exs.y) * vs[kTile + ev] * 1.0000002f;
                     }
@@ -368,7 +376,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         }
                         store_partial(part, mg, it, kp, lane, acc_re, acc_im);
                     }
+                    stamp(3);
                     __syncthreads();
+                    stamp(4);
                     if constexpr (SPLIT) {
                         if (a.tails && ff == 0 && tid < IP) {
                             // power-of-two column scales, the same for every frequency of this group
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         eq += (float)m * (z.x * xtv.y - z.y * xtv.x);
                     }
                     // (`part` is next written after the following slab's first barrier)
+                    stamp(5);
                 }
             }
             if constexpr (SPLIT) vs = (vs == vscale) ? vscale + 2 * kTile : vscale;   // the next group writes the other buffer
@@ -428,6 +439,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 #pragma unroll
         for (int q = 0; q < R; ++q) ro[q] = nro[q];
     }
+    stamp(30);
+    stamp.realtime(31);
 }
 
 // Row stride (halves) of the half-precision filter kernel's image of a tile, [16 vertices][4 planes][KP]: a multiple of
@@ -508,6 +521,8 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
+    static const int who = [] { const char* e = getenv("FC_STAMP_KERNEL"); return (e && e[0] == 'd') ? 1 : 2; }();
+    a.stamp_who = who;
     return a;
 }
 

@@ -18,6 +18,7 @@ LABELS_FWD = {0: 'run gathered (2 targets)', 1: 'rows converted', 2: 'barrier: s
               5: 'last slab contracted, partials stored', 6: 'y stored', 10: 'tile start'}
 
 
+LABELS_DATA = {10: 'tile start', 0: 'gathered', 1: 'slab converted + kept', 2: 'barrier: slab', 3: 'contracted', 4: 'barrier: partials', 5: 'gx terms'}
 LABELS_FILTER = {10: 'tile start', 1: 'row regrouped', 0: 'x~ operand + next rows requested', 2: 'barrier', 3: 'MFMAs'}
 LABELS_BWD = {10: 'tile start', 0: 'run gathered', 1: 'rows converted', 2: 'barrier: slab full', 7: 'slab copied', 3: 'contracted',
               4: 'barrier: slab free', 5: 'gxt exchanged', 6: 'gx stored', 8: 'barrier: x-buf free', 9: 'padding zeroed'}
@@ -29,6 +30,8 @@ def main():
     ap.add_argument('--wave', type=int, nargs='*', default=[0, 7])
     ap.add_argument('--tiles', type=int, default=2)
     args = ap.parse_args()
+    if args.which in ('data', 'filter'):                # which of the two backward kernels stamps (read once by the library)
+        os.environ['FC_STAMP_KERNEL'] = args.which
     if not os.environ.get('FIELDCONV_HIP_LIB'):       # (a development variant built by tools/build_variants.sh)
         __graft_entry__.build()
     from fieldconv_amd import _lib
@@ -64,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     lib.fc_debug_stamp_buffer(None)
     st = buf.cpu().view(16, 256)
-    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_BWD
+    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_DATA if args.which == 'data' else LABELS_BWD
     t0 = min([int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0])] or [0])
     # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
     import collections
