@@ -1,6 +1,7 @@
 """In-kernel timeline of workgroup 0 of the record-driven kernels (development).
 
-    python tools/stamps.py [fwd|bwd] [--wave W ...]
+    python tools/stamps.py [fwd|bwd|data|filter] [--wave W ...]      (fwd: ring-major forward; bwd: the opt-in ring-major backward data
+                                                                      kernel, FC_BWD_RING=1; data / filter: the default backward kernels)
 
 Runs the config-2 layer a few times, then once with the stamp buffer armed (fc_debug_stamp_buffer), and prints for the
 chosen wavefronts the cycles between consecutive stamps, labelled as in the kernel source."""
