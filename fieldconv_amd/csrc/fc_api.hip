@@ -128,13 +128,14 @@ int fc_forward_geometric(const float* x, const float* geo_t, const fc_csr* by_ta
 
 int32_t fc_records_flags(const fc_dims* dims, int32_t record_driven) {
     if (!record_driven) return 0;
-    if (!fc::dims_valid(dims) || !fc::dims_supported(dims) || dims->R > 8 || !fc::rows_fit_32bit(dims)) return 1;
-    return fc::backward_ring_fits(dims) ? 3 : 1;
+    (void)dims;
+    return 1;
 }
 
 size_t fc_backward_workspace_bytes(const fc_dims* dims, int32_t records) {
     if (!fc::dims_supported(dims)) return 0;
-    return (records & 2) ? fc::backward_ring_workspace_bytes(dims) : fc::backward_workspace_bytes(dims);
+    (void)records;
+    return fc::backward_workspace_bytes(dims);
 }
 
 static int check_bwd(const float* x, const float* gy, const float* sten, const fc_csr* by_source, const float* wpk_bwd,
@@ -161,9 +162,7 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
     if (rc != FC_OK) return rc;
     if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
     if (dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
-    if (records & 2)
-        return fc::backward_ring_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims,
-                                           static_cast<hipStream_t>(stream));
+    (void)records;
     return fc::backward_data_impl(x, gy, rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, true,
                                   static_cast<hipStream_t>(stream));
 }
@@ -171,14 +170,14 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
 int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!x || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    if (records & 2) return fc::backward_ring_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+    (void)records;
     return fc::backward_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
 int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    if (records & 2) return fc::backward_ring_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+    (void)records;
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
@@ -197,8 +196,7 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
         return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
                                      params->g_spherical, params->g_phase, dims, stream);
     }
-    return (records & 2) ? fc::backward_ring_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream))
-                         : fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream));
+    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream));
 }
 
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,

@@ -56,22 +56,12 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
 int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float* sph, const float* phase, int ftype,
                             float* g_zonal, float* g_sph, float* g_phase, const fc_dims* d, hipStream_t stream);
 
-// ring-major backward path (fc_backward_ring.hpp / .hip)
-bool backward_ring_fits(const fc_dims* d);
-size_t packed_bwd_ring_image_floats(const fc_dims* d);
-size_t backward_ring_workspace_bytes(const fc_dims* d);
-int backward_ring_data_impl(const float* x, const float* gy, const float* rec, const fc_csr* g, const float* wpk, float* gx,
-                            void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
-int backward_ring_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
-int backward_ring_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
-
 // reduction of the filter-gradient partials fused with the parameter-gradient chain (fc_pack.hip); *_finish_params_impl
 // pick the partial layout of their kernel family
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
                             const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
                             const fc_dims* d, hipStream_t stream);
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream);
-int backward_ring_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
 

@@ -10,7 +10,6 @@
 #include "fc_kernels.hpp"
 #include "fc_tile.hpp"
 #include "fc_forward_ring.hpp"
-#include "fc_backward_ring.hpp"
 
 namespace fc {
 
@@ -51,8 +50,6 @@ struct PackArgs {
     unsigned blocks_f;       // workgroups that write the forward image; the rest write the backward image
     int ring_f;              // forward image in ring-major layout (fc_forward_ring.hpp): one slab of planes per RING,
                              // k = f*KI + i inside it, instead of one per frequency with k = r*KI + i
-    int ring_b;              // backward image in the ring-major block layout of fc_backward_ring.hpp (geometry: gbr)
-    BrGeom gbr;
 };
 
 constexpr int kPackThreads = 256;
@@ -124,50 +121,6 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
     const unsigned blk = is_bwd ? blockIdx.x - a.blocks_f : blockIdx.x;
     const MmaGeom& g = is_bwd ? a.gb : a.gf;
     float* const img = is_bwd ? bwd : fwd;
-    if (is_bwd && a.ring_b) {
-        // ring-major backward image (fc_backward_ring.hpp): workgroup = (row i, ring q); [IP] inverse row scales, then
-        // [R][4 planes][BT blocks][IP][32] halves; block boff[f] + s holds conj(W[o,i,q,f]) / F at the slab entries
-        // k = 32 (kb0[f] + s) + kk that belong to frequency f (o = k - f*KI < O), zeros elsewhere
-        __shared__ float redb[kPackThreads / kWave];
-        const BrGeom& gb = a.gbr;
-        const int i = blk / a.R, q = blk - i * a.R;
-        auto entry = [&](const int o, const int r, const int f, const bool with_phase) {
-            if (i >= a.I) return make_float2(0.f, 0.f);
-            const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!with_phase && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.I, o, i, r, f)
-                                         : w[(((size_t)o * a.I + i) * a.R + r) * a.F + f];
-            const float sc = 1.f / (float)a.F;
-            return make_float2(v.x * sc, -v.y * sc);
-        };
-        float mx = row_max2<FROM_PARAMS>(w, zonal, sph, a, true, i);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-        if ((threadIdx.x & 63) == 0) redb[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        mx = sqrtf(fmaxf(fmaxf(redb[0], redb[1]), fmaxf(redb[2], redb[3]))) * 1.0000002f;
-        float scale, inv;
-        split_scale(mx, scale, inv);
-        if (threadIdx.x == 0 && q == 0) img[i] = inv;
-        _Float16* const planes = reinterpret_cast<_Float16*>(img + gb.IP);
-        const size_t plane = (size_t)gb.BT * gb.IP * 32;
-        for (int idx = threadIdx.x; idx < gb.BT * 32; idx += kPackThreads) {
-            const int bi = idx >> 5, kk = idx & 31;
-            int f = 0;
-            for (int ff = 0; ff < a.F; ++ff)
-                if (bi >= gb.boff[ff] && bi < gb.boff[ff] + gb.nb[ff]) f = ff;
-            const int o = 32 * (gb.kb0[f] + bi - gb.boff[f]) + kk - f * gb.KI;
-            float2 v = make_float2(0.f, 0.f);
-            if (o >= 0 && o < a.O) v = entry(o, q, f, true);
-            _Float16 rh, rl, ih, il;
-            split_halves(v.x * scale, rh, rl);
-            split_halves(v.y * scale, ih, il);
-            _Float16* p = planes + (size_t)q * 4 * plane + ((size_t)bi * gb.IP + i) * 32 + kk;
-            p[0] = rh;
-            p[plane] = rl;
-            p[2 * plane] = ih;
-            p[3 * plane] = il;
-        }
-        return;
-    }
     if (!g.split) {
         const size_t j = (size_t)blk * kPackThreads + threadIdx.x;
         if (j >= (size_t)a.F * 2 * g.MP * g.KP) return;
@@ -224,10 +177,8 @@ size_t packed_filter_floats_fwd(const fc_dims* d, int records) {
     if (ring_forward_image(d, records)) return packed_ring_image_floats(d->O, 2 * d->B + 1, d->I, d->R, split_mode());
     return packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, split_mode());
 }
-// records bit 1: the ring-major backward image (the caller got the bit from fc_backward_image_flags for the dims of the
-// backward launch)
 size_t packed_filter_floats_bwd(const fc_dims* d, int records) {
-    if (records & 2) return packed_bwd_ring_image_floats(d);
+    (void)records;
     return packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, split_mode());
 }
 
@@ -237,12 +188,10 @@ static int launch_pack(const float* w_eff, const float* zonal, const float* sph,
     PackArgs a;
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
     a.ring_f = ring_forward_image(d, records & 1) ? 1 : 0;
-    a.ring_b = (records & 2) ? 1 : 0;
-    a.gbr = br_geom(d->I, d->O, d->R, a.F);
     a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
     a.blocks_f = wpk_fwd ? pack_blocks(a.gf, a.ring_f ? a.R : a.F) : 0u;                 // wpk_fwd == NULL: backward image only
-    const unsigned blocks_b = a.ring_b ? (unsigned)(a.gbr.IP * a.R) : pack_blocks(a.gb, a.F);
+    const unsigned blocks_b = pack_blocks(a.gb, a.F);
     const unsigned blocks = a.blocks_f + (wpk_bwd ? blocks_b : 0u);                       // wpk_bwd == NULL: forward image only
     if (blocks == 0) return FC_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,

@@ -31,8 +31,6 @@ MODES = {
     'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
-    'ring_major_backward': {'FC_BWD_RING': '2'},         # the opt-in ring-major backward kernels (32-vertex tiles, DMA-fed filter kernel)
-    'ring_major_backward_with_roles': {'FC_BWD_RING': '2', 'FC_BWD_ROLES': '1'},   # ... gathering and contracting wavefronts (band limit <= 2)
     'separate_finish_kernels': {'FC_SPLIT_FINISH': '1'},   # fc_backward_finish + fc_filter_param_grads instead of the fused launch
     'no_half_tiles': {'FC_HALF_TILES': '0'},
     'half_tiles_in_the_backward_pass_too': {'FC_HALF_TILES': '2'},

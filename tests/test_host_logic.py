@@ -48,7 +48,7 @@ def test_supported_query_and_sizes_need_no_gpu():
     assert lib.fc_packed_filter_floats_fwd(ctypes.byref(d), 0) == 48 + 5 * 2 * 48 * 288
     assert lib.fc_packed_filter_floats_bwd(ctypes.byref(d), 0) == 48 + 5 * 2 * 48 * 288
     assert lib.fc_backward_workspace_bytes(ctypes.byref(d), 0) > 0
-    assert lib.fc_records_flags(ctypes.byref(d), 0) == 0 and lib.fc_records_flags(ctypes.byref(d), 1) in (1, 3)
+    assert lib.fc_records_flags(ctypes.byref(d), 0) == 0 and lib.fc_records_flags(ctypes.byref(d), 1) == 1
     bad = _lib.FcDims(100, 10, 48, 48, 9, 2)
     assert lib.fc_supported(ctypes.byref(bad)) == 0
     wide = _lib.FcDims(100, 10, 128, 48, 6, 2)
@@ -333,26 +333,3 @@ def test_graph_views_keep_the_cached_graph_clean():
     assert get_graph(edges, bound, N) is view and tuple(bound.shape) == (E, R, F) and torch.equal(bound.materialize(), sten)
     own = SupportGraph(edges, sten, N)                   # a graph of one's own may be changed directly
     assert own.restrict_targets(8).n_targets == 8
-
-
-def test_role_split_backward_kernel_reads_no_row_in_flight():
-    """fc_backward_roles.hpp counts its own loads (inline asm): no instruction hipcc generates may read a destination register
-    between the request and the kernel's wait.  tools/check_counted_loads.py compiles the source to ISA and checks every
-    instantiation the plan can select (band limit <= 2)."""
-    import importlib.util
-    import shutil
-    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
-        pytest.skip('no hipcc')
-    spec = importlib.util.spec_from_file_location('check_counted_loads', os.path.join(ROOT, 'tools', 'check_counted_loads.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    found = mod.kernels(mod.compile_isa(os.path.join('/tmp', 'fc_backward_ring.%d.s' % os.getpid())))
-    checked = 0
-    for (R, B), lines in found.items():
-        if B > 2:
-            continue
-        n, bad = mod.check(lines)
-        assert n == 16 and not bad, (R, B, n, bad[:5])
-        checked += 1
-    assert checked >= 6
-    os.remove(os.path.join('/tmp', 'fc_backward_ring.%d.s' % os.getpid()))

@@ -1,7 +1,6 @@
 """In-kernel timeline of workgroup 0 of the record-driven kernels (development).
 
-    python tools/stamps.py [fwd|bwd|data|filter] [--wave W ...]      (fwd: ring-major forward; bwd: the opt-in ring-major backward data
-                                                                      kernel, FC_BWD_RING=1; data / filter: the default backward kernels)
+    python tools/stamps.py [fwd|data|filter] [--wave W ...]      (fwd: ring-major forward; data / filter: the backward kernels)
 
 Runs the config-2 layer a few times, then once with the stamp buffer armed (fc_debug_stamp_buffer), and prints for the
 chosen wavefronts the cycles between consecutive stamps, labelled as in the kernel source."""
@@ -21,8 +20,6 @@ LABELS_FWD = {0: 'run gathered (2 targets)', 1: 'rows converted', 2: 'barrier: s
 
 LABELS_DATA = {10: 'tile start', 0: 'gathered', 1: 'slab converted + kept', 2: 'barrier: slab', 3: 'contracted', 4: 'barrier: partials', 5: 'gx terms'}
 LABELS_FILTER = {10: 'tile start', 1: 'row regrouped', 0: 'x~ operand + next rows requested', 2: 'barrier', 3: 'MFMAs'}
-LABELS_BWD = {10: 'tile start', 0: 'run gathered', 1: 'rows converted', 2: 'barrier: slab full', 7: 'slab copied', 3: 'contracted',
-              4: 'barrier: slab free', 5: 'gxt exchanged', 6: 'gx stored', 8: 'barrier: x-buf free', 9: 'padding zeroed'}
 
 
 def main():
@@ -68,7 +65,7 @@ def main():
     torch.cuda.synchronize()
     lib.fc_debug_stamp_buffer(None)
     st = buf.cpu().view(16, 256)
-    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_DATA if args.which == 'data' else LABELS_BWD
+    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_DATA
     t0 = min([int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0])] or [0])
     # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
     import collections
