@@ -57,7 +57,13 @@ def under_profiler():
     return bool(env.get('ROCP_TOOL_LIBRARIES')) or 'rocprof' in env.get('LD_PRELOAD', '')
 
 
-def build_native(force=False, verbose=False):
+def build_variant(name, extra_flags, verbose=False):
+    """Development: the same sources with extra compiler flags (-DFC_EXP_...) as _native/lib<name>.so, selected at run
+    time with FIELDCONV_HIP_LIB; the product library and its digest are untouched."""
+    return build_native(force=True, verbose=verbose, _variant=(os.path.join(OUT_DIR, 'lib%s.so' % name), list(extra_flags)))
+
+
+def build_native(force=False, verbose=False, _variant=None):
     """Compile every HIP source for gfx950 (one hipcc per source, in parallel) and link them into one
     shared library; returns its path."""
     if not force and not needs_build():
@@ -68,7 +74,8 @@ def build_native(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     digest = _source_digest()
     hipcc = _hipcc()
-    compile_flags = [f for f in FLAGS if f != '-shared']
+    compile_flags = [f for f in FLAGS if f != '-shared'] + (_variant[1] if _variant else [])
+    lib_path = _variant[0] if _variant else LIB_PATH
     objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(OUT_DIR, src.replace('.hip', '.%d.o' % os.getpid()))
@@ -82,7 +89,7 @@ def build_native(force=False, verbose=False):
         out, _ = proc.communicate()
         if proc.returncode != 0:
             errors.append(f'{src}:\n{out}')
-    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    tmp = lib_path + '.tmp.%d' % os.getpid()
     try:
         if errors:
             raise RuntimeError('hipcc failed:\n' + '\n'.join(errors))
@@ -90,15 +97,16 @@ def build_native(force=False, verbose=False):
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             raise RuntimeError('hipcc link failed:\n' + res.stdout)
-        os.replace(tmp, LIB_PATH)
-        with open(DIGEST_PATH + '.tmp.%d' % os.getpid(), 'w') as f:
-            f.write(digest)
-        os.replace(DIGEST_PATH + '.tmp.%d' % os.getpid(), DIGEST_PATH)
+        os.replace(tmp, lib_path)
+        if not _variant:
+            with open(DIGEST_PATH + '.tmp.%d' % os.getpid(), 'w') as f:
+                f.write(digest)
+            os.replace(DIGEST_PATH + '.tmp.%d' % os.getpid(), DIGEST_PATH)
     finally:
         for f in objs + [tmp]:
             if os.path.exists(f):
                 os.remove(f)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == '__main__':

@@ -26,11 +26,11 @@ static bool dims_supported(const fc_dims* d) {
     return forward_fits(d) && backward_fits(d);
 }
 
-// The factored kernels address feature rows with 32-bit byte offsets: N * C * 8 must stay below 4 GiB
-// (8 million vertices at 64 channels).
+// The factored kernels address feature rows with 32-bit byte offsets formed by a 24-bit multiply: N * C * 8 must stay
+// below 4 GiB (8 million vertices at 64 channels) and N below 2^24.
 static bool rows_fit_32bit(const fc_dims* d) {
     const uint64_t c = (uint64_t)(d->I > d->O ? d->I : d->O);
-    return (uint64_t)d->N * c * 8 < (1ull << 32);
+    return (uint64_t)d->N * c * 8 < (1ull << 32) && d->N < (1 << 24);
 }
 
 static unsigned long long* g_stamps = nullptr;

@@ -54,10 +54,12 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 }
 
 // Row gather with a 32-bit byte offset: base (wave-uniform, SGPR pair) + vertex * row bytes + lane part fits the
-// scalar-base form of global_load, one v_mad instead of a 64-bit multiply and add per slot.  The callers guarantee
-// N * C * 8 < 2^32 (checked on the host).
+// scalar-base form of global_load.  The offset is ONE v_mad_u32_u24 instead of v_mul_lo_u32 + v_add (measured: no visible
+// change -- the walks are not bound by their vector instructions, tools/ubench/walk.hip).  The callers guarantee
+// N * C * 8 < 2^32 and N < 2^24 (checked on the host, rows_fit_32bit).
 __device__ __forceinline__ float2 gather_row(const float2* __restrict__ base, int vertex, uint32_t row_bytes, uint32_t lane_bytes) {
-    const uint32_t off = (uint32_t)vertex * row_bytes + lane_bytes;
+    uint32_t off;        // (hipcc lowers __umul24 to v_and + v_mul_lo_u32: hence the instruction itself)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(vertex), "s"(row_bytes), "v"(lane_bytes));
     return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + off);
 }
 

@@ -76,3 +76,4 @@ if 'f' in which:
 if 'b' in which:
     print(f'FC_DEBUG={tag} {kind} bwd_data median/min us: %.1f %.1f' % timeit(bwd_data))
     print(f'FC_DEBUG={tag} {kind} bwd_filter median/min us: %.1f %.1f' % timeit(bwd_filter))
+    print('gx checksum: %.9e %.9e' % (gx.abs().double().sum().item(), gx[::97].real.double().sum().item()))
