@@ -116,6 +116,23 @@ def cpu_baseline(args, threads, shape=None, slab=4000):
                       f'{t_all:.1f} s'}
 
 
+def env_report():
+    """Every development switch of the package / the library / this script that is set in this process (fieldconv_amd/_env.py)."""
+    from fieldconv_amd import _env
+    return _env.active()
+
+
+def describe_kernels(graph, I, O, B):
+    """The library's own account of the kernels a FieldConv forward + backward over this graph launches (fc_describe_kernels)."""
+    import ctypes
+    from fieldconv_amd import _lib
+    from fieldconv_amd.functional import make_dims
+    buf = ctypes.create_string_buffer(1024)
+    kind = 2 if getattr(graph, 'geo_t', None) is not None else (1 if graph.factored else 0)
+    rc = _lib.load().fc_describe_kernels(ctypes.byref(make_dims(graph, I, O, B)), kind, buf, len(buf))
+    return buf.value.decode() if rc == 0 else f'fc_describe_kernels failed ({rc})'
+
+
 def child_run(args, env_extra, extra_args=(), dump=True):
     """The same workload in a child process (library switches are fixed per process); returns (json line, dumped y / gx)."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -201,21 +218,26 @@ def init_dist(dev, backend):
 
 SETTLE_SECONDS = 0.3
 PROTOCOL_NOTE = ('value / ms_per_step: literally the command line -- `warmup` untimed steps as the first GPU work of the process, fence, '
-                 '`steps` timed steps, fence.  `settled`: the same warmup + steps repeated after settled.extra_untimed_steps further '
-                 'untimed steps (~0.3 s of load), i.e. at the clock a training run lives at; reported beside it, never as value '
-                 '(--cold skips it)')
+                 '`steps` timed steps, fence, no instrumentation inside.  Per-kernel times (kernels, roofline): HIP events on every 4th '
+                 'launch in a separate pass of `steps` untimed steps straight behind the timed region.  `settled`: the same warmup + '
+                 'steps repeated after settled.extra_untimed_steps further untimed steps (~0.3 s of load), i.e. at the clock a training '
+                 'run lives at; reported beside it, never as value (--cold skips it)')
 
 
 def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, after_timed=None, settle=True):
     """-> (seconds for `steps` steps under the LITERAL protocol, max over ranks; info).
 
     The literal protocol -- `warmup` steps, fence, `steps` steps, fence, as the first GPU work of the process -- is the value
-    of record.  The MI355X's clock governor takes ~100 ms of sustained load to reach the clock it then holds
-    (tools/clock_trace.py: 2.0-2.1 GHz during the first 20 ms of work with a dip to 1.9 GHz after ~3 ms, 2.4 GHz from ~80 ms
-    on), so a 25-step run of 0.4 ms steps lies entirely inside that ramp.  With settle=True the same steps then keep the
-    device busy for SETTLE_SECONDS (untimed) and the protocol is repeated: info['settled'] = (seconds, extra untimed steps
-    before its warm-up) -- an extra, not the value.  before_timed() / after_timed(tag) bracket each timed region
-    (tag 'literal' / 'settled') for the per-kernel HIP events."""
+    of record and carries NO instrumentation.  The MI355X's clock governor takes ~100 ms of sustained load to reach the clock
+    it then holds (tools/clock_trace.py: 2.0-2.1 GHz during the first 20 ms of work with a dip to 1.9 GHz after ~3 ms,
+    2.4 GHz from ~80 ms on), so a 25-step run of 0.4 ms steps lies entirely inside that ramp.  With settle=True the same steps
+    then keep the device busy for SETTLE_SECONDS (untimed) and the protocol is repeated: info['settled'] = (seconds, extra
+    untimed steps before its warm-up) -- an extra, not the value.
+
+    Per-kernel HIP events (an event pair is two barrier packets, ~5 us of idle GPU) are taken in a separate INSTRUMENTED
+    pass of `steps` untimed steps straight behind each timed region (tags 'literal' / 'settled'): before_timed() arms the
+    events, after_timed(tag) harvests them.  The literal pass's instrumented steps are steps warmup+steps .. warmup+2*steps of
+    the process, i.e. still inside the clock ramp the literal region ran in."""
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -226,15 +248,18 @@ def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, a
         for _ in range(warmup):
             step()
         fence()
-        if before_timed is not None:
-            before_timed()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         elapsed = time.perf_counter() - t0
-        if after_timed is not None:
-            after_timed(tag)
+        if before_timed is not None:            # the instrumented pass: same steps, event pairs on a sample of the launches, untimed
+            before_timed()
+            for _ in range(steps):
+                step()
+            fence()
+            if after_timed is not None:
+                after_timed(tag)
         if use_dist:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             if backend == 'gloo':
@@ -252,7 +277,24 @@ def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, a
     n_settle = max(1, int(SETTLE_SECONDS / (literal / steps)))          # the same count on every rank (literal is the max over ranks)
     for _ in range(n_settle):
         step()
-    return literal, {'settled': (protocol('settled'), n_settle)}
+    return literal, {'settled': (protocol('settled'), n_settle + steps)}
+
+
+def run_identity(use_dist, dev, backend, local_rank, extra):
+    """What actually ran where: one record per rank (all-gathered), so that a multi-GPU line can be checked the first time an
+    8-GPU node produces one -- the communicator's size as RCCL sees it, the device every rank sat on, its share of the mesh."""
+    props = torch.cuda.get_device_properties(dev)
+    me = {'rank': dist.get_rank() if use_dist else 0, 'local_rank': local_rank, 'device': props.name,
+          'device_uuid': str(getattr(props, 'uuid', '')) or None, 'pci_bus_id': getattr(props, 'pci_bus_id', None),
+          'compute_units': props.multi_processor_count}
+    me.update(extra)
+    if not use_dist:
+        return {'backend': None, 'ranks': 1, 'per_rank': [me], 'distinct_devices': 1}
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, me)
+    ids = {(g_['device_uuid'] or g_['pci_bus_id'] or g_['local_rank']) for g_ in gathered}
+    return {'backend': dist.get_backend() + (' (= RCCL on ROCm)' if dist.get_backend() == 'nccl' else ''),
+            'ranks': dist.get_world_size(), 'per_rank': gathered, 'distinct_devices': len(ids)}
 
 
 def sum_over_ranks(value, use_dist, dev, backend):
@@ -333,8 +375,10 @@ def run_dp(args, world, rank, dev, use_dist, backend):
     elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
                                settle=not args.cold)
     E_total = sum_over_ranks(E, use_dist, dev, backend)
+    identity = run_identity(use_dist, dev, backend, dev.index, {'vertices': N, 'edges': E})
     if rank != 0:
         return None
+    from fieldconv_amd.graph import get_graph
     n_params = sum(p.numel() for p in params)
     # algorithmic bytes of every FieldConv of the network: (in, out) per layer
     F = 2 * B + 1
@@ -400,7 +444,9 @@ def run_dp(args, world, rank, dev, use_dist, backend):
                    'verts_per_gpu': N, 'edges_per_mesh_rank0': E, 'convs_per_step': n_convs, 'parameters': n_params,
                    'parallelism': 'single GPU (replica)' if world == 1 and not use_dist else
                                   f'data-parallel x{world}: one mesh per GPU, one bucketed all-reduce of {4 * buckets.flat.numel()} gradient '
-                                  f'bytes per step over RCCL'},
+                                  f'bytes per step over RCCL',
+                   'kernels': describe_kernels(get_graph(*pre(data)[:2], N), nf, nf, B), 'env': env_report()},
+        'ranks': identity,
         'roofline': roofline, 'kernels': per_kernel, 'cpu_baseline': cpu, 'settled': settled, 'protocol': PROTOCOL_NOTE,
     }
 
@@ -504,7 +550,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         if graph_step:
             return                          # a replayed graph runs no Python: the kernels are timed on eager steps afterwards
         kernel_timer.reset(pairs=4 * (args.steps // 3 + 1))
-        # every 4th launch of each kernel inside the timed region carries a HIP-event pair (every 3rd when the forward pass
+        # every 4th launch of each kernel in the instrumented pass carries a HIP-event pair (every 3rd when the forward pass
         # is two launches per step, so that interior and boundary launches are sampled alternately)
         kernel_timer.stride = 3 if split_fwd else 4
         kernel_timer.enabled = True
@@ -528,6 +574,44 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     ms_per_step = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps) / 1e6
+    # What the collectives cost a step: the same step with the three collectives taken out (halo rows left as they are, no
+    # gradient exchange, no all-reduce -- same kernels, same shapes), timed at the sustained clock like `settled`; the
+    # difference to the settled step is the communication a step does not hide (its host time included).
+    comm = None
+    if use_dist and not graph_step:
+        xl0 = torch.cat([x.detach(), torch.zeros(plan.n_halo, C, dtype=x.dtype, device=dev)]).requires_grad_(True)
+        gyl = gy if mesh_graph.n_targets == n_owned else torch.cat([gy, torch.zeros(n_local - n_owned, C, dtype=gy.dtype, device=dev)])
+        saved_hooks = (mesh_graph.on_gx, mesh_graph.forward_split)
+        mesh_graph.on_gx, mesh_graph.forward_split = None, None
+
+        def step_nocomm():
+            return torch.autograd.grad(conv(xl0, edges, sten), [xl0] + params, grad_outputs=gyl)
+        for _ in range(args.warmup + 5):
+            step_nocomm()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_nocomm()
+        torch.cuda.synchronize()
+        nocomm_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        mesh_graph.on_gx, mesh_graph.forward_split = saved_hooks
+        t = torch.tensor([nocomm_ms], dtype=torch.float64)
+        if backend == 'gloo':
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nocomm_ms = float(t.item())
+        ref_ms = (info['settled'][0] / args.steps * 1e3) if info['settled'] is not None else ms_per_step
+        comm = {'collectives_per_step': 3, 'step_without_collectives_ms': nocomm_ms,
+                'exposed_ms_per_step': ref_ms - nocomm_ms, 'relative_to': 'settled' if info['settled'] is not None else 'literal',
+                'halo_bytes_forward_rank0': plan.n_halo * C * 8, 'halo_bytes_backward_rank0': int(plan.send_idx.numel()) * C * 8,
+                'allreduce_bytes': 4 * buckets.flat.numel(),
+                'note': 'exposed = (step with halo exchange forward, transposed exchange backward, bucketed all-reduce) - (the same '
+                        'kernels without them), both at the sustained clock, max over ranks'}
+    identity = run_identity(use_dist, dev, backend, dev.index, {'owned_vertices': int(n_owned), 'halo_rows': 0 if plan is None else plan.n_halo,
+                                                                 'edges': E})
     prep_ms, prep_mallocs = measure_prep()
     if rank != 0:
         return None
@@ -558,7 +642,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     per_kernel = kernel_report(harvested.get('literal', {}))
     counters_meta, counters = committed_counters(list(per_kernel))
     for name, c in counters.items():
-        for key in ('mfma_busy', 'valu_busy', 'hbm_bytes_per_launch', 'hbm_read_bytes', 'hbm_write_bytes'):
+        for key in ('mfma_busy', 'valu_busy', 'valu_insts', 'salu_insts', 'hbm_bytes_per_launch', 'hbm_read_bytes', 'hbm_write_bytes'):
             if key in c:
                 per_kernel[name][key] = c[key]
     dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
@@ -569,9 +653,19 @@ def run_layer(args, world, rank, dev, use_dist, backend):
                     'avg_launch_ms': per_kernel[dom]['avg_ms'], 'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes'],
                     'mfma_busy': per_kernel[dom].get('mfma_busy'), 'valu_busy': per_kernel[dom].get('valu_busy'),
                     'counters': counters_meta,
-                    'note': 'HIP events inside the timed region of the literal protocol (every 4th launch).  Not HBM-bound: the '
-                            'kernels are bound by vector-instruction issue (valu_busy) with the matrix pipe and the memory system '
-                            'mostly idle; achieved = algorithmic bytes / launch time as SURVEY 8(d) prescribes'}
+                    'note': 'HIP events on every 4th launch in the instrumented pass straight behind the literal timed region (the timed '
+                            'region itself carries no events).  Not HBM-bound: the walks of the gathers pay for their vector arithmetic, '
+                            'their row fetches (one per ~28 cycles and CU whatever the cache level) and their record reads one after '
+                            'the other (tools/ubench/walk.hip, DESIGN 3.11), with the matrix pipe and HBM mostly idle; achieved = '
+                            'algorithmic bytes / launch time as SURVEY 8(d) prescribes'}
+        # the bound the kernels live under: of all vector instructions the dominant kernel issues, how many are the gather's
+        # own arithmetic (2 + 2B complex products and 2F ring updates per edge, packed: 2 instructions per complex product)
+        c = counters.get(dom, {})
+        if c.get('valu_insts'):
+            useful = E * ((2 + 2 * B) * 2 + 2 * F) if dom != 'fc_backward_filter' else None
+            roofline['issue'] = {'vector_insts_per_launch': c['valu_insts'], 'scalar_insts_per_launch': c.get('salu_insts'),
+                                 'gather_arithmetic_insts_per_launch': useful,
+                                 'useful_frac': (useful / c['valu_insts']) if useful else None, 'valu_busy': c.get('valu_busy')}
     settled = None
     if info['settled'] is not None:
         t_set, n_extra = info['settled']
@@ -596,7 +690,9 @@ def run_layer(args, world, rank, dev, use_dist, backend):
                    ('factored records' if factored else 'dense rows'),
                    'parallelism': 'single GPU' if world == 1 else f'vertex partition x{world}, one-hop halo over RCCL',
                    'halo_rows_rank0': 0 if plan is None else plan.n_halo,
-                   'step_launch': 'one HIP graph per step (BENCH_GRAPH_STEP=1)' if graph_step else 'eager'},
+                   'step_launch': 'one HIP graph per step (BENCH_GRAPH_STEP=1)' if graph_step else 'eager',
+                   'kernels': describe_kernels(mesh_graph, C, C, B), 'env': env_report()},
+        'ranks': identity, 'communication': comm,
         'roofline': roofline,
         'kernels': per_kernel,
         'hbm_frac_fwd_bwd': (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -698,14 +794,21 @@ def main():
 
     # Development switches of the library change what is computed (FC_DEBUG* skip whole phases): a benchmark line taken
     # with one of them set would be wrong or mislabelled, so it is refused outright.
-    bad = sorted(k_ for k_ in os.environ if k_.startswith('FC_DEBUG'))
+    from fieldconv_amd import _env
+    bad = sorted(k_ for k_ in os.environ if k_ in _env.WRONG_RESULTS)
     if bad:
         sys.exit('bench.py refuses to run with library debug switches set: ' + ', '.join(bad))
+    # ... and a name with one of our prefixes that nothing reads is a typo or the switch of a removed kernel: the line would
+    # claim a configuration that did not run.  The switches that ARE set travel in config.env.
+    bad = _env.unknown()
+    if bad:
+        sys.exit('bench.py: unknown switch(es) ' + ', '.join(bad) + ' (known: ' + ', '.join(sorted(_env.SWITCHES)) + ')')
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves.  Nothing in this process has touched the
-        # GPU yet (importing torch and parsing arguments do not), it never will, and the ranks are CHILD processes (no exec
-        # of a GPU-initialised process): rank 0's JSON line is relayed as our last stdout line, the exit code is the launcher's.
+        # GPU yet (importing torch and parsing arguments do not; the device count comes from sysfs), it never will, and the
+        # ranks are CHILD processes (no exec of a GPU-initialised process): rank 0's JSON line is relayed as our last stdout
+        # line, the exit code is the launcher's.
         sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -742,12 +845,32 @@ def main():
         dist.destroy_process_group()
 
 
+def visible_gpus():
+    """GPUs a child process will see, WITHOUT initialising the HIP runtime here (torch.cuda.device_count() is hipGetDeviceCount):
+    KFD topology nodes with SIMDs (CPUs are nodes without), narrowed by ROCR_/HIP_/CUDA_VISIBLE_DEVICES when set."""
+    import glob
+    n = 0
+    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            for line in open(path):
+                if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([t for t in v.split(',') if t.strip() != ''])
+            n = min(n, listed)
+    return n
+
+
 def self_launch(n):
     """Run `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child and relay
     its output; -> exit code.  Fewer visible devices than ranks: refused, unless BENCH_BACKEND=gloo (test rigs: ranks share
     devices, host-staged collectives)."""
     import socket
-    ndev = torch.cuda.device_count()                    # counts devices without creating a context
+    ndev = visible_gpus()                               # from sysfs and the *_VISIBLE_DEVICES variables: no HIP call in this process
     if ndev < n and os.environ.get('BENCH_BACKEND', 'nccl') != 'gloo':
         print(f'bench.py --gpus {n}: only {ndev} GPU(s) visible (RCCL needs one device per rank; BENCH_BACKEND=gloo shares devices '
               'for functional tests)', file=sys.stderr)

@@ -1,0 +1,53 @@
+"""Registry of the environment switches the package and its library read.
+
+Every switch is a development aid: it selects an older kernel family for an A/B run, switches a fusion off, or
+instruments a kernel.  None is needed for normal use.  The registry exists so that (a) a benchmark line can say which
+switches were set when it was taken and refuse names it does not know (a typo such as FC_MFMA_MODE=f32 must not silently
+benchmark the default), and (b) tests/test_host_logic.py can check that no switch is read anywhere without being listed here.
+"""
+import os
+
+SWITCHES = {
+    # ---- read by libfieldconv_hip.so (once per process)
+    'FC_MFMA': 'f32: fp32-MFMA contractions throughout; f16: single halves (reduced precision); default: split halves',
+    'FC_RING': '0: frequency-major forward kernels for every mesh size; 2: ring-major ones for every size',
+    'FC_RING_HALVES': '0: no half tiles in the last round of the ring-major forward kernel',
+    'FC_HALF_TILES': '0: no half tiles in the frequency-major kernels; 2: half tiles in the backward kernels too',
+    'FC_FILTER2': '0: the LDS-staged half-precision filter-gradient kernel instead of the register-fed one',
+    'FC_SPLIT_FINISH': '1: partial sums and parameter-gradient chain as two launches',
+    'FC_EDGE_PARTS_MAX': 'cap (log2) on the number of workgroups that share a tile on small meshes',
+    'FC_ECHO_WPV': 'wavefronts per vertex in the ECHO descriptor kernels (1, 2 or 4)',
+    'FC_STAMP_KERNEL': 'data | filter: which backward kernel writes in-kernel time stamps (tools/stamps.py)',
+    'FC_DEBUG': 'forward kernels: skip phases (WRONG RESULTS; refused by bench.py)',
+    'FC_DEBUG_BWD': 'backward kernels: skip phases (WRONG RESULTS; refused by bench.py)',
+    # ---- read by the Python package
+    'FIELDCONV_HIP_LIB': 'path of a prebuilt libfieldconv_hip.so (development variants, fieldconv_amd.build.build_variant)',
+    'FIELDCONV_DENSE': '1: FCPrecomp stencils through the dense-stencil kernels',
+    'FIELDCONV_NO_GEO': '1: 64-byte factored records in the forward pass instead of geometric ones',
+    'FIELDCONV_TORCH_GRAPH': '1: support graph built with torch ops instead of fc_graph_build',
+    'FIELDCONV_NO_EDGE_SPLIT': '1: no edge split on small meshes',
+    'FIELDCONV_EAGER_STENCIL': '1: FCPrecomp returns the dense (E,R,F) tensor',
+    'FIELDCONV_NO_FUSED_EPILOGUE': '1: residual add and modReLU as separate operators',
+    'FIELDCONV_SEPARATE_CALLS': '1: one foreign call per kernel instead of fc_forward_params / fc_backward_all',
+    # ---- read by bench.py only
+    'BENCH_BACKEND': 'gloo: several ranks share a device (test rigs); default nccl (= RCCL)',
+    'BENCH_FORCE_DIST': '1: run the partitioned / data-parallel code path with one rank',
+    'BENCH_FORWARD_OVERLAP': '1: interior targets under the forward halo exchange',
+    'BENCH_NO_OVERLAP': '1: gradient halo exchange not overlapped with the filter-gradient kernel',
+    'BENCH_GRAPH_STEP': '1: the partitioned step captured in one HIP graph',
+}
+
+PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')
+WRONG_RESULTS = ('FC_DEBUG', 'FC_DEBUG_BWD')
+
+
+def active(environ=None):
+    """{name: value} of the registered switches that are set."""
+    environ = os.environ if environ is None else environ
+    return {k: environ[k] for k in sorted(SWITCHES) if k in environ}
+
+
+def unknown(environ=None):
+    """Names with one of our prefixes that nothing reads (typos, switches of removed kernels)."""
+    environ = os.environ if environ is None else environ
+    return sorted(k for k in environ if k.startswith(PREFIXES) and k not in SWITCHES)

@@ -42,6 +42,7 @@ SIGNATURES = {
     'fc_debug_stamp_buffer': (None, [_vp]),
     'fc_status_string': (ctypes.c_char_p, [ctypes.c_int]),
     'fc_supported': (ctypes.c_int, [_DP]),
+    'fc_describe_kernels': (ctypes.c_int, [_DP, _c_int32, ctypes.c_char_p, ctypes.c_size_t]),
     'fc_shape_compiled': (ctypes.c_int, [_c_int32, _c_int32]),
     'fc_generic_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_generic_scatter': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),

@@ -1,4 +1,5 @@
 // extern "C" surface of libfieldconv_hip.so; see include/fieldconv_hip.h for the contract.
+#include <stdio.h>
 #include <stdlib.h>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
@@ -42,7 +43,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 6; }
+int fc_abi_version(void) { return 7; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -56,6 +57,16 @@ const char* fc_status_string(int s) {
 }
 
 int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0; }
+
+int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t buffer_bytes) {
+    if (!buffer || buffer_bytes < 2 || kind < 0 || kind > 2 || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
+    char fwd[256], bwd[384];
+    fc::describe_forward(dims, kind, fwd, sizeof(fwd));
+    fc::describe_backward(dims, kind != 0, bwd, sizeof(bwd));
+    snprintf(buffer, buffer_bytes, "%s; %s", fwd, bwd);
+    return FC_OK;
+}
 
 size_t fc_packed_filter_floats_fwd(const fc_dims* d, int32_t records) {
     if (!fc::dims_valid(d)) return 0;

@@ -1,5 +1,6 @@
 // FieldConv backward: filter-gradient kernel, the reductions, the fp32-MFMA instantiation of the data
 // kernel and the mode dispatch (data kernel: fc_backward_kernels.hpp).
+#include <stdio.h>
 #include "fc_backward_kernels.hpp"
 
 namespace fc {
@@ -628,6 +629,18 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
     if (need <= 6) return launch_backward_filter<6>(x2, hdump, gwp, a, p, d, stream);      // 64 channels x 6 rings: 24 row tiles over 4 wavefronts per column
     if (need <= kMaxGwTiles) return launch_backward_filter<kMaxGwTiles>(x2, hdump, gwp, a, p, d, stream);
     return FC_ERR_UNSUPPORTED;
+}
+
+// Which kernels a backward pass with these dims launches (fc_describe_kernels).
+void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
+    const BwdPlan p = plan_backward(d, split_mode());
+    const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
+    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d; %s; %s", records ? "records" : "dense rows", mode, p.ntiles,
+             1 << p.parts_log2,
+             p.fhalf ? (staged ? "fc_backward_filter_half_kernel (LDS-staged slabs)" : "fc_backward_filter_half2_kernel (register-fed rows)")
+                     : "fc_backward_filter_kernel (fp32 MFMA)",
+             "fc_backward_finish_params (fused sum + parameter chain)");
 }
 
 // Fixed-order sum of the per-workgroup filter-gradient partials left in the workspace.

@@ -1,4 +1,5 @@
 // FieldConv forward on per-edge records, ring-major kernels (fc_forward_ring.hpp): instantiation and launch.
+#include <stdio.h>
 #include "fc_forward_ring.hpp"
 #include "fc_forward_kernels.hpp"
 
@@ -21,6 +22,20 @@ bool forward_ring_fits(const fc_dims* d) {
     static const bool force = [] { const char* e = getenv("FC_RING"); return e && atoi(e) == 2; }();
     if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
     return force || (d->N + kTile - 1) / kTile > num_cus();
+}
+
+// Which kernel a forward launch with these dims takes (fc_describe_kernels); kind as in forward_impl.
+void describe_forward(const fc_dims* d, int kind, char* buf, size_t n) {
+    const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
+    const char* rec = kind == 2 ? "geometric records" : kind == 1 ? "factored records" : "dense rows";
+    if (kind != 0 && forward_ring_fits(d)) {
+        const RingPlan p = plan_ring(d->O, 2 * d->B + 1, d->I, split_mode());
+        snprintf(buf, n, "fc_forward_ring_kernel<%s,%s> (ring-major, 2 workgroups x 8 wavefronts per CU, %zu B LDS, %d record chunks)", rec,
+                 mode, p.lds, p.nr);
+    } else {
+        snprintf(buf, n, "%s<%s,%s> (frequency-major, 16 wavefronts per CU, parts=%d)", kind ? "fc_forward_factored_kernel" : "fc_forward_kernel",
+                 rec, mode, 1 << forward_parts_log2(d, kind));
+    }
 }
 
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {

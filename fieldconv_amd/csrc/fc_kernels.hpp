@@ -64,6 +64,9 @@ int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, s
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
+// one-line descriptions of the kernels a launch with these dims selects (fc_describe_kernels)
+void describe_forward(const fc_dims* d, int kind, char* buf, size_t n);
+void describe_backward(const fc_dims* d, int records, char* buf, size_t n);
 
 // FCPrecomp's area sums total[dst] += w[src] over the kept edges (csrc/fc_precomp.hip), shared with the fused build
 int precomp_area_sums(const int64_t* edges, const int32_t* keep, const float* w, float* total, int N, int E, hipStream_t s);

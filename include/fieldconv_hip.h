@@ -65,6 +65,11 @@ const char* fc_status_string(int status);
  * The operator is linear in the input channels and independent across output channels: wider layers are run as
  * channel blocks by the caller (fieldconv_amd/functional.py does). */
 int fc_supported(const fc_dims* dims);
+/* Which kernels a forward + backward pass with these dims launches in this process, as one line of text (kernel family,
+ * record kind, MFMA mode, tile counts): the library picks them from the dims, the device's CU count and the development
+ * switches it read from the environment, and a benchmark line should say what it timed.  kind: 0 dense rows, 1 factored
+ * records, 2 geometric records in the forward pass (factored ones in the backward pass).  No GPU work. */
+int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t buffer_bytes);
 
 /* ---- filter packing -------------------------------------------------------------------- *
  * W_eff (O,I,R,F) complex64 is what reference nn/field_conv.py:10-33 (weightContrib*) builds
@@ -83,12 +88,8 @@ int fc_supported(const fc_dims* dims);
  * 256 tiles of 16 vertices): the layout follows dims->N, so an image is packed with the dims of the launch it is for
  * (a forward pass launched in two row ranges packs one image per range).  Sizes differ between the two families, ask with
  * the same `records`.  wpk_bwd may be NULL: only the forward image is written. */
-/* `records` for every call below that takes one: 0 for the dense-stencil entry points; for the record-driven ones the value
- * fc_records_flags(dims, 1) returns for the dims of the BACKWARD launch (the whole mesh): 1, or 3 when that launch takes the
- * ring-major backward kernels (csrc/fc_backward_ring.hpp; opt-in with FC_BWD_RING=1 / 2 in the environment, otherwise
- * fc_records_flags never sets the bit) -- bit 1 selects their backward image
- *   IP inverse row scales, then R x {re_hi, re_lo, im_hi, im_lo} x BT blocks x IP x 32 halves, conjugated, k = f*ceil8(O) + o,
- * their workspace layout and their kernels in fc_backward_workspace_bytes / _data_factored / _filter / _finish / _all.
+/* `records` for every call below that takes one: 0 for the dense-stencil entry points, 1 for the record-driven ones
+ * (fc_records_flags(dims, record_driven) returns exactly that; kept so that a binding never hard-codes the value).
  * Either image pointer of the packing calls may be NULL (not both): only the other image is written. */
 int32_t fc_records_flags(const fc_dims* dims, int32_t record_driven);
 size_t fc_packed_filter_floats_fwd(const fc_dims* dims, int32_t records);

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
-    assert _lib.load(path).fc_abi_version() == 6
+    assert _lib.load(path).fc_abi_version() == 7
 
 
 def test_supported_query_and_sizes_need_no_gpu():
@@ -305,11 +305,65 @@ def test_bench_refuses_debug_switches_and_explains_missing_gpus():
     res = subprocess.run([sys.executable, bench], env=dict(env, FC_DEBUG_BWD='2'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300)
     assert res.returncode != 0 and 'FC_DEBUG_BWD' in res.stderr and res.stdout.strip() == ''
+    # a name with one of the package's prefixes that nothing reads (a typo, the switch of a removed kernel) is refused as well
+    res = subprocess.run([sys.executable, bench], env=dict(env, FC_BWD_RING='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and 'unknown switch' in res.stderr and 'FC_BWD_RING' in res.stderr and res.stdout.strip() == ''
     import torch
     if torch.cuda.device_count() == 0:
         res = subprocess.run([sys.executable, bench, '--gpus', '2'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                              timeout=300)
         assert res.returncode == 2 and 'GPU(s) visible' in res.stderr
+
+
+def test_every_environment_switch_is_registered():
+    """fieldconv_amd/_env.py lists every switch the library (getenv in csrc/), the package and bench.py read: bench.py records
+    the ones that are set and refuses names it does not know, so an unlisted switch would be refused or go unreported."""
+    from fieldconv_amd import _env
+    found = set()
+    for d, _, files in os.walk(os.path.join(ROOT, 'fieldconv_amd')):
+        for f in files:
+            if f.endswith(('.hip', '.hpp', '.py')) and f != '_env.py':
+                text = open(os.path.join(d, f), errors='ignore').read()
+                found |= set(re.findall(r'getenv\("([A-Z][A-Z_0-9]+)"\)', text))
+                found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'((?:FC|FIELDCONV|BENCH)_[A-Z_0-9]+)'", text))
+    text = open(os.path.join(ROOT, 'bench.py')).read()
+    found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'((?:FC|FIELDCONV|BENCH)_[A-Z_0-9]+)'", text))
+    assert found, 'no switches parsed'
+    assert found <= set(_env.SWITCHES), sorted(found - set(_env.SWITCHES))
+    assert set(_env.SWITCHES) <= found, sorted(set(_env.SWITCHES) - found)          # nothing listed that nobody reads any more
+    assert _env.unknown({'FC_MFMA': 'f32', 'FC_TYPO': '1', 'PATH': 'x'}) == ['FC_TYPO']
+    assert _env.active({'FC_MFMA': 'f32', 'HOME': 'x'}) == {'FC_MFMA': 'f32'}
+
+
+def test_kernel_description_and_gpu_count_need_no_gpu():
+    """fc_describe_kernels names the kernel families a launch selects (bench.py's config.kernels); bench.py counts devices for
+    its self-launch from sysfs, without a HIP call."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(1024)
+    d = _lib.FcDims(20000, 607843, 48, 48, 6, 2)
+    assert lib.fc_describe_kernels(ctypes.byref(d), 2, buf, len(buf)) == 0
+    text = buf.value.decode()
+    if os.environ.get('FC_MFMA') in (None, '') and os.environ.get('FC_RING') in (None, ''):
+        assert 'fc_forward_ring_kernel<geometric records,split-f16>' in text and 'fc_backward_filter_half2_kernel' in text, text
+    small = _lib.FcDims(1024, 131072, 48, 48, 6, 2)
+    assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and b'frequency-major' in buf.value
+    assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(100, 10, 48, 48, 9, 2)), 1, buf, len(buf)) == -2
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = {k: os.environ.pop(k, None) for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
+    try:
+        n = bench.visible_gpus()
+        assert n >= 0
+        os.environ['HIP_VISIBLE_DEVICES'] = '0'
+        assert bench.visible_gpus() == min(n, 1)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
 
 
 def test_graph_views_keep_the_cached_graph_clean():
