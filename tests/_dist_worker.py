@@ -37,8 +37,55 @@ def features(n_total, C, seed):
     return torch.complex(torch.randn(n_total, C, generator=g), torch.randn(n_total, C, generator=g))
 
 
+def plan_at_config4_size():
+    """BASELINE configs[3]'s per-rank size -- 20 000 owned vertices per rank, k = 32, C = 48 -- with the ranks at hand: the
+    partition, the halo plan and both exchanges (no convolution: the oracle would need minutes here).  Checks the sizes the
+    multi-GPU benchmark line reports and that the rows that travel are the right ones in both directions."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    per_rank, k, C = 20000, 32, 48
+    n_total = per_rank * world
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=0, support='p95', interior_first=True)
+    plan = HaloPlan(n_owned, halo_global, bounds, device=torch.device('cpu'))
+    lo = int(bounds[rank])
+    assert n_owned == per_rank and int(bounds[-1]) == n_total
+    assert plan.n_halo == int(halo_global.numel()) and sum(plan.recv_counts) == plan.n_halo and plan.recv_counts[rank] == 0
+    frac = plan.n_halo / n_owned
+    assert 0.01 < frac < 0.25, frac                      # a compact patch of a 2-D surface: a one-hop rim of a few per cent
+    # every rank's send counts are its peers' receive counts
+    counts = [None] * world
+    dist.all_gather_object(counts, (plan.send_counts, plan.recv_counts))
+    for p in range(world):
+        assert counts[p][1][rank] == plan.send_counts[p] and counts[p][0][rank] == plan.recv_counts[p]
+    src, dst = data.supp_edges[:, 0], data.supp_edges[:, 1]
+    assert int(dst.max()) < n_owned and int(src.max()) < n_owned + plan.n_halo      # targets are owned; sources owned or halo
+    assert bool((src[dst < data.n_interior] < n_owned).all())
+    # forward: the halo rows are the owners' rows; backward: every halo row's cotangent returns to its owner and is summed there
+    x_all = features(n_total, C, 1)
+    x_owned = x_all[lo:lo + n_owned].clone().requires_grad_(True)
+    x_local = halo_exchange(x_owned, plan)
+    assert torch.equal(x_local[n_owned:].detach(), x_all[halo_global])
+    g_local = features(n_owned + plan.n_halo, C, 100 + rank)
+    (gx,) = torch.autograd.grad(x_local, [x_owned], grad_outputs=g_local)
+    sent = [None] * world
+    dist.all_gather_object(sent, (halo_global.numpy(), g_local[n_owned:].numpy()))
+    expect = g_local[:n_owned].clone()
+    for p in range(world):
+        if p == rank:
+            continue
+        ids, rows = torch.from_numpy(sent[p][0]), torch.from_numpy(sent[p][1])
+        mine = (ids >= lo) & (ids < lo + n_owned)
+        expect.index_add_(0, ids[mine] - lo, rows[mine])
+    assert torch.allclose(gx, expect, rtol=0, atol=1e-5)
+    print(f'rank {rank}: config-4 plan n_owned={n_owned} halo={plan.n_halo} ({100 * frac:.1f} %) interior={data.n_interior} '
+          f'edges={int(data.supp_edges.shape[0])} send={plan.send_counts} recv={plan.recv_counts} '
+          f'halo bytes fwd={plan.n_halo * C * 8}', flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     dist.init_process_group('gloo')
+    if os.environ.get('FC_DIST_PLAN_ONLY') == '1':
+        return plan_at_config4_size()
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = os.environ.get('FC_DIST_TEST_DEVICE', 'cpu') == 'cuda'
     dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
