@@ -44,8 +44,13 @@ SIGNATURES = {
     'fc_supported': (ctypes.c_int, [_DP]),
     'fc_describe_kernels': (ctypes.c_int, [_DP, _c_int32, ctypes.c_char_p, ctypes.c_size_t]),
     'fc_shape_compiled': (ctypes.c_int, [_c_int32, _c_int32]),
-    'fc_generic_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
-    'fc_generic_scatter': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_generic_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_cgemm': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                _c_int32, ctypes.c_double, _c_int32, _vp]),
+    'fc_tangent_nonlin_forward_f64': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),
+    'fc_tangent_nonlin_backward_workspace_bytes_f64': (ctypes.c_size_t, [_c_int32, _c_int32]),
+    'fc_tangent_nonlin_backward_f64': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _c_int32, _c_int32, _vp]),
+    'fc_generic_scatter': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_packed_filter_floats_fwd': (_sz, [_DP, _c_int32]),
     'fc_packed_filter_floats_bwd': (_sz, [_DP, _c_int32]),
     'fc_pack_filter': (ctypes.c_int, [_vp, _vp, _vp, _DP, _c_int32, _vp]),

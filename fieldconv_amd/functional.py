@@ -425,7 +425,7 @@ def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, a
     complex64 or None.  Layers wider than the kernels' channel block fall back to the separate operators."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
-    if not _compiled(graph):            # no specialised kernels for this (n_rings, band_limit): run-time path, separate operators
+    if _run_time_path(x, graph):        # no specialised kernels for this (n_rings, band_limit), or double precision: separate operators
         h = field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph)
         if addend is not None:
             h = h + addend
@@ -449,11 +449,24 @@ def field_conv_act(x, zonal, spherical, phase, ftype, band_limit, graph, bias, a
     return _FieldConvActFn.apply(x, zonal, spherical, phase, bias.reshape(-1), addend, int(ftype), int(band_limit), graph)
 
 
+def _dtype_code(t):
+    """fc_dtype of a complex (or real) tensor: 0 = float32-based, 1 = float64-based."""
+    return 1 if t.dtype in (torch.complex128, torch.float64) else 0
+
+
+def _cgemm(lib, A, B, C, M, N, K, sam, sak, sbk, sbn, conj_b, alpha):
+    """C (M,N) = alpha * A . op(B) on the matrix pipe (csrc/fc_cgemm.hip); strides in complex elements."""
+    check(lib.fc_cgemm(_p(A), _p(B), _p(C), M, N, K, sam, sak, sbk, sbn, 1 if conj_b else 0, float(alpha), _dtype_code(C), _stream()),
+          'fc_cgemm')
+    return C
+
+
 class _GenericFieldConvFn(torch.autograd.Function):
-    """FieldConv for (n_rings, band_limit) pairs without specialised kernels (n_rings > 8, band_limit > 3 or 0): the gather
-    and the scatter are run-time HIP kernels on dense stencil rows (csrc/fc_generic.hip), the three contractions with the
-    filter plain complex GEMMs (rocBLAS through torch.matmul).  Same arithmetic as reference nn/field_conv.py:128-137 and its
-    autograd; any channel count."""
+    """FieldConv for (n_rings, band_limit) pairs without specialised kernels (n_rings > 8, band_limit > 3 or 0) and for
+    complex128 features of any shape (the reference's modules run under .double()): the gather and the scatter are run-time
+    HIP kernels on dense stencil rows (csrc/fc_generic.hip), the three contractions with the filter complex GEMMs on the
+    matrix pipe (csrc/fc_cgemm.hip), all in the tensors' own precision.  Same arithmetic as reference nn/field_conv.py:128-137
+    and its autograd; any channel count."""
 
     @staticmethod
     def forward(ctx, x, w_eff, graph):
@@ -461,10 +474,11 @@ class _GenericFieldConvFn(torch.autograd.Function):
         x = x.contiguous()
         O, I, R, F = w_eff.shape
         B = (F - 1) // 2
-        nt = graph.n_targets
+        nt, K = graph.n_targets, I * R * F
         with _on(x.device):
             contrib = _GenericFieldConvFn._gather(lib, x, graph, I, R, B)
-            y = (contrib.view(nt, -1) @ w_eff.reshape(O, -1).transpose(0, 1)) / F
+            y = torch.empty((nt, O), dtype=x.dtype, device=x.device)
+            _cgemm(lib, contrib, w_eff, y, nt, O, K, K, 1, 1, K, False, 1.0 / F)          # y = contrib . W^T / F
         ctx.save_for_backward(x, w_eff)
         ctx.graph = graph
         return y
@@ -472,10 +486,10 @@ class _GenericFieldConvFn(torch.autograd.Function):
     @staticmethod
     def _gather(lib, x, graph, I, R, B):
         F = 2 * B + 1
-        contrib = torch.empty((graph.n_targets, I, R, F), dtype=torch.complex64, device=x.device)
+        contrib = torch.empty((graph.n_targets, I, R, F), dtype=x.dtype, device=x.device)
         by_t = _csr(graph.rowptr_t, graph.nbr_t, None)
-        check(lib.fc_generic_gather(_p(x), _p(graph.sten_t), ctypes.byref(by_t), _p(contrib), graph.n_targets, I, R, B, _stream()),
-              'fc_generic_gather')
+        check(lib.fc_generic_gather(_p(x), _p(graph.sten_t), ctypes.byref(by_t), _p(contrib), graph.n_targets, I, R, B, _dtype_code(x),
+                                    _stream()), 'fc_generic_gather')
         return contrib
 
     @staticmethod
@@ -485,33 +499,44 @@ class _GenericFieldConvFn(torch.autograd.Function):
         graph = ctx.graph
         O, I, R, F = w_eff.shape
         B = (F - 1) // 2
-        nt = graph.n_targets
+        nt, K = graph.n_targets, I * R * F
         gy = gy.contiguous()
         with _on(x.device):
             contrib = _GenericFieldConvFn._gather(lib, x, graph, I, R, B)      # recomputed, not kept between the passes
-            wm = w_eff.reshape(O, -1)
-            g_contrib = ((gy @ wm.conj()) / F).contiguous()                    # (nt, I*R*F)
-            gw = ((gy.transpose(0, 1) @ contrib.view(nt, -1).conj()) / F).reshape(O, I, R, F)
+            g_contrib = torch.empty((nt, K), dtype=x.dtype, device=x.device)
+            _cgemm(lib, gy, w_eff, g_contrib, nt, K, O, O, 1, K, 1, True, 1.0 / F)        # gy . conj(W) / F
+            gw = torch.empty((O, I, R, F), dtype=x.dtype, device=x.device)
+            _cgemm(lib, gy, contrib, gw, O, K, nt, 1, O, K, 1, True, 1.0 / F)             # gy^T . conj(contrib) / F
             gx = torch.empty_like(x)
             by_s = _csr(graph.rowptr_s, graph.nbr_s, None)
-            check(lib.fc_generic_scatter(_p(x), _p(g_contrib), _p(graph.sten_s), ctypes.byref(by_s), _p(gx), graph.N, I, R, B, _stream()),
-                  'fc_generic_scatter')
+            check(lib.fc_generic_scatter(_p(x), _p(g_contrib), _p(graph.sten_s), ctypes.byref(by_s), _p(gx), graph.N, I, R, B, _dtype_code(x),
+                                         _stream()), 'fc_generic_scatter')
         return gx, gw, None
 
 
 def _generic_field_conv(x, w_eff, graph):
     if graph.sten_t is None or graph.sten_s is None:
+        if x.dtype == torch.complex128:
+            raise _lib.FieldConvNativeError('complex128 features need a complex128 stencil (the support graph at hand was built from '
+                                            'float32 data: records only)')
         raise _lib.FieldConvNativeError('the run-time FieldConv path needs a support graph with dense stencil rows')
-    if x.dtype != torch.complex64 or w_eff.dtype != torch.complex64:
-        raise ValueError('field_conv expects complex64 features and filters')
+    if x.dtype not in (torch.complex64, torch.complex128) or w_eff.dtype != x.dtype or graph.sten_t.dtype != x.dtype:
+        raise ValueError(f'field_conv expects features, filter and stencil of one complex dtype, got {x.dtype}, {w_eff.dtype}, '
+                         f'{graph.sten_t.dtype}')
     if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != w_eff.shape[1]:
         raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {w_eff.shape[1]})')
     if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
         raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
-    if w_eff.shape[1] * graph.R * graph.F * 8 > 160 * 1024:
+    itemsize = 16 if x.dtype == torch.complex128 else 8
+    if w_eff.shape[1] * graph.R * graph.F * itemsize > 160 * 1024:
         raise _lib.FieldConvNativeError(f'in_channels * n_rings * (2 band_limit + 1) = {w_eff.shape[1] * graph.R * graph.F} exceeds the '
-                                        'run-time path\'s LDS budget (20480)')
+                                        f'run-time path\'s LDS budget ({160 * 1024 // itemsize})')
     return _GenericFieldConvFn.apply(x, w_eff.contiguous(), graph)
+
+
+def _run_time_path(x, graph):
+    """True when a convolution takes the run-time kernels: no specialised kernels for the stencil's shape, or double precision."""
+    return x.dtype == torch.complex128 or not _compiled(graph)
 
 
 def _compiled(graph):
@@ -541,7 +566,7 @@ def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
     input channels (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
-    if not _compiled(graph):
+    if _run_time_path(x, graph):
         if zonal.shape[2] != graph.R or 2 * band_limit + 1 != graph.F:
             raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={zonal.shape[2]}, band_limit={band_limit}')
         from .nn.field_conv import effective_filter          # the (tiny) assembly and its autograd in torch
@@ -569,8 +594,11 @@ def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
 
 
 def field_conv(x, w_eff, graph):
-    """x (N,I) complex64, w_eff (O,I,R,F) complex64, graph: fieldconv_amd.graph.SupportGraph -> (N,O) complex64."""
+    """x (N,I) complex64, w_eff (O,I,R,F) complex64, graph: fieldconv_amd.graph.SupportGraph -> (N,O) complex64; complex128
+    throughout takes the run-time kernels in double precision."""
     _require_device(x, 'field_conv')
+    if x.dtype == torch.complex128:
+        return _generic_field_conv(x, w_eff, graph)
     if x.dtype != torch.complex64 or w_eff.dtype != torch.complex64:
         raise ValueError('field_conv expects complex64 features and filters')
     if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != w_eff.shape[1]:
@@ -628,8 +656,43 @@ class _TangentLinFn(torch.autograd.Function):
         return gx, g_re, g_im
 
 
+class _TangentLinF64Fn(torch.autograd.Function):
+    """reference nn/tangent_lin.py:27-29 in double precision: three complex GEMMs on the matrix pipe (fc_cgemm), any width"""
+
+    @staticmethod
+    def forward(ctx, x, re_w, im_w):
+        lib = _lib.load()
+        x = x.contiguous()
+        wc = torch.complex(re_w, im_w).contiguous()
+        O, I = wc.shape
+        N = x.shape[0]
+        with _on(x.device):
+            y = torch.empty((N, O), dtype=x.dtype, device=x.device)
+            _cgemm(lib, x, wc, y, N, O, I, I, 1, 1, I, False, 1.0)                        # x . Wc^T
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, wc = ctx.saved_tensors
+        O, I = wc.shape
+        N = x.shape[0]
+        gy = gy.contiguous()
+        with _on(x.device):
+            gx = torch.empty_like(x)
+            _cgemm(lib, gy, wc, gx, N, I, O, O, 1, I, 1, True, 1.0)                       # gy . conj(Wc)
+            gw = torch.empty_like(wc)
+            _cgemm(lib, gy, x, gw, O, I, N, 1, O, I, 1, True, 1.0)                        # gy^T . conj(x)
+        return gx, gw.real.contiguous(), gw.imag.contiguous()
+
+
 def tangent_lin(x, re_w, im_w):
     _require_device(x, 'tangent_lin')
+    if x.dtype == torch.complex128:
+        if re_w.dtype != torch.float64 or x.dim() != 2 or x.shape[1] != re_w.shape[1]:
+            raise ValueError(f'tangent_lin: x {tuple(x.shape)} {x.dtype} does not match weights {tuple(re_w.shape)} {re_w.dtype}')
+        return _TangentLinF64Fn.apply(x, re_w, im_w)
     if x.dtype != torch.complex64:
         raise ValueError('tangent_lin expects complex64 features')
     if x.dim() != 2 or x.shape[1] != re_w.shape[1]:
@@ -679,8 +742,43 @@ class _TangentNonLinFn(torch.autograd.Function):
         return gx, gb
 
 
+class _TangentNonLinF64Fn(torch.autograd.Function):
+    """reference nn/tangent_nonlin.py:24-35 in double precision (csrc/fc_pointwise_f64.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        lib = _lib.load()
+        x = x.contiguous()
+        b = bias.contiguous()
+        N, C = x.shape
+        with _on(x.device):
+            y = torch.empty_like(x)
+            check(lib.fc_tangent_nonlin_forward_f64(_p(x), _p(b), _p(y), N, C, _stream()), 'fc_tangent_nonlin_forward_f64')
+        ctx.save_for_backward(x, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, b = ctx.saved_tensors
+        N, C = x.shape
+        gy = gy.contiguous()
+        with _on(x.device):
+            gx = torch.empty_like(x)
+            gb = torch.empty_like(b)
+            nbytes = lib.fc_tangent_nonlin_backward_workspace_bytes_f64(N, C)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            check(lib.fc_tangent_nonlin_backward_f64(_p(x), _p(b), _p(gy), _p(gx), _p(gb), _p(ws), nbytes, N, C, _stream()),
+                  'fc_tangent_nonlin_backward_f64')
+        return gx, gb
+
+
 def tangent_nonlin(x, bias):
     _require_device(x, 'tangent_nonlin')
+    if x.dtype == torch.complex128:
+        if bias.dtype != torch.float64 or x.dim() != 2 or bias.numel() != x.shape[1]:
+            raise ValueError(f'tangent_nonlin: x {tuple(x.shape)} {x.dtype} does not match bias {tuple(bias.shape)} {bias.dtype}')
+        return _TangentNonLinF64Fn.apply(x, bias)
     if x.dtype != torch.complex64:
         raise ValueError('tangent_nonlin expects complex64 features')
     if x.dim() != 2 or bias.numel() != x.shape[1]:

@@ -270,8 +270,12 @@ class SupportGraph:
             raise ValueError('supp_edges must have shape (E, 2)')
         if supp_sten.dim() != 3 or supp_sten.shape[0] != supp_edges.shape[0]:
             raise ValueError('supp_sten must have shape (E, R, 2B+1) with the same E as supp_edges')
-        if supp_sten.dtype != torch.complex64:
-            raise ValueError('supp_sten must be complex64 (torch.cfloat)')
+        if supp_sten.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError('supp_sten must be complex64 (torch.cfloat) or complex128')
+        if supp_sten.dtype == torch.complex128:
+            # double precision (the reference's modules run under .double()): dense stencil rows in slot order for the
+            # run-time kernels (csrc/fc_generic.hip); the record-driven kernels and the native graph build are float32
+            allow_factored, native = False, False
         if supp_edges.dtype not in (torch.int64, torch.int32):
             raise ValueError('supp_edges must be an integer tensor')
         dev = supp_sten.device

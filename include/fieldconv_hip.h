@@ -205,20 +205,30 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
 
 /* ---- any (n_rings, band_limit): the run-time path for shapes outside the compiled set (reference nn/field_conv.py:62-98
  * takes any) ---- *
- * fc_shape_compiled: 1 for n_rings 2..8 x band_limit 1..3 (the specialised kernels above), else 0.  For the others the
- * operator is evaluated in the reference's own two steps, with dense stencil rows in slot order:
+ * fc_shape_compiled: 1 for n_rings 2..8 x band_limit 1..3 (the specialised kernels above), else 0.  For the others -- and for
+ * complex128 features of ANY shape (the reference's modules run under .double()) -- the operator is evaluated in the reference's
+ * own two steps, with dense stencil rows in slot order, in the tensors' own precision (dtype):
  *   fc_generic_gather   contrib (n_targets, I, R, F) c64 = the per-target response of :128-134 (by_target CSR with nbr; sten_t
- *                       (E,R,F) c64 in its slot order); the caller contracts it with W_eff (a plain complex GEMM:
- *                       y = contrib.view(n, I*R*F) @ W_eff.view(O, I*R*F)^T / F) and forms the two backward GEMMs
- *                       g_contrib = gy @ conj(W_eff) / F, gW_eff = gy^T @ conj(contrib) / F;
+ *                       (E,R,F) complex in its slot order); the caller contracts it with W_eff and forms the two backward
+ *                       products with fc_cgemm (below);
  *   fc_generic_scatter  gx (N, I) c64 from g_contrib (n_targets, I, R, F) over the out-edges (by_source CSR with nbr = targets,
  *                       sten_s in its slot order), including the chain rule through the rotation e^{-i m angle(x)}.
- * I * R * F * 8 bytes (gather) must fit the CU's 160 KB of LDS; any channel count otherwise. */
+ * I * R * F complex numbers (gather) must fit the CU's 160 KB of LDS; any channel count otherwise. */
+typedef enum fc_dtype { FC_F32 = 0, FC_F64 = 1 } fc_dtype;       /* real scalar type of a complex tensor: complex64 / complex128 */
 int fc_shape_compiled(int32_t n_rings, int32_t band_limit);
-int fc_generic_gather(const float* x, const float* sten_t, const fc_csr* by_target, float* contrib, int32_t n_targets, int32_t I,
-                      int32_t R, int32_t B, void* stream);
-int fc_generic_scatter(const float* x, const float* g_contrib, const float* sten_s, const fc_csr* by_source, float* gx, int32_t N,
-                       int32_t I, int32_t R, int32_t B, void* stream);
+int fc_generic_gather(const void* x, const void* sten_t, const fc_csr* by_target, void* contrib, int32_t n_targets, int32_t I,
+                      int32_t R, int32_t B, int32_t dtype, void* stream);
+int fc_generic_scatter(const void* x, const void* g_contrib, const void* sten_s, const fc_csr* by_source, void* gx, int32_t N,
+                       int32_t I, int32_t R, int32_t B, int32_t dtype, void* stream);
+/* The contractions of the run-time path (and TangentLin in double precision): a complex GEMM on the matrix pipe,
+ *   C[m, n] = alpha * sum_k A[m*sam + k*sak] * op(B[k*sbk + n*sbn]),   op = conj when conj_b != 0,
+ * C (M, N) row-major and contiguous, A and B complex arrays addressed with element strides (in complex numbers), all three of
+ * dtype FC_F32 (interleaved float pairs) or FC_F64 (double pairs).  With contrib viewed as (n, K = I*R*F) and W_eff as (O, K):
+ *   y         = contrib . W_eff^T / F         fc_cgemm(contrib, W, y,  n, O, K,  K, 1,  1, K,  0, 1/F)
+ *   g_contrib = gy . conj(W_eff) / F          fc_cgemm(gy, W, gc,      n, K, O,  O, 1,  K, 1,  1, 1/F)
+ *   gW_eff    = gy^T . conj(contrib) / F      fc_cgemm(gy, contrib, gW, O, K, n,  1, O,  K, 1,  1, 1/F)            */
+int fc_cgemm(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+             int32_t conj_b, double alpha, int32_t dtype, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */
@@ -239,6 +249,13 @@ int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32
 size_t fc_tangent_nonlin_backward_workspace_bytes(int32_t N, int32_t C);
 int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
                                void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream);
+
+/* The same in double precision (complex128 features, float64 bias): the reference's modules run under .double().
+ * TangentLin in double precision is fc_cgemm with Wc = Re + i Im built by the caller. */
+int fc_tangent_nonlin_forward_f64(const double* x, const double* bias, double* y, int32_t N, int32_t C, void* stream);
+size_t fc_tangent_nonlin_backward_workspace_bytes_f64(int32_t N, int32_t C);
+int fc_tangent_nonlin_backward_f64(const double* x, const double* bias, const double* gy, double* gx, double* gbias,
+                                   void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream);
 
 /* ---- ECHO descriptors, reference nn/echo.py:94-148 (ECHO.forward with rasterize :30-61, diskMap :11-27) ---- *
  * hist[n,c,b] = sum over in-edges e of n of the bilinear votes of the point ln[e] * exp(-i angle(x[src_e,c])) in the

@@ -1063,3 +1063,102 @@ def test_conv_epilogue_fusion_matches_separate_operators(dev, monkeypatch, N, k)
         out[fused] = (y.detach(),) + torch.autograd.grad(y, [xd] + params, grad_outputs=gy)
     for a, b in zip(out[True], out[False]):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ double precision (the reference's modules run under .double())
+FC64 = {k: v for k, v in load_golden('fieldconv.npz').items() if k.endswith('f64')}
+
+
+@pytest.mark.parametrize('tag', sorted(FC64))
+def test_fieldconv_golden_f64(tag, dev):
+    """FieldConv(...).double() on complex128 features and a complex128 stencil: the run-time kernels in double precision
+    (csrc/fc_generic.hip, fc_cgemm) against the reference's own float64 run (fixtures *_f64: the three ftypes)."""
+    from fieldconv_amd.nn import FieldConv
+    c = FC64[tag]
+    assert c['x'].dtype == np.complex128 and c['sten'].dtype == np.complex128
+    ftype, B, R = int(c['ftype']), int(c['B']), int(c['R'])
+    conv = FieldConv(c['x'].shape[1], c['y'].shape[1], band_limit=B, n_rings=R, ftype=ftype).double()
+    conv.load_state_dict({'zonal': torch.from_numpy(c['zonal']), 'spherical': torch.from_numpy(c['spherical']),
+                          'phase': torch.from_numpy(c['phase'])})
+    conv = conv.to(dev)
+    x = D(c['x'], dev).requires_grad_(True)
+    y = conv(x, D(c['edges'], dev), D(c['sten'], dev))
+    assert y.dtype == torch.complex128
+    assert rel_err(H(y), c['y']) < 1e-12
+    params = dict(conv.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev))
+    assert rel_err(H(grads[0]), c['gx']) < 1e-12
+    for (name, _), g in zip(params.items(), grads[1:]):
+        assert g.dtype == torch.float64 and rel_err(H(g), c['g_' + name]) < 1e-12, name
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_cgemm_three_layouts(dtype, dev):
+    """fc_cgemm (MFMA f32 / f64) in the three forms the run-time path uses -- A . B^T, A . conj(B), A^T . conj(B) -- on sizes
+    that are no multiples of the 64 x 64 x 16 tiling, against torch.matmul in double precision."""
+    from fieldconv_amd import _lib
+    from fieldconv_amd.functional import _cgemm
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+
+    def rnd(*shape):
+        return torch.complex(torch.randn(*shape, generator=g, dtype=torch.float64), torch.randn(*shape, generator=g, dtype=torch.float64))
+    tol = 1e-13 if dtype == torch.complex128 else 2e-6
+    for (n, O, K) in ((200, 7, 90), (130, 70, 333), (65, 64, 16), (1, 1, 1)):
+        A, W, G = rnd(n, K), rnd(O, K), rnd(n, O)
+        Ad, Wd, Gd = A.to(dtype).to(dev), W.to(dtype).to(dev), G.to(dtype).to(dev)
+        y = torch.empty((n, O), dtype=dtype, device=dev)
+        _cgemm(lib, Ad, Wd, y, n, O, K, K, 1, 1, K, False, 0.5)
+        assert rel_err(H(y).astype(np.complex128), (A @ W.T * 0.5).numpy()) < tol
+        gc = torch.empty((n, K), dtype=dtype, device=dev)
+        _cgemm(lib, Gd, Wd, gc, n, K, O, O, 1, K, 1, True, 1.0)
+        assert rel_err(H(gc).astype(np.complex128), (G @ W.conj()).numpy()) < tol
+        gw = torch.empty((O, K), dtype=dtype, device=dev)
+        _cgemm(lib, Gd, Ad, gw, O, K, n, 1, O, K, 1, True, 2.0)
+        assert rel_err(H(gw).astype(np.complex128), (G.T @ A.conj() * 2.0).numpy()) < tol
+
+
+def test_fc_resnet_block_in_double_precision(dev):
+    """FCResNetBlock(...).double(): FieldConv, TangentLin and TangentNonLin in double precision.  Output against the oracle
+    evaluated in complex128; every gradient through a central difference of the loss along a random direction (double
+    precision makes that a 1e-7 check)."""
+    from fieldconv_amd.nn import FCResNetBlock
+    g = torch.Generator().manual_seed(17)
+    N, k, Cin, Cout, B, R = 150, 9, 5, 7, 2, 4
+    F = 2 * B + 1
+    dst = torch.arange(N).repeat_interleave(k)
+    src = torch.randint(0, N, (N * k,), generator=g)
+    order = torch.argsort(src, stable=True)
+    edges = torch.stack((src[order], dst[order]), 1)
+    sten = torch.complex(torch.randn(N * k, R, F, generator=g, dtype=torch.float64), torch.randn(N * k, R, F, generator=g, dtype=torch.float64)) * 0.3
+    x = torch.complex(torch.randn(N, Cin, generator=g, dtype=torch.float64), torch.randn(N, Cin, generator=g, dtype=torch.float64))
+    # (no exact zeros here: the operator is not differentiable at the origin box -- the reference assigns such entries a zero
+    #  angle gradient by convention, which a central difference across the box cannot reproduce; the fixtures cover them)
+    blk = FCResNetBlock(Cin, Cout, band_limit=B, n_rings=R, ftype=1).double().to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    ed, sd = edges.to(dev), sten.to(dev)
+    y = blk(xd, ed, sd)
+    p = {n_: H(v) for n_, v in blk.state_dict().items()}
+    y_ref = orc.fc_resnet_block_forward(x.numpy(), edges.numpy(), sten.numpy(), p, 1, B)
+    assert y.dtype == torch.complex128 and rel_err(H(y), y_ref) < 1e-12
+    gy = torch.complex(torch.randn(N, Cout, generator=g, dtype=torch.float64), torch.randn(N, Cout, generator=g, dtype=torch.float64)).to(dev)
+    params = list(blk.parameters())
+    grads = torch.autograd.grad(y, [xd] + params, grad_outputs=gy)
+
+    def loss():
+        with torch.no_grad():
+            return float(torch.sum(torch.real(torch.conj(gy) * blk(xd, ed, sd))))
+    eps = 1e-6
+    for t, gt in zip([xd] + params, grads):
+        v = torch.randn(t.shape, generator=g, dtype=torch.float64).to(dev)
+        if t.is_complex():
+            v = torch.complex(v, torch.randn(t.shape, generator=g, dtype=torch.float64).to(dev))
+        with torch.no_grad():
+            t.add_(eps * v)
+            lp = loss()
+            t.sub_(2 * eps * v)
+            lm = loss()
+            t.add_(eps * v)
+        fd = (lp - lm) / (2 * eps)
+        an = float(torch.sum(torch.real(torch.conj(gt) * v))) if t.is_complex() else float(torch.sum(gt * v))
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)), (tuple(t.shape), fd, an)

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     path = build_native()
     lib = ctypes.CDLL(path)
     header = open(os.path.join(ROOT, 'include', 'fieldconv_hip.h')).read()
-    declared = set(re.findall(r'\b(fc_[a-z_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(fc_[a-z0-9_]+)\s*\(', header))
     assert declared, 'no declarations parsed'
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
@@ -211,8 +211,10 @@ def test_support_graph_groups_edges_both_ways():
     assert get_graph(edges, sten, N) is a
     sten.mul_(2)
     assert get_graph(edges, sten, N) is not a
+    dbl = SupportGraph(edges, sten.to(torch.cdouble), N)             # double precision: dense rows for the run-time kernels, no records
+    assert not dbl.factored and dbl.sten_t.dtype == torch.complex128 and torch.equal(dbl.rowptr_t, a.rowptr_t)
     with pytest.raises(ValueError):
-        SupportGraph(edges, sten.to(torch.cdouble), N)
+        SupportGraph(edges, sten.real, N)
     empty = SupportGraph(torch.zeros(0, 2, dtype=torch.long), torch.zeros(0, 3, 3, dtype=torch.cfloat), 4)
     assert empty.rowptr_t.tolist() == [0] * 5
 
