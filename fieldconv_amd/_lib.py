@@ -45,6 +45,9 @@ SIGNATURES = {
     'fc_describe_kernels': (ctypes.c_int, [_DP, _c_int32, ctypes.c_char_p, ctypes.c_size_t]),
     'fc_shape_compiled': (ctypes.c_int, [_c_int32, _c_int32]),
     'fc_generic_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _c_int32, _c_int32, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_wide_workspace_bytes': (ctypes.c_size_t, [_DP, _c_int32, _c_int32, _c_int32]),
+    'fc_forward_wide': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _vp, ctypes.c_size_t, _DP, _c_int32, _c_int32, _vp]),
+    'fc_backward_wide': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _DP, _c_int32, _vp]),
     'fc_cgemm': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                 _c_int32, ctypes.c_double, _c_int32, _vp]),
     'fc_tangent_nonlin_forward_f64': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),

@@ -655,14 +655,16 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream) {
+int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
+                                int o0, int i0, int Ifull) {
     const BwdPlan p = plan_backward(d, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes);
     // partial (p, f, k = r*O + o, i) at ((p*F + f)*KP + k)*IP + i
     return reduce_param_grads_impl(gwp, (size_t)p.F * p.KP * p.IP, (size_t)d->O * p.IP, (size_t)p.KP * p.IP, (size_t)p.IP, p.P, gw_eff,
-                                   fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream);
+                                   fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream, o0,
+                                   i0, Ifull);
 }
 
 #define FC_BWD_DATA_ARGS const float*, const float*, const float*, const fc_csr*, const float*, float*, void*, size_t, const fc_dims*, bool, hipStream_t

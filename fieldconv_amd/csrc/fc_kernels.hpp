@@ -58,10 +58,17 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
 
 // reduction of the filter-gradient partials fused with the parameter-gradient chain (fc_pack.hip); *_finish_params_impl
 // pick the partial layout of their kernel family
+// (o0, i0, Ifull: the filter is the block [o0, o0 + O) x [i0, i0 + I) of parameter tensors with Ifull input channels; whole
+// layer: 0, 0, 0)
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
                             const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
-                            const fc_dims* d, hipStream_t stream);
-int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream);
+                            const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0);
+int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
+                                int o0 = 0, int i0 = 0, int Ifull = 0);
+int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,
+                           hipStream_t stream);
+int pack_filter_params_block_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd, float* wpk_bwd,
+                                  const fc_dims* d, int records, int o0, int i0, int Ifull, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
 // one-line descriptions of the kernels a launch with these dims selects (fc_describe_kernels)

@@ -50,6 +50,8 @@ struct PackArgs {
     unsigned blocks_f;       // workgroups that write the forward image; the rest write the backward image
     int ring_f;              // forward image in ring-major layout (fc_forward_ring.hpp): one slab of planes per RING,
                              // k = f*KI + i inside it, instead of one per frequency with k = r*KI + i
+    int o0, i0, Ifull;       // the (O, I) filter is the block [o0, o0 + O) x [i0, i0 + I) of parameter tensors with Ifull input
+                             // channels (wide layers run as channel blocks, fc_wide.hip); a whole layer: 0, 0, I
 };
 
 constexpr int kPackThreads = 256;
@@ -66,8 +68,9 @@ __device__ __forceinline__ float2 packed_value(const float2* __restrict__ w, con
     if (f >= a.F) return make_float2(0.f, 0.f);
     const int o = is_bwd ? c : m, i = is_bwd ? m : c;
     if (o >= a.O || i >= a.I || r >= a.R) return make_float2(0.f, 0.f);
-    const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!WITH_PHASE && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.I, o, i, r, f)
-                                 : w[(((size_t)o * a.I + i) * a.R + r) * a.F + f];
+    const float2 v = FROM_PARAMS ? filter_entry(zonal, sph, phase, (!WITH_PHASE && a.ftype == 1) ? 0 : a.ftype, a.B, a.R, a.Ifull, a.o0 + o,
+                                                a.i0 + i, r, f)
+                                 : w[(((size_t)(a.o0 + o) * a.Ifull + a.i0 + i) * a.R + r) * a.F + f];
     const float sc = 1.f / (float)a.F;
     return make_float2(v.x * sc, (is_bwd ? -v.y : v.y) * sc);
 }
@@ -85,7 +88,7 @@ __device__ __forceinline__ float row_max2(const float2* __restrict__ w, const fl
         for (int idx = threadIdx.x; idx < C * a.R; idx += kPackThreads) {
             const int c = idx / a.R, r = idx - c * a.R;
             const int o = is_bwd ? c : m, i = is_bwd ? m : c;
-            const size_t oir = ((size_t)o * a.I + i) * a.R + r;
+            const size_t oir = ((size_t)(a.o0 + o) * a.Ifull + a.i0 + i) * a.R + r;
             if (a.ftype == 2) {
                 mx = fmaxf(mx, zonal[oir * 2] * zonal[oir * 2] + zonal[oir * 2 + 1] * zonal[oir * 2 + 1]);
                 for (int b = 0; b < 2 * a.B; ++b) {
@@ -104,7 +107,7 @@ __device__ __forceinline__ float row_max2(const float2* __restrict__ w, const fl
         for (int idx = threadIdx.x; idx < C * a.R * a.F; idx += kPackThreads) {
             const int c = idx / (a.R * a.F), rf = idx - c * (a.R * a.F);
             const int o = is_bwd ? c : m, i = is_bwd ? m : c;
-            const float2 v = w[((size_t)o * a.I + i) * a.R * a.F + rf];
+            const float2 v = w[((size_t)(a.o0 + o) * a.Ifull + a.i0 + i) * a.R * a.F + rf];
             mx = fmaxf(mx, v.x * v.x + v.y * v.y);
         }
     }
@@ -184,9 +187,10 @@ size_t packed_filter_floats_bwd(const fc_dims* d, int records) {
 
 template <bool FROM_PARAMS>
 static int launch_pack(const float* w_eff, const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
-                       float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream) {
+                       float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0) {
     PackArgs a;
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
+    a.o0 = o0; a.i0 = i0; a.Ifull = Ifull > 0 ? Ifull : d->I;
     a.ring_f = ring_forward_image(d, records & 1) ? 1 : 0;
     a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
@@ -206,6 +210,16 @@ int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const f
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
                             float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream) {
     return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, records, stream);
+}
+
+int pack_filter_params_block_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd, float* wpk_bwd,
+                                  const fc_dims* d, int records, int o0, int i0, int Ifull, hipStream_t stream) {
+    return launch_pack<true>(nullptr, zonal, sph, phase, ftype, wpk_fwd, wpk_bwd, d, records, stream, o0, i0, Ifull);
+}
+
+int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,
+                           hipStream_t stream) {
+    return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, records, stream, o0, i0, Ifull);
 }
 
 int split_mode() {
@@ -305,7 +319,9 @@ struct RpStrides { size_t sp, sr, sf, so; };
 __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     const float2* __restrict__ gwp, const RpStrides st, const int P, float2* __restrict__ gw_out, const float* __restrict__ zonal,
     const float* __restrict__ sph, const float* __restrict__ phase, const int ftype, float* __restrict__ g_zonal,
-    float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B) {
+    float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B, const int po0,
+    const int pi0, const int Ifull) {
+    // (po0, pi0, Ifull: the filter is the block [po0, po0 + O) x [pi0, pi0 + I) of parameter tensors with Ifull input channels)
     __shared__ float2 part[kRpGroups][kRpPairs * 8 * 7];     // [group][(r*F + f)*16 + pair]
     __shared__ float2 gws[kRpPairs * 8 * 7];                 // [pair][r][f]
     __shared__ float gph[kRpPairs * 8 * (kMaxB + 1)];        // [pair][r][q]
@@ -352,14 +368,14 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     const int pair = threadIdx.x / R, r = threadIdx.x - pair * R;
     const bool valid = pair < kRpPairs && i0 + pair < I;
     if (valid)
-        param_grads_entry(gws + (pair * 8 + r) * 7, zonal, sph, phase, ftype, g_zonal, g_sph, gph + (pair * 8 + r) * (kMaxB + 1), I, R, B, o,
-                          i0 + pair, r);
+        param_grads_entry(gws + (pair * 8 + r) * 7, zonal, sph, phase, ftype, g_zonal, g_sph, gph + (pair * 8 + r) * (kMaxB + 1), Ifull, R, B,
+                          po0 + o, pi0 + i0 + pair, r);
     __syncthreads();
     if (valid && ftype == 1 && r == 0) {
         for (int q = 0; q <= B; ++q) {
             float acc = 0.f;
             for (int rr = 0; rr < R; ++rr) acc += gph[(pair * 8 + rr) * (kMaxB + 1) + q];
-            g_phase[((size_t)o * I + i0 + pair) * (B + 1) + q] = acc;
+            g_phase[((size_t)(po0 + o) * Ifull + pi0 + i0 + pair) * (B + 1) + q] = acc;
         }
     }
 }
@@ -367,12 +383,13 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
 // gwp: the partials, P of them, entry (p, r, f, o, i) at gwp[p*sp + r*sr + f*sf + o*so + i]
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
                             const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
-                            const fc_dims* d, hipStream_t stream) {
+                            const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull) {
     if (d->R > 8 || d->B > kMaxB || kRpPairs * d->R > kRpThreads) return FC_ERR_UNSUPPORTED;
     const int nit = (d->I + kRpPairs - 1) / kRpPairs;
     const RpStrides st{sp, sr, sf, so};
     hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(d->O * nit), dim3(kRpThreads), 0, stream, reinterpret_cast<const float2*>(gwp), st,
-                       P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I, d->R, d->B);
+                       P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I, d->R, d->B, o0, i0,
+                       Ifull > 0 ? Ifull : d->I);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -546,6 +546,82 @@ def _compiled(graph):
 MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)
 
 
+class _WideFieldConvFn(torch.autograd.Function):
+    """FieldConv wider than the kernels' channel block (reference nn/field_conv.py:62 takes any width): channel blocks enqueued
+    by ONE native call per pass (csrc/fc_wide.hip: fc_forward_wide / fc_backward_wide) -- block copies, filter packing from the
+    parameter blocks, the sum over input blocks in the convolution's epilogue, block-wise parameter gradients; no Python loop and
+    no concatenation.  Either the module parameters (params = (zonal, spherical, phase), w_eff None) or an explicit filter."""
+
+    @staticmethod
+    def forward(ctx, x, zonal, spherical, phase, w_eff, ftype, B, graph, blk):
+        lib = _lib.load()
+        x = x.contiguous()
+        explicit = w_eff is not None
+        if explicit:
+            w_eff = w_eff.contiguous()
+            O, I = w_eff.shape[0], w_eff.shape[1]
+        else:
+            zonal, spherical, phase = zonal.contiguous(), spherical.contiguous(), phase.contiguous()
+            O, I = zonal.shape[0], zonal.shape[1]
+        dims = make_dims(graph, I, O, B)
+        records = 1 if graph.factored else 0
+        kind, recs = (2, graph.geo_t) if graph.geo_t is not None else ((1, graph.rec_t) if graph.factored else (0, graph.sten_t))
+        by_t = _csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
+        with _on(x.device):
+            nbytes = lib.fc_wide_workspace_bytes(ctypes.byref(dims), blk, records, 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            y = torch.empty((graph.N, O), dtype=torch.complex64, device=x.device)
+            fp = None if explicit else FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, None, None, None)
+            check(lib.fc_forward_wide(_p(x), _p(recs), ctypes.byref(by_t), kind, ctypes.byref(fp) if fp is not None else None,
+                                      _p(w_eff) if explicit else None, _p(y), _p(ws), nbytes, ctypes.byref(dims), records, blk, _stream()),
+                  'fc_forward_wide')
+        ctx.save_for_backward(x, *( (w_eff,) if explicit else (zonal, spherical, phase) ))
+        ctx.graph, ctx.ftype, ctx.B, ctx.blk, ctx.explicit, ctx.io = graph, ftype, B, blk, explicit, (I, O)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        graph, blk = ctx.graph, ctx.blk
+        I, O = ctx.io
+        x = ctx.saved_tensors[0]
+        gy = gy.contiguous()
+        dims = make_dims(graph, I, O, ctx.B)
+        records = 1 if graph.factored else 0
+        sten = graph.rec_s if graph.factored else graph.sten_s
+        by_s = _csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
+        with _on(x.device):
+            nbytes = lib.fc_wide_workspace_bytes(ctypes.byref(dims), blk, records, 1)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            gx = torch.empty_like(x)
+            if ctx.explicit:
+                w_eff = ctx.saved_tensors[1]
+                gw = torch.empty_like(w_eff)
+                check(lib.fc_backward_wide(_p(x), _p(gy), _p(sten), ctypes.byref(by_s), records, None, _p(w_eff), _p(gw), _p(gx), _p(ws), nbytes,
+                                           ctypes.byref(dims), blk, _stream()), 'fc_backward_wide')
+                return gx, None, None, None, gw, None, None, None, None
+            zonal, spherical, phase = ctx.saved_tensors[1:]
+            g_z, g_s = torch.empty_like(zonal), torch.empty_like(spherical)
+            g_p = torch.empty_like(phase) if ctx.ftype == 1 else None
+            fp = FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ctx.ftype, g_z.data_ptr(), g_s.data_ptr(),
+                                g_p.data_ptr() if g_p is not None else None)
+            check(lib.fc_backward_wide(_p(x), _p(gy), _p(sten), ctypes.byref(by_s), records, ctypes.byref(fp), None, None, _p(gx), _p(ws), nbytes,
+                                       ctypes.byref(dims), blk, _stream()), 'fc_backward_wide')
+        return gx, g_z, g_s, g_p, None, None, None, None, None
+
+
+def _wide_checks(x, graph, I, R, F):
+    if x.dtype != torch.complex64:
+        raise ValueError('field_conv expects complex64 features')
+    if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != I:
+        raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {I})')
+    if R != graph.R or F != graph.F:
+        raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter has n_rings={R}, 2 band_limit + 1 = {F}')
+    if graph.n_targets != graph.N or graph.forward_split is not None or graph.on_gx is not None:
+        raise _lib.FieldConvNativeError('layers wider than the channel block are not available on a partitioned mesh '
+                                        '(restricted targets / exchange hooks)')
+
+
 def _channel_block(graph, I, O, B):
     """Widest channel block (<= 64) the compiled kernels take for this stencil shape: 64 in general, less when slab,
     partial sums and record ring would not fit the CU's LDS (e.g. 8 rings with more than 56 channels)."""
@@ -562,8 +638,8 @@ def _channel_block(graph, I, O, B):
 
 def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
     """FieldConv from the raw module parameters (see FieldConv.forward).  Layers wider than the kernels' channel block
-    (64, fewer for the largest ring counts) run as blocks of input x output channels: the operator is linear in the
-    input channels (partial outputs are summed) and independent across output channels (outputs are concatenated)."""
+    (64, fewer for the largest ring counts) run as blocks of input x output channels, enqueued by one native call per pass
+    (_WideFieldConvFn): the operator is linear in the input channels and independent across output channels."""
     _require_device(x, 'field_conv')
     O, I = zonal.shape[0], zonal.shape[1]
     if _run_time_path(x, graph):
@@ -572,18 +648,9 @@ def field_conv_params(x, zonal, spherical, phase, ftype, band_limit, graph):
         from .nn.field_conv import effective_filter          # the (tiny) assembly and its autograd in torch
         return _generic_field_conv(x, effective_filter(zonal, spherical, phase, int(ftype), int(band_limit)), graph)
     blk = _channel_block(graph, I, O, band_limit)
-    if I > blk or O > blk:
-        outs = []
-        for o0 in range(0, O, blk):
-            osl = slice(o0, min(o0 + blk, O))
-            acc = None
-            for i0 in range(0, I, blk):
-                isl = slice(i0, min(i0 + blk, I))
-                part = field_conv_params(x[:, isl], zonal[osl, isl], spherical[osl, isl], phase[osl, isl], ftype, band_limit,
-                                         graph)
-                acc = part if acc is None else acc + part
-            outs.append(acc)
-        return torch.cat(outs, dim=1)
+    if I > blk or O > blk:              # channel blocks, enqueued natively (csrc/fc_wide.hip)
+        _wide_checks(x, graph, I, zonal.shape[2], 2 * band_limit + 1)
+        return _WideFieldConvFn.apply(x, zonal, spherical, phase, None, int(ftype), int(band_limit), graph, int(blk))
     if x.dtype != torch.complex64:
         raise ValueError('field_conv expects complex64 features')
     if x.dim() != 2 or x.shape[0] != graph.N or x.shape[1] != zonal.shape[1]:
@@ -610,14 +677,8 @@ def field_conv(x, w_eff, graph):
         return _generic_field_conv(x, w_eff, graph)
     blk = _channel_block(graph, I, O, (graph.F - 1) // 2)
     if I > blk or O > blk:              # channel blocks, as in field_conv_params
-        outs = []
-        for o0 in range(0, O, blk):
-            acc = None
-            for i0 in range(0, I, blk):
-                part = field_conv(x[:, i0:i0 + blk], w_eff[o0:o0 + blk, i0:i0 + blk], graph)
-                acc = part if acc is None else acc + part
-            outs.append(acc)
-        return torch.cat(outs, dim=1)
+        _wide_checks(x, graph, I, w_eff.shape[2], w_eff.shape[3])
+        return _WideFieldConvFn.apply(x, None, None, None, w_eff, 0, (graph.F - 1) // 2, graph, int(blk))
     return _FieldConvFn.apply(x, w_eff, graph)
 
 
@@ -656,8 +717,9 @@ class _TangentLinFn(torch.autograd.Function):
         return gx, g_re, g_im
 
 
-class _TangentLinF64Fn(torch.autograd.Function):
-    """reference nn/tangent_lin.py:27-29 in double precision: three complex GEMMs on the matrix pipe (fc_cgemm), any width"""
+class _TangentLinGemmFn(torch.autograd.Function):
+    """reference nn/tangent_lin.py:27-29 as three complex GEMMs on the matrix pipe (fc_cgemm): double precision, and mixes wider
+    than the 64 channels the LDS-resident fp32 kernel takes"""
 
     @staticmethod
     def forward(ctx, x, re_w, im_w):
@@ -692,22 +754,14 @@ def tangent_lin(x, re_w, im_w):
     if x.dtype == torch.complex128:
         if re_w.dtype != torch.float64 or x.dim() != 2 or x.shape[1] != re_w.shape[1]:
             raise ValueError(f'tangent_lin: x {tuple(x.shape)} {x.dtype} does not match weights {tuple(re_w.shape)} {re_w.dtype}')
-        return _TangentLinF64Fn.apply(x, re_w, im_w)
+        return _TangentLinGemmFn.apply(x, re_w, im_w)
     if x.dtype != torch.complex64:
         raise ValueError('tangent_lin expects complex64 features')
     if x.dim() != 2 or x.shape[1] != re_w.shape[1]:
         raise ValueError(f'x has shape {tuple(x.shape)}, expected (N, {re_w.shape[1]})')
     O, I = re_w.shape
-    if I > MAX_CHANNELS or O > MAX_CHANNELS:        # the kernel keeps the whole filter in LDS: wider mixes run as 64 x 64 blocks
-        outs = []
-        for o0 in range(0, O, MAX_CHANNELS):
-            acc = None
-            for i0 in range(0, I, MAX_CHANNELS):
-                part = _TangentLinFn.apply(x[:, i0:i0 + MAX_CHANNELS], re_w[o0:o0 + MAX_CHANNELS, i0:i0 + MAX_CHANNELS],
-                                           im_w[o0:o0 + MAX_CHANNELS, i0:i0 + MAX_CHANNELS])
-                acc = part if acc is None else acc + part
-            outs.append(acc)
-        return torch.cat(outs, dim=1)
+    if I > MAX_CHANNELS or O > MAX_CHANNELS:        # the fp32 kernel keeps the whole filter in LDS: wider mixes are plain GEMMs
+        return _TangentLinGemmFn.apply(x, re_w, im_w)
     return _TangentLinFn.apply(x, re_w, im_w)
 
 

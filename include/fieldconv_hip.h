@@ -62,8 +62,8 @@ const char* fc_status_string(int status);
 /* 1 if the compiled kernels cover these dims, 0 otherwise (then every call returns FC_ERR_UNSUPPORTED for them):
  * (n_rings, band_limit) among the compiled shapes, at most 64 channels, and slab + partial sums + record ring within
  * the CU's 160 KB of LDS in the current MFMA mode (8 rings with more than 56 channels are not, in the default mode).
- * The operator is linear in the input channels and independent across output channels: wider layers are run as
- * channel blocks by the caller (fieldconv_amd/functional.py does). */
+ * The operator is linear in the input channels and independent across output channels: wider layers run as channel blocks
+ * (fc_forward_wide / fc_backward_wide below). */
 int fc_supported(const fc_dims* dims);
 /* Which kernels a forward + backward pass with these dims launches in this process, as one line of text (kernel family,
  * record kind, MFMA mode, tile counts): the library picks them from the dims, the device's CU count and the development
@@ -202,6 +202,24 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
  * differently from fc_backward_finish's single chain.  fc_backward_all uses it when it is given params. */
 int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
                               const fc_filter_params* params, void* stream);
+
+/* ---- layers wider than 64 channels, natively (reference nn/field_conv.py:62 takes any width) ----------------------------------- *
+ * The kernels above take at most 64 input and 64 output channels (one channel per lane in their gather phases).  The operator is
+ * linear in the input channels and independent across output channels, so a wider layer is nob x nib launches of the same
+ * kernels on channel blocks of `block` channels (a multiple of 8, <= 64, with fc_supported(block x block) true); these two entry
+ * points enqueue a whole pass from one call -- strided 2-D copies cut x / gy into contiguous blocks, the filter images are packed
+ * straight from the (o0, i0) block of the full parameter tensors (or of an explicit W_eff), the sum over input blocks rides in the
+ * convolution's residual epilogue, the input gradient's sum over output blocks is a fixed-order sum of partials, and a block's
+ * parameter gradients land in their block of the full gradient tensors (params->g_*), or in gw_eff (O,I,R,F) for an explicit filter.
+ * Exactly one of `params` / `w_eff` is given.  dims carries the FULL widths I, O; y (N,O), gx (N,I) complex64, overwritten.
+ * workspace: fc_wide_workspace_bytes(dims, block, records, backward) bytes. */
+size_t fc_wide_workspace_bytes(const fc_dims* dims, int32_t block, int32_t records, int32_t backward);
+int fc_forward_wide(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind, const fc_filter_params* params,
+                    const float* w_eff, float* y, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
+                    int32_t block, void* stream);
+int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
+                     const fc_filter_params* params, const float* w_eff, float* gw_eff, float* gx, void* workspace,
+                     size_t workspace_bytes, const fc_dims* dims, int32_t block, void* stream);
 
 /* ---- any (n_rings, band_limit): the run-time path for shapes outside the compiled set (reference nn/field_conv.py:62-98
  * takes any) ---- *

@@ -667,6 +667,58 @@ def test_wide_layers_are_split_into_channel_blocks(dev):
     assert rel_err(H(grads[1]), gz) < TOL and rel_err(H(grads[2]), gs) < TOL and rel_err(H(grads[3]), gp) < TOL
 
 
+def test_wide_layers_natively_explicit_filter_three_blocks_and_records(dev):
+    """The native channel-block path (csrc/fc_wide.hip) beyond the module case above: an explicit filter (field_conv) with THREE
+    input blocks and two output blocks on dense stencil rows; the module on an FCPrecomp stencil (record-driven kernels inside
+    the blocks, 130 -> 70 channels); a wide FCResNetBlock (wide TangentLin through fc_cgemm, 100 -> 72 channels) against the
+    oracle's block; and the source contains no Python block loop any more."""
+    import inspect
+    from fieldconv_amd import functional as Fn
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    from fieldconv_amd.nn import FCResNetBlock, FieldConv
+    src = inspect.getsource(Fn.field_conv_params) + inspect.getsource(Fn.field_conv) + inspect.getsource(Fn._GenericFieldConvFn)
+    assert 'torch.cat' not in src and 'matmul' not in src and ' @ ' not in src
+    # (1) explicit filter, dense rows, 150 -> 70 channels
+    N, k, I, O, B, R = 150, 8, 150, 70, 1, 3
+    edges, sten, x, gy, W = make_case(23, N, k, I, O, B, R, True)
+    graph = SupportGraph(edges.to(dev), sten.to(dev), N)
+    xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    y = field_conv(xd, Wd, graph)
+    gx, gW = torch.autograd.grad(y, [xd, Wd], grad_outputs=gy.to(dev))
+    y_ref = orc.fieldconv_forward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy())
+    gx_ref, gW_ref = orc.fieldconv_backward(x.numpy(), edges.numpy(), sten.numpy(), W.numpy(), gy.numpy())
+    assert rel_err(H(y), y_ref) < TOL and rel_err(H(gx), gx_ref) < TOL and rel_err(H(gW), gW_ref) < TOL
+    # (2) module on an FCPrecomp stencil (records), 130 -> 70 channels, band limit 2
+    from fieldconv_amd.data import sphere_support
+    from oracle.torch_composites import FCPrecomp
+    N, k, I, O, B, R = 700, 10, 130, 70, 2, 6
+    data = sphere_support(N, k, seed=4)
+    e2, s2, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(8)
+    x2 = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    gy2 = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=1).to(dev)
+    x2d = x2.to(dev).requires_grad_(True)
+    y2 = conv(x2d, e2.to(dev), s2.to(dev))
+    grads = torch.autograd.grad(y2, [x2d] + list(conv.parameters()), grad_outputs=gy2.to(dev))
+    z, sp, ph = H(conv.zonal), H(conv.spherical), H(conv.phase)
+    W2 = orc.effective_filter(z, sp, ph, 1, B)
+    y2_ref, gx2_ref, gW2_ref = orc.fieldconv_forward_backward(x2.numpy(), e2.numpy(), s2.numpy(), W2, gy2.numpy())
+    gz, gs, gp = orc.effective_filter_vjp(gW2_ref, z, sp, ph, 1, B)
+    assert rel_err(H(y2), y2_ref) < TOL and rel_err(H(grads[0]), gx2_ref) < TOL
+    assert rel_err(H(grads[1]), gz) < TOL and rel_err(H(grads[2]), gs) < TOL and rel_err(H(grads[3]), gp) < TOL
+    # (3) a wide block: output against the oracle's block
+    blk = FCResNetBlock(100, 72, band_limit=1, n_rings=3, ftype=1).to(dev)
+    N, k = 150, 8
+    e3, s3, x3, _, _ = make_case(29, N, k, 100, 72, 1, 3, True)
+    y3 = blk(x3.to(dev), e3.to(dev), s3.to(dev))
+    p3 = {n_: H(v) for n_, v in blk.state_dict().items()}
+    y3_ref = orc.fc_resnet_block_forward(x3.numpy(), e3.numpy(), s3.numpy(), p3, 1, 1)
+    assert rel_err(H(y3), y3_ref) < 2 * TOL
+    torch.autograd.grad(y3.abs().sum(), list(blk.parameters()))          # the backward pass of every piece runs
+
+
 # ---------------------------------------------------------------- full benchmark size: properties
 def test_full_size_properties(dev):
     """Config 2 of BASELINE.json (20k vertices, k=32, C=48, B=2, R=6): the oracle needs ~32 GB at
