@@ -88,6 +88,14 @@ __device__ __forceinline__ void lds_dma16_untracked(const void* src_lane, const 
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src_lane) : "memory", "m0");
 }
 
+// The same for the lanes of `mask` only (a wave-uniform 64-bit lane mask): lane l < popcount writes its 16 bytes at
+// lds_dst_uniform + 16 l.  Uniform control flow around the call (the full EXEC mask is restored afterwards).
+__device__ __forceinline__ void lds_dma16_untracked_lanes(const void* src_lane, const void* lds_dst_uniform, unsigned long long mask) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_uniform);
+    asm volatile("s_mov_b64 exec, %2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, -1"
+                 : : "s"(dst), "v"(src_lane), "s"(mask) : "memory", "m0");
+}
+
 // Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
 __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);

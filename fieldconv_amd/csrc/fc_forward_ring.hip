@@ -30,8 +30,8 @@ void describe_forward(const fc_dims* d, int kind, char* buf, size_t n) {
     const char* rec = kind == 2 ? "geometric records" : kind == 1 ? "factored records" : "dense rows";
     if (kind != 0 && forward_ring_fits(d)) {
         const RingPlan p = plan_ring(d->O, 2 * d->B + 1, d->I, split_mode());
-        snprintf(buf, n, "fc_forward_ring_kernel<%s,%s> (ring-major, 2 workgroups x 8 wavefronts per CU, %zu B LDS, %d record chunks)", rec,
-                 mode, p.lds, p.nr);
+        snprintf(buf, n, "fc_forward_ring_kernel<%s,%s> (ring-major, 2 workgroups x 8 wavefronts per CU, %zu B LDS, %d %s record chunks%s)",
+                 rec, mode, p.lds, p.nr, p.logh ? "half-size" : "1 KiB", p.alias ? ", partials aliased onto the slab" : "");
     } else {
         snprintf(buf, n, "%s<%s,%s> (frequency-major, 16 wavefronts per CU, parts=%d)", kind ? "fc_forward_factored_kernel" : "fc_forward_kernel",
                  rec, mode, 1 << forward_parts_log2(d, kind));
@@ -43,10 +43,10 @@ size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves) {
     return (size_t)g.MP + (size_t)R * halves * g.MP * g.KP;
 }
 
-template <int R, int B, bool GEO>
+template <int R, int B, bool GEO, int LOGH>
 static int launch_forward_ring(const float2* x, const float* rec, const fc_csr* g, const float* wpk, float2* y, const RingArgs& a,
                                size_t lds, int grid, hipStream_t stream) {
-    auto kern = fc_forward_ring_kernel<R, B, GEO>;
+    auto kern = fc_forward_ring_kernel<R, B, GEO, LOGH>;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDuoThreads), lds, stream, x, rec, g->rowptr, g->runs, wpk, y, a);
@@ -66,6 +66,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.part_stride = (uint32_t)forward_part_stride(d);
     a.epi = make_epi(epi);
     a.nr = p.nr;
+    a.alias_part = p.alias;
     a.wpk_bytes = (uint32_t)(packed_ring_image_floats(d->O, F, d->I, d->R, p.g.split) * sizeof(float));
     a.slab_bytes_w = (uint32_t)(2 * p.g.split * p.g.MP * p.g.KP * 2);
     static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();
@@ -85,10 +86,17 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     int rc = FC_ERR_UNSUPPORTED;
     const float2* x2 = reinterpret_cast<const float2*>(x);
     float2* y2 = reinterpret_cast<float2*>(a.parts_log2 ? static_cast<float*>(ws) : y);
-#define FC_CASE(RR, BB)                                                                                    \
-    if (d->R == RR && d->B == BB)                                                                          \
-        rc = kind == 2 ? launch_forward_ring<RR, BB, true>(x2, rec, g, wpk, y2, a, p.lds, grid, stream)    \
-                       : launch_forward_ring<RR, BB, false>(x2, rec, g, wpk, y2, a, p.lds, grid, stream);
+#define FC_CASE(RR, BB)                                                                                            \
+    if (d->R == RR && d->B == BB) {                                                                                \
+        if constexpr (BB >= 2) {                                                                                   \
+            if (p.logh)                                                                                            \
+                rc = kind == 2 ? launch_forward_ring<RR, BB, true, 1>(x2, rec, g, wpk, y2, a, p.lds, grid, stream)  \
+                               : launch_forward_ring<RR, BB, false, 1>(x2, rec, g, wpk, y2, a, p.lds, grid, stream); \
+        }                                                                                                          \
+        if (!p.logh)                                                                                               \
+            rc = kind == 2 ? launch_forward_ring<RR, BB, true, 0>(x2, rec, g, wpk, y2, a, p.lds, grid, stream)      \
+                           : launch_forward_ring<RR, BB, false, 0>(x2, rec, g, wpk, y2, a, p.lds, grid, stream);    \
+    }
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
     if (rc != FC_OK || a.parts_log2 == 0) return rc;

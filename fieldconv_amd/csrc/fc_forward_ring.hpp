@@ -37,7 +37,9 @@ struct RingArgs {
     int ntiles;
     int parts_log2;         // edge split for small meshes, as in FwdArgs
     uint32_t part_stride;
-    int nr;                 // 1 KiB record chunks per stream in the LDS ring (2 or 4)
+    int nr;                 // record chunks per stream in the LDS ring (2 or 4)
+    int alias_part;         // 1: the k-partials of the tile epilogue live in the slab's first bytes (plans that would not fit half a
+                            // CU's LDS otherwise: 64 channels at band limit 3); costs two more barriers and a re-zeroing per tile
     int nv_full;            // work items [0, nv_full) are whole 16-vertex tiles; items beyond are HALF tiles (8 vertices, one per
                             // wavefront): the last, partly filled round of a persistent grid is cut in two so that every
                             // workgroup gets a share of it (1250 tiles on 512 workgroups: 2.6 tile times instead of 3)
@@ -66,30 +68,36 @@ struct RingLds {
     int* runs;          // [8 wavefronts][2 streams][2 tile parities][8] ring-run offsets
     float* ring;        // [8 wavefronts][2 streams][nr][256]
 };
-__host__ __device__ inline size_t ring_lds_floats(const MmaGeom& g, int nr) {
-    return (size_t)slab_floats(g) + partial_floats(g.NKP, g.MP) + kTile + kDuoWaves * 32 + (size_t)kDuoWaves * 2 * nr * 256;
+// chunk_floats: 256 (1 KiB record chunks) or 128 (half-size chunks); alias: the partials share the slab's memory
+__host__ __device__ inline size_t ring_lds_floats(const MmaGeom& g, int nr, int chunk_floats = 256, bool alias = false) {
+    const size_t slab = slab_floats(g), part = partial_floats(g.NKP, g.MP);
+    return (alias ? (slab > part ? slab : part) : slab + part) + kTile + kDuoWaves * 32 + (size_t)kDuoWaves * 2 * nr * chunk_floats;
 }
-__device__ __forceinline__ RingLds ring_lds(char* smem, const MmaGeom& g) {
+__device__ __forceinline__ RingLds ring_lds(char* smem, const MmaGeom& g, bool alias) {
     RingLds l;
     l.slab = reinterpret_cast<float*>(smem);
-    l.part = l.slab + slab_floats(g);
-    l.vinv = l.part + partial_floats(g.NKP, g.MP);
+    l.part = alias ? l.slab : l.slab + slab_floats(g);
+    const size_t slab = slab_floats(g), part = partial_floats(g.NKP, g.MP);
+    l.vinv = l.slab + (alias ? (slab > part ? slab : part) : slab + part);
     l.runs = reinterpret_cast<int*>(l.vinv + kTile);
     l.ring = reinterpret_cast<float*>(l.runs + kDuoWaves * 32);
     return l;
 }
 
-template <int R, int B, bool GEO>
+// LOGH = 1: half-size record chunks (512 bytes, 32 DMA lanes) -- a stream's ring is then 1 KiB at nr = 2
+template <int R, int B, bool GEO, int LOGH = 0>
 __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
     const float2* __restrict__ gx_, const float* __restrict__ grec, const int32_t* __restrict__ growptr,
     const int32_t* __restrict__ gruns, const float* __restrict__ gwpk, float2* __restrict__ gy_, const RingArgs a) {
     constexpr int F = 2 * B + 1;
     constexpr int RECF = GEO ? kGeoRecordFloats : factored_record_floats(B);
-    constexpr int LOG_CR = GEO ? kGeoLogChunkRecords : factored_log_chunk_records(B);
+    constexpr int LOG_CR = (GEO ? kGeoLogChunkRecords : factored_log_chunk_records(B)) - LOGH;
     constexpr int CR = 1 << LOG_CR;
+    constexpr int CHUNK = 256 >> LOGH;          // floats per ring chunk
+    static_assert(LOG_CR >= 2, "a record chunk holds at least four records");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MmaGeom& g = a.g;
-    const RingLds l = ring_lds(smem, g);
+    const RingLds l = ring_lds(smem, g, a.alias_part != 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,10 +123,11 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
     const int nvt = a.ntiles << pl;
 
     // stream j in {0, 1}: my target in row wave + 8 j of the tile
-    auto ring_of = [&](const int j) { return l.ring + (wave * 2 + j) * nr * 256; };
+    auto ring_of = [&](const int j) { return l.ring + (wave * 2 + j) * nr * CHUNK; };
     auto dma_chunk = [&](const int j, const int first, const int ch) {
         const float* src = grec + ((size_t)first + (size_t)ch * CR) * RECF + lane * 4;
-        lds_dma16_untracked(src, ring_of(j) + (ch & (nr - 1)) * 256);
+        if constexpr (LOGH == 0) lds_dma16_untracked(src, ring_of(j) + (ch & (nr - 1)) * CHUNK);
+        else lds_dma16_untracked_lanes(src, ring_of(j) + (ch & (nr - 1)) * CHUNK, 0xffffffffull);        // 32 lanes x 16 bytes
     };
     // slots [b, e) of stream j's target in virtual tile vt; its ring-run offsets (relative to b, clipped to the part) go to LDS
     auto slot_range = [&](const int vt, const int j, const int par, int& b, int& e) {
@@ -151,8 +160,8 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
         }
     };
     auto rec_ptr = [&](const float* ring, const int s) {
-        if constexpr (CR * RECF == 256) return ring + ((s * RECF) & (nr * 256 - 1));
-        else return ring + ((s >> LOG_CR) & (nr - 1)) * 256 + (s & (CR - 1)) * RECF;
+        if constexpr (CR * RECF == CHUNK) return ring + ((s * RECF) & (nr * CHUNK - 1));
+        else return ring + ((s >> LOG_CR) & (nr - 1)) * CHUNK + (s & (CR - 1)) * RECF;
     };
     // source rows of the first two slots of a stream whose first record chunk is on its way to the ring
     auto first_rows = [&](const int j, const int nslots, float2& r0, float2& r1) {
@@ -395,6 +404,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
             first_rows(j, end[j] - beg[j], px[j][0], px[j][1]);       // the next tile's first source rows fly during the epilogue
         }
         contract(R - 1);
+        if (a.alias_part) __syncthreads();               // every wavefront's last reads of the slab are done: its memory takes the partials
         if (mma_active) store_partial(l.part, g, mt, kp, lane, tot_re, tot_im);
         tot_re = f32x4{0.f, 0.f, 0.f, 0.f};
         tot_im = tot_re;
@@ -419,6 +429,13 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
                 }
             }
         }
+        if (a.alias_part) {
+            // the slab's memory held the partials: zero them (the k padding of a slab row is never written by flush_row and meets
+            // zero filter entries in the contraction -- it must not hold the bit patterns of partial sums)
+            __syncthreads();
+            for (int idx = tid; idx < partial_floats(g.NKP, g.MP); idx += kDuoThreads) l.slab[idx] = 0.f;
+            __syncthreads();
+        }
         stamp(6);
         par ^= 1;
     }
@@ -430,19 +447,26 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
 struct RingPlan {
     MmaGeom g;
     int nr;
+    int logh;               // 1: half-size record chunks
+    int alias;              // 1: partials aliased onto the slab
     size_t lds;
     bool ok;
 };
+// In order of preference: 4 or 2 full chunks per stream; then the partials aliased onto the slab; then half-size chunks as well
+// (64 channels at band limit 3: 107 KB -> 90 KB -> 74 KB).  Half-size chunks exist for band limits >= 2 (kernel instantiations).
 inline RingPlan plan_ring(int M, int F, int channels, int halves) {
     RingPlan p;
     p.g = ring_geom(M, F, channels, halves);
     p.ok = false;
-    p.nr = 0; p.lds = 0;
+    p.nr = 0; p.lds = 0; p.logh = 0; p.alias = 0;
     if (halves != 2 || p.g.NMT > kDuoWaves) return p;
-    for (int nr = 4; nr >= 2; nr >>= 1) {
-        const size_t lds = ring_lds_floats(p.g, nr) * sizeof(float);
+    static const bool compact = !(getenv("FC_RING_COMPACT") && atoi(getenv("FC_RING_COMPACT")) == 0);      // 0: round-3 plans only
+    const int tries[4][3] = {{4, 0, 0}, {2, 0, 0}, {2, 0, 1}, {2, 1, 1}};       // nr, logh, alias
+    for (int t = 0; t < (compact ? 4 : 2); ++t) {
+        if (tries[t][1] && F < 5) continue;
+        const size_t lds = ring_lds_floats(p.g, tries[t][0], 256 >> tries[t][1], tries[t][2] != 0) * sizeof(float);
         if (lds <= kDuoMaxLds) {
-            p.nr = nr; p.lds = lds; p.ok = true;
+            p.nr = tries[t][0]; p.logh = tries[t][1]; p.alias = tries[t][2]; p.lds = lds; p.ok = true;
             break;
         }
     }

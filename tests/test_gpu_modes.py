@@ -30,6 +30,7 @@ MODES = {
     'separate_pointwise_operators': {'FIELDCONV_NO_FUSED_EPILOGUE': '1'},   # no residual / modReLU epilogue in the convolutions
     'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
+    'ring_without_compact_lds_plans': {'FC_RING_COMPACT': '0'},   # 64 channels at band limit 3 back on the frequency-major forward kernel
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
     'separate_finish_kernels': {'FC_SPLIT_FINISH': '1'},   # fc_backward_finish + fc_filter_param_grads instead of the fused launch
     'no_half_tiles': {'FC_HALF_TILES': '0'},
