@@ -281,6 +281,13 @@ def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, a
 
 
 def run_identity(use_dist, dev, backend, local_rank, extra):
+    try:
+        return _run_identity(use_dist, dev, backend, local_rank, extra)
+    except Exception as exc:          # noqa: BLE001  (a report, never the reason for a failed bench)
+        return {'error': f'{type(exc).__name__}: {exc}'[:300], 'ranks': dist.get_world_size() if use_dist else 1}
+
+
+def _run_identity(use_dist, dev, backend, local_rank, extra):
     """What actually ran where: one record per rank (all-gathered), so that a multi-GPU line can be checked the first time an
     8-GPU node produces one -- the communicator's size as RCCL sees it, the device every rank sat on, its share of the mesh."""
     props = torch.cuda.get_device_properties(dev)
@@ -577,8 +584,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     # What the collectives cost a step: the same step with the three collectives taken out (halo rows left as they are, no
     # gradient exchange, no all-reduce -- same kernels, same shapes), timed at the sustained clock like `settled`; the
     # difference to the settled step is the communication a step does not hide (its host time included).
-    comm = None
-    if use_dist and not graph_step:
+    def measure_comm():
         xl0 = torch.cat([x.detach(), torch.zeros(plan.n_halo, C, dtype=x.dtype, device=dev)]).requires_grad_(True)
         gyl = gy if mesh_graph.n_targets == n_owned else torch.cat([gy, torch.zeros(n_local - n_owned, C, dtype=gy.dtype, device=dev)])
         saved_hooks = (mesh_graph.on_gx, mesh_graph.forward_split)
@@ -610,6 +616,16 @@ def run_layer(args, world, rank, dev, use_dist, backend):
                 'allreduce_bytes': 4 * buckets.flat.numel(),
                 'note': 'exposed = (step with halo exchange forward, transposed exchange backward, bucketed all-reduce) - (the same '
                         'kernels without them), both at the sustained clock, max over ranks'}
+        return comm
+
+    comm = None
+    if use_dist and not graph_step:
+        hooks = (mesh_graph.on_gx, mesh_graph.forward_split)
+        try:        # (an extra: whatever goes wrong here on a first multi-rank RCCL run must not cost the line its value)
+            comm = measure_comm()
+        except Exception as exc:        # noqa: BLE001
+            mesh_graph.on_gx, mesh_graph.forward_split = hooks
+            comm = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     identity = run_identity(use_dist, dev, backend, dev.index, {'owned_vertices': int(n_owned), 'halo_rows': 0 if plan is None else plan.n_halo,
                                                                  'edges': E})
     prep_ms, prep_mallocs = measure_prep()

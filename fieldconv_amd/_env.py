@@ -38,6 +38,16 @@ SWITCHES = {
     'BENCH_GRAPH_STEP': '1: the partitioned step captured in one HIP graph',
 }
 
+# read by the test suite only (tests/test_gpu_parity.py); known names, so that a shell that still has them set can run bench.py
+TEST_SWITCHES = {
+    'FC_FUZZ_SHAPES': 'number of shapes in the seeded sweep against the oracle (default 40)',
+    'FC_FUZZ_SEED': 'seed of that sweep',
+    'FC_FUZZ_WIDE': '1: the sweep also draws layers wider than 64 channels and (n_rings, band_limit) pairs outside the compiled set',
+    'FC_DIST_TEST_DEVICE': 'cuda: the distributed test worker runs the HIP kernels (two gloo ranks on one GPU)',
+    'FC_DIST_OVERLAP': '0: the distributed test worker without forward / backward overlap',
+    'FC_DIST_PLAN_ONLY': '1: the distributed test worker checks partition and halo plan at config-4 size only',
+}
+
 PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')
 WRONG_RESULTS = ('FC_DEBUG', 'FC_DEBUG_BWD')
 
@@ -51,4 +61,4 @@ def active(environ=None):
 def unknown(environ=None):
     """Names with one of our prefixes that nothing reads (typos, switches of removed kernels)."""
     environ = os.environ if environ is None else environ
-    return sorted(k for k in environ if k.startswith(PREFIXES) and k not in SWITCHES)
+    return sorted(k for k in environ if k.startswith(PREFIXES) and k not in SWITCHES and k not in TEST_SWITCHES)

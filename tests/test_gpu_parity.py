@@ -481,11 +481,12 @@ def test_factored_stencil_path_vs_oracle_and_dense(shape, dev):
 
 def _random_shapes(n, seed=2024):
     rng = np.random.default_rng(seed)
+    wide = os.environ.get('FC_FUZZ_WIDE', '0') == '1'         # also layers wider than 64 channels and shapes of the run-time path
     shapes = []
     for _ in range(n):
-        R = int(rng.integers(2, 9))
-        B = int(rng.integers(1, 4))
-        I, O = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+        R = int(rng.integers(2, 12 if wide else 9))
+        B = int(rng.integers(1, 5 if wide else 4))
+        I, O = int(rng.integers(1, 161 if wide else 65)), int(rng.integers(1, 161 if wide else 65))
         N = int(rng.integers(5, 400))
         k = int(rng.integers(1, 45))
         shapes.append((N, k, I, O, B, R, bool(rng.integers(0, 2))))
