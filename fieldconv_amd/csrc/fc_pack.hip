@@ -310,7 +310,7 @@ __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, cons
 // the P partials of its (i, r, f) entries -- partial (p, r, f, o, i) lies at gwp[p*sp + r*sr + f*sf + o*so + i], which covers
 // the layouts of both filter-gradient kernel families -- writes gW_eff (when asked for) and leaves it in LDS, from where the
 // workgroup's (pair, ring) threads pull it back to (zonal, spherical, phase) exactly as fc_filter_param_grads_kernel does.
-constexpr int kRpPairs = 16;
+constexpr int kRpPairs = 16;          // (8 / 4 input channels per workgroup: 16 / 26 us instead of 10 at config 2 -- the partials' 128-byte segments shrink)
 constexpr int kRpThreads = 1024;
 constexpr int kRpGroups = 4;           // an entry's P partials are summed in four consecutive groups, by four threads
 constexpr int kRpMaxPer = 16;          // partials per group held in flight

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(1024) void walk(const float2* __restrict__ ggy, con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int O = a.C;
-    const int ol = lane < O ? lane : 0;
+    // lanes beyond the channel count: channel 0 (what the kernels do), or with V bit 512 the LAST channel (the 128-byte line the
+    // neighbouring lanes touch anyway), or with bit 1024 consecutive addresses behind the row (a fourth line)
+    const int ol = lane < O ? lane : ((V & 512) ? O - 1 : (V & 1024) ? lane : 0);
     uint32_t vrow = 8u * O;
     asm volatile("" : "+v"(vrow));
     float* const ring = reinterpret_cast<float*>(smem) + wave * 4 * 256;      // LDS record ring: 4 chunks of 16 records
@@ -504,7 +506,7 @@ static void run(const char* name, const Args& a, long E, int threads, int lds_by
     hipFuncSetAttribute(reinterpret_cast<const void*>(walk<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int reps = 20;
+    const int reps = 200;
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(walk<V>, dim3(grid), dim3(threads), lds_bytes, 0, a.gy, a.rec, a.rec8, a.rowptr, a.runs, a);
     hipEventRecord(e0);
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(walk<V>, dim3(grid), dim3(threads), lds_bytes, 0, a.gy, a.rec, a.rec8, a.rowptr, a.runs, a);
@@ -588,7 +590,11 @@ int main(int argc, char** argv) {
     hipMalloc(&dclk, 4 * 8);
     a.gy = reinterpret_cast<const float2*>(dgy); a.rec = drec; a.rec8 = drec8; a.rec8b = drec8b; a.rowptr = drow; a.runs = druns; a.out = dout; a.clk = dclk; a.N = N; a.C = C;
     printf("walk microbenchmark: N=%d, E=%ld (%.1f slots per vertex), C=%d, neighbour window %d rows per tile\n", N, E, (double)E / N, C, W);
-    for (int threads : {1024, 512, 256}) {
+    // the clock governor needs ~100 ms of load to settle: run the shipped walk for ~0.4 s first, and compare variants
+    // by cycles (in-kernel clock) rather than by microseconds -- a variant's clock depends on what ran before it
+    for (int i = 0; i < 6000; ++i) hipLaunchKernelGGL(walk<0 | 2 | 4>, dim3(256), dim3(1024), 100 * 1024, 0, a.gy, a.rec, a.rec8, a.rowptr, a.runs, a);
+    hipDeviceSynchronize();
+    for (int threads : {1024, 1024, 512, 256}) {
         const int lds = 100 * 1024;        // one workgroup per CU
         run<0 | 2 | 4>("LDS ring, rows, math (shipped walk)", a, E, threads, lds);
         run<0 | 2 | 4 | 256>("shipped walk, math under an exec mask of C lanes", a, E, threads, lds);
@@ -606,6 +612,9 @@ int main(int argc, char** argv) {
         run<16 | 2 | 4>("no records, rows, math", a, E, threads, lds);
         run<16 | 4>("no records, no rows, math only", a, E, threads, lds);
         run<16 | 2>("no records, rows only", a, E, threads, lds);
+        run<16 | 2 | 512>("rows only, idle lanes read the last channel", a, E, threads, lds);
+        run<16 | 2 | 1024>("rows only, idle lanes read on behind the row", a, E, threads, lds);
+        run<0 | 2 | 4 | 512>("shipped walk, idle lanes read the last channel", a, E, threads, lds);
     }
     // two workgroups of 1024 per CU is impossible at 128 registers; 2 x 512 gives the same 4 waves/SIMD with independent workgroups
     run<1 | 2 | 4>("scalar records, rows, math, 2 WG x 512 / CU", a, E, 512, 60 * 1024, 512);
