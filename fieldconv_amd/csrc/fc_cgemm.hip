@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restr
     __shared__ T a_re[kGemmTile][kGemmK + kGemmPad], a_im[kGemmTile][kGemmK + kGemmPad];
     __shared__ T b_re[kGemmK][kGemmTile + kGemmPad], b_im[kGemmK][kGemmTile + kGemmPad];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kGemmTile, n0 = blockIdx.x * kGemmTile;
+    const int m0 = blockIdx.x * kGemmTile, n0 = blockIdx.y * kGemmTile;      // (M, the vertex count in two of the three uses, on the unbounded grid axis)
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;       // this wavefront's quarter of the tile
     const int fr = lane & 15, fq = lane >> 4;
     V4 cre[2][2], cim[2][2];
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restr
 
 template <typename T>
 static int launch_cgemm(const void* A, const void* B, void* C, const GemmArgs& g, hipStream_t stream) {
-    const dim3 grid((g.N + kGemmTile - 1) / kGemmTile, (g.M + kGemmTile - 1) / kGemmTile);
+    const dim3 grid((g.M + kGemmTile - 1) / kGemmTile, (g.N + kGemmTile - 1) / kGemmTile);
+    if (grid.y > 65535u) return FC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(fc_cgemm_kernel<T>, grid, dim3(kGemmThreads), 0, stream, static_cast<const T*>(A), static_cast<const T*>(B),
                        static_cast<T*>(C), g);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
