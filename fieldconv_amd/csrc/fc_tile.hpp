@@ -150,10 +150,16 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 // The same for a complex value scaled by s: hi = (re_hi, im_hi), lo = (re_lo, im_lo).  In vector form hipcc
 // emits v_cvt_pk_f16_f32 (round to nearest even) and folds the scale into the residual's packed FMA.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// The residual comes from v_fma_mixlo / mixhi_f16: lo = half(v*s - hi) with the half operand read in place and one rounding -- two
+// instructions instead of two conversions back to fp32, a packed FMA and a packed conversion (six -> four vector instructions per
+// complex value; bit-identical, since v*s is exact for a power-of-two s and v*s - hi is exact in fp32).
 __device__ __forceinline__ void split_halves2(f32x2 v, float s, f16x2& hi, f16x2& lo) {
     const f32x2 vs = v * f32x2{s, s};
     hi = __builtin_convertvector(vs, f16x2);
-    lo = __builtin_convertvector(vs - __builtin_convertvector(hi, f32x2), f16x2);
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v.x), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v.y), "v"(s), "v"(hi));
+    lo = __builtin_bit_cast(f16x2, l);
 }
 // Writing one ring of a slab row (lane = channel c, element k = r*KI + c).  Neighbouring lanes exchange
 // their packed halves over DPP so that every lane stores two full dwords with ONE ds_write2_b32 instead of
