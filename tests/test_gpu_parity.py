@@ -91,7 +91,7 @@ def test_pointwise_golden(dev):
 
 
 @pytest.mark.parametrize('N,I,O,offset', [(37, 5, 7, 0), (1000, 48, 48, 0), (333, 64, 33, 0), (20000, 48, 48, 0), (500, 126, 121, 0),
-                                          (130, 16, 16, 1), (5, 1, 3, 0), (4099, 24, 40, 0)])
+                                          (130, 16, 16, 1), (5, 1, 3, 0), (4099, 24, 40, 0), (2048, 48, 50, 0), (2049, 20, 17, 0)])
 def test_pointwise_vs_oracle(N, I, O, offset, dev):
     """Ragged sizes, channel counts off the 16-wide MFMA tile, and an input that starts 8 bytes off a
     16-byte boundary (offset=1 -> scalar load path)."""

@@ -15,6 +15,6 @@ steps = 40
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 calls = sum(int(r['Calls']) for r in rows)
 print(f'GPU busy {tot / steps / 1e6:.3f} ms/step, {calls / steps:.1f} launches/step')
-for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
+for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 60]:
     print(f"{r['Name'][:64]:64s} {int(r['Calls']) / steps:5.1f}/step {float(r['TotalDurationNs']) / steps / 1e3:8.1f} us/step  avg {float(r['AverageNs']) / 1e3:7.1f}")
 PY
