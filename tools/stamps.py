@@ -27,6 +27,7 @@ def main():
     ap.add_argument('which', nargs='?', default='fwd')
     ap.add_argument('--wave', type=int, nargs='*', default=[0, 7])
     ap.add_argument('--tiles', type=int, default=2)
+    ap.add_argument('--warm', type=int, default=5, help='steps before the stamped one (a few hundred: the settled clock)')
     args = ap.parse_args()
     if args.which in ('data', 'filter'):                # which of the two backward kernels stamps (read once by the library)
         os.environ['FC_STAMP_KERNEL'] = args.which
@@ -48,7 +49,7 @@ def main():
     def step():
         y = conv(x, edges, sten)
         torch.autograd.grad(y, [x] + params, grad_outputs=gy)
-    for _ in range(5):
+    for _ in range(args.warm):
         step()
     torch.cuda.synchronize()
     buf = torch.zeros(16 * 256, dtype=torch.int64, device=dev)
