@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
 
 // gw_eff[o][i][r][f] = 1/F sum_p gwp[p][f][r*O+o][i]
 __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __restrict__ gw, int P, int F, int R,
-                                    int O, int I, int KP, int IP) {
+                                    int O, int I, int KP, int IP, int pairs /* k = dump_k(r, o) */) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over (f, k<R*O, i<I), i fastest
     const int total = F * R * O * I;
     if (idx >= total) return;
@@ -571,7 +571,12 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
         s.y += v.y;
     }
     const float sc = 1.f / (float)F;
-    const int r = k / O, o = k - r * O;
+    int r = k / O, o = k - r * O;
+    if (pairs && k < (R >> 1) * 2 * O) {
+        const int pr = k / (2 * O), rem = k - pr * 2 * O;
+        r = 2 * pr + (rem & 1);
+        o = rem >> 1;
+    }
     gw[(((size_t)o * I + i) * R + r) * F + f] = make_float2(s.x * sc, s.y * sc);
 }
 
@@ -651,7 +656,7 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
     const float2* gwp = reinterpret_cast<const float2*>(static_cast<char*>(ws) + p.hdump_bytes);
     const int total = p.F * d->R * d->O * d->I;
     hipLaunchKernelGGL(fc_reduce_gw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, gwp,
-                       reinterpret_cast<float2*>(gw_eff), p.P, p.F, d->R, d->O, d->I, p.KP, p.IP);
+                       reinterpret_cast<float2*>(gw_eff), p.P, p.F, d->R, d->O, d->I, p.KP, p.IP, p.gd.split != 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -662,7 +667,7 @@ int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const 
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes);
     // partial (p, f, k = r*O + o, i) at ((p*F + f)*KP + k)*IP + i
-    return reduce_param_grads_impl(gwp, (size_t)p.F * p.KP * p.IP, (size_t)d->O * p.IP, (size_t)p.KP * p.IP, (size_t)p.IP, p.P, gw_eff,
+    return reduce_param_grads_impl(gwp, (size_t)p.F * p.KP * p.IP, (size_t)d->O * p.IP, (size_t)p.KP * p.IP, (size_t)p.IP, p.gd.split != 0, p.P, gw_eff,
                                    fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream, o0,
                                    i0, Ifull);
 }

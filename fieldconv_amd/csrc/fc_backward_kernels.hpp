@@ -337,21 +337,32 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         if (lane < mg.KI) {
                             lds_u32* const row = (lds_u32*)hre + wave * (KS / 2);    // LDS row of my vertex, see fc_forward_kernels.hpp
                             int o0 = split_pair_offset(lane, mg.split);
-                            float2* const dst2 = reinterpret_cast<float2*>(dst);
-                            int d0 = wave * (a.KD / 2) + lane;                // kept slab: complex entry k = r*O + lane of my vertex's row
+                            // kept slab: my vertex's row, the rings in PAIRS (dump_k): entries (2p, lane) and (2p + 1, lane) are 16
+                            // consecutive bytes, one store -- three per frequency instead of six (a store costs the CU's memory
+                            // path by the instruction, not by the byte: data kernel 165 -> 161 us); the last ring of an odd count alone
+                            f32x2* const dst2 = reinterpret_cast<f32x2*>(dst) + wave * (a.KD / 2);
+                            int d0 = 2 * lane;
+                            f32x2 even = f32x2{0.f, 0.f};
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
                                 f16x2 hi, lo;
                                 split_halves2(h[r][ff], scale, hi, lo);
+                                f32x2 kept = h[r][ff];
+                                if (a.dump_halves) kept = f32x2{__builtin_bit_cast(float, hi), __builtin_bit_cast(float, lo)};
                                 if (lane < O && !(a.dbg & 8)) {
-                                    f32x2 kept = h[r][ff];
-                                    if (a.dump_halves) kept = f32x2{__builtin_bit_cast(float, hi), __builtin_bit_cast(float, lo)};
-                                    if (a.nt_dump) __builtin_nontemporal_store(kept, reinterpret_cast<f32x2*>(dst2) + d0);
-                                    else dst2[d0] = make_float2(kept.x, kept.y);
+                                    if (r & 1) {
+                                        const f32x4 two = f32x4{even.x, even.y, kept.x, kept.y};
+                                        if (a.nt_dump) __builtin_nontemporal_store(two, reinterpret_cast<f32x4*>(dst2 + d0));
+                                        else *reinterpret_cast<f32x4*>(dst2 + d0) = two;
+                                    } else if (r == R - 1) {
+                                        if (a.nt_dump) __builtin_nontemporal_store(kept, dst2 + (R - 1) * O + lane);
+                                        else dst2[(R - 1) * O + lane] = kept;
+                                    }
                                 }
+                                even = kept;
                                 split_pair_store(row, o0, hi, lo, lane, mg.split);
                                 o0 += mg.split * mg.KI;
-                                d0 += O;
+                                if (r & 1) d0 += 2 * O;
                                 asm volatile("" : "+v"(o0), "+v"(d0));
                             }
                         }

@@ -60,9 +60,17 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
 // pick the partial layout of their kernel family
 // (o0, i0, Ifull: the filter is the block [o0, o0 + O) x [i0, i0 + I) of parameter tensors with Ifull input channels; whole
 // layer: 0, 0, 0)
-int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
-                            const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
-                            const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0);
+// (ring_pairs: the partials' k index is dump_k(r, o) * so instead of r * sr + o * so)
+int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
+                            const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
+                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0);
+
+// k index of entry (ring r, channel o) in a row of the kept H slabs, hence of the filter-gradient partials.  The split modes keep the
+// rings in PAIRS -- (2p, o) and (2p + 1, o) adjacent -- so that the data kernel stores two entries with one instruction; the last ring
+// of an odd count, and every ring in fp32 mode, lie ring-major.
+__host__ __device__ inline int dump_k(int r, int o, int R, int O, bool pairs) {
+    return (pairs && (r | 1) < R) ? (r >> 1) * 2 * O + 2 * o + (r & 1) : r * O + o;
+}
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
                                 int o0 = 0, int i0 = 0, int Ifull = 0);
 int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,

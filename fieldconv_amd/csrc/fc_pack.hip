@@ -307,14 +307,14 @@ __global__ void fc_filter_param_grads_kernel(const float2* __restrict__ gw, cons
 
 // The fixed-order sum of the filter-gradient kernels' per-workgroup partials AND the parameter-gradient chain in one launch
 // (fewer and fatter small kernels).  Workgroup = (output channel o, 16 input channels): every thread sums
-// the P partials of its (i, r, f) entries -- partial (p, r, f, o, i) lies at gwp[p*sp + r*sr + f*sf + o*so + i], which covers
-// the layouts of both filter-gradient kernel families -- writes gW_eff (when asked for) and leaves it in LDS, from where the
+// the P partials of its (i, r, f) entries -- partial (p, r, f, o, i) lies at gwp[p*sp + r*sr + f*sf + o*so + i], or with the
+// rings in pairs (RpStrides::pairs) -- writes gW_eff (when asked for) and leaves it in LDS, from where the
 // workgroup's (pair, ring) threads pull it back to (zonal, spherical, phase) exactly as fc_filter_param_grads_kernel does.
 constexpr int kRpPairs = 16;          // (8 / 4 input channels per workgroup: 16 / 26 us instead of 10 at config 2 -- the partials' 128-byte segments shrink)
 constexpr int kRpThreads = 1024;
 constexpr int kRpGroups = 4;           // an entry's P partials are summed in four consecutive groups, by four threads
 constexpr int kRpMaxPer = 16;          // partials per group held in flight
-struct RpStrides { size_t sp, sr, sf, so; };
+struct RpStrides { size_t sp, sr, sf, so; int pairs; };       // pairs: k = dump_k(r, o) (fc_kernels.hpp)
 
 __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     const float2* __restrict__ gwp, const RpStrides st, const int P, float2* __restrict__ gw_out, const float* __restrict__ zonal,
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         const int i = i0 + pi;
         float2 s = make_float2(0.f, 0.f);
         if (i < I) {
-            const float2* src = gwp + (size_t)r * st.sr + (size_t)f * st.sf + (size_t)o * st.so + i;
+            const size_t ro = st.pairs ? (size_t)dump_k(r, o, R, O, true) * st.so : (size_t)r * st.sr + (size_t)o * st.so;
+            const float2* src = gwp + ro + (size_t)f * st.sf + i;
             const int pend = min((grp + 1) * per, P);
             for (int p0 = grp * per; p0 < pend; p0 += kRpMaxPer) {
                 float2 v[kRpMaxPer];
@@ -381,12 +382,12 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
 }
 
 // gwp: the partials, P of them, entry (p, r, f, o, i) at gwp[p*sp + r*sr + f*sf + o*so + i]
-int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, int P, float* gw_eff, const float* zonal,
-                            const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph, float* g_phase,
-                            const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull) {
+int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
+                            const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
+                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull) {
     if (d->R > 8 || d->B > kMaxB || kRpPairs * d->R > kRpThreads) return FC_ERR_UNSUPPORTED;
     const int nit = (d->I + kRpPairs - 1) / kRpPairs;
-    const RpStrides st{sp, sr, sf, so};
+    const RpStrides st{sp, sr, sf, so, ring_pairs ? 1 : 0};
     hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(d->O * nit), dim3(kRpThreads), 0, stream, reinterpret_cast<const float2*>(gwp), st,
                        P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I, d->R, d->B, o0, i0,
                        Ifull > 0 ? Ifull : d->I);

@@ -95,8 +95,9 @@ __device__ __forceinline__ void mma_slab(rsrc_t wimg, int f_bytes, const float* 
     auto ldw = [&](int plane, int kb) { return __builtin_bit_cast(float4, buffer_load16(wimg, wv, f_bytes + plane * wplane + 64 * kb)); };
     float4 wr = ldw(0, kp), wi = ldw(1, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
-        const int kn = min(kb + g.NKP, g.KST - 1);          // next block (clamped re-read at the end)
-        const float4 wr_n = ldw(0, kn), wi_n = ldw(1, kn);
+        const bool more = kb + g.NKP < g.KST;               // (wave-uniform: the last block requests nothing -- a clamped re-read
+        float4 wr_n = wr, wi_n = wi;                        //  of it was a third of this wavefront's fragment loads)
+        if (more) { wr_n = ldw(0, kb + g.NKP); wi_n = ldw(1, kb + g.NKP); }
         const float4 br = *reinterpret_cast<const float4*>(bre + 16 * kb);
         const float4 bi = *reinterpret_cast<const float4*>(bim + 16 * kb);
         // re += Wre*Sre - Wim*Sim ; im += Wim*Sre + Wre*Sim
@@ -204,8 +205,8 @@ __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const l
         auto lds1 = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s1 + 64 * kb + 8 * plane); };
         u32x4 wr = ldw1(0, kp), wi = ldw1(1, kp);
         for (int kb = kp; kb < g.KST; kb += g.NKP) {
-            const int kn = min(kb + g.NKP, g.KST - 1);
-            const u32x4 n_wr = ldw1(0, kn), n_wi = ldw1(1, kn);
+            u32x4 n_wr = wr, n_wi = wi;
+            if (kb + g.NKP < g.KST) { n_wr = ldw1(0, kb + g.NKP); n_wi = ldw1(1, kb + g.NKP); }
             const u32x4 sr = lds1(0, kb);
             u32x4 si = lds1(1, kb);
             acc_re = mfma32h(wr, sr, acc_re); acc_im = mfma32h(wi, sr, acc_im);
@@ -221,8 +222,10 @@ __device__ __forceinline__ void mma_slab_split(rsrc_t wimg, int f_bytes, const l
     auto lds = [&](int plane, int kb) { return *reinterpret_cast<lds_u32x4*>(s0 + 128 * kb + 8 * plane); };
     u32x4 wrh = ldw(0, kp), wrl = ldw(1, kp), wih = ldw(2, kp), wil = ldw(3, kp);
     for (int kb = kp; kb < g.KST; kb += g.NKP) {
-        const int kn = min(kb + g.NKP, g.KST - 1);          // next block (clamped re-read at the end)
-        const u32x4 n_wrh = ldw(0, kn), n_wrl = ldw(1, kn), n_wih = ldw(2, kn), n_wil = ldw(3, kn);
+        // the next block's fragments (wave-uniform branch: the last block requests nothing -- clamped re-reads of it were 60 of the 168
+        // fragment loads of a slab, and a load costs the CU's memory path by the instruction)
+        u32x4 n_wrh = wrh, n_wrl = wrl, n_wih = wih, n_wil = wil;
+        if (kb + g.NKP < g.KST) { n_wrh = ldw(0, kb + g.NKP); n_wrl = ldw(1, kb + g.NKP); n_wih = ldw(2, kb + g.NKP); n_wil = ldw(3, kb + g.NKP); }
         // re += Wre*Sre - Wim*Sim ; im += Wim*Sre + Wre*Sim, each product = lo*hi + hi*lo + hi*hi.
         // The real-part fragments of the slab are consumed before the imaginary ones are read, and those
         // are negated in place, to keep the live register set small next to the gather accumulators.
