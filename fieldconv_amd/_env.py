@@ -11,6 +11,7 @@ SWITCHES = {
     # ---- read by libfieldconv_hip.so (once per process)
     'FC_MFMA': 'f32: fp32-MFMA contractions throughout; f16: single halves (reduced precision); default: split halves',
     'FC_RING': '0: frequency-major forward kernels for every mesh size; 2: ring-major ones for every size',
+    'FC_GROUP_SPLIT': '0: the backward data kernel never runs the two frequency groups of a tile as separate work items; 2 (development): wherever legal',
     'FC_RING_COMPACT': '0: no compact LDS plans (aliased partials, half-size record chunks) for the ring-major forward kernel',
     'FC_RING_HALVES': '0: no half tiles in the last round of the ring-major forward kernel',
     'FC_HALF_TILES': '0: no half tiles in the frequency-major kernels; 2: half tiles in the backward kernels too',

@@ -641,8 +641,8 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
     const BwdPlan p = plan_backward(d, split_mode());
     const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
     static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
-    snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d; %s; %s", records ? "records" : "dense rows", mode, p.ntiles,
-             1 << p.parts_log2,
+    snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d%s; %s; %s", records ? "records" : "dense rows", mode, p.ntiles,
+             1 << p.parts_log2, p.gsplit ? " (the two frequency groups of a tile as separate work items)" : "",
              p.fhalf ? (staged ? "fc_backward_filter_half_kernel (LDS-staged slabs)" : "fc_backward_filter_half2_kernel (register-fed rows)")
                      : "fc_backward_filter_kernel (fp32 MFMA)",
              "fc_backward_finish_params (fused sum + parameter chain)");

@@ -46,6 +46,10 @@ struct BwdArgs {
     int parts_log2;      // 2^parts_log2 workgroups share a vertex tile, each with that share of every source's edges (see
                          // FwdArgs); virtual tile vt covers the vertices of tile vt >> parts_log2
     uint32_t part_stride;   // complex numbers between the parts' partial gx arrays
+    int gsplit;          // 1: the two frequency GROUPS of a tile (shapes with F*R > 32: band limit 3) are separate work items -- item
+                         // vt < ntiles runs group 0 of tile vt, item ntiles + t group 1 of tile t -- each with its own walk and its own
+                         // partial gx (sum_parts adds the two): a mesh of 1.2 x the CUs' tiles takes 3 rounds of half items instead of 2
+                         // of whole ones.  Only without an edge split and without half tiles (plan_backward)
     int ngw;             // KST * NMT 16x16 gW tiles per frequency
     int KD;              // row stride (floats) of the H slabs kept for the filter kernel, one row of interleaved
                          // (re, im) pairs per vertex: 2*KP + 8, so that the filter kernel's 8-byte A-fragment reads
@@ -123,13 +127,15 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     // slots of my source in virtual tile vt: part p of 2^pl takes [n p / parts, n (p+1) / parts) of the source's n slots,
     // with the ring-run offsets clipped to that range (see fc_forward_kernels.hpp)
     const int pl = a.parts_log2;
+    const int nitems = a.gsplit ? 2 * a.ntiles : a.ntiles;
+    auto tile_of = [&](const int vt) { return (a.gsplit && vt >= a.ntiles) ? vt - a.ntiles : vt; };
     auto slot_range = [&](const int vt, int& b, int& e, int (&run)[R]) {
         b = 0;
         e = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) run[q] = 0;
-        const int j = item_vertex(vt, wave, a.nv_full, pl, a.N);
-        if (vt < a.ntiles && j < a.N) {
+        const int j = item_vertex(tile_of(vt), wave, a.nv_full, pl, a.N);
+        if (vt < nitems && j < a.N) {
             const int rb = growptr[j];
             const int n = growptr[j + 1] - rb;
             const int part = vt & ((1 << pl) - 1);
@@ -154,10 +160,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     Stamper stamp{(a.stamps && a.stamp_who == 1 && blockIdx.x == 0) ? a.stamps + wave * 256 : nullptr, 0};       // development: in-kernel timeline
     stamp.realtime(29);
     stamp(28);
-    for (int tile = first_tile_of_block(); tile < a.ntiles; tile += gridDim.x) {
+    for (int vt = first_tile_of_block(); vt < nitems; vt += gridDim.x) {
         stamp(10);
-        int nbeg = 0, nend = 0, nro[R];      // my source in the next tile
-        slot_range(tile + gridDim.x, nbeg, nend, nro);
+        const int tile = tile_of(vt);
+        const int gsel = (a.gsplit && vt >= a.ntiles) ? 1 : 0;      // gsplit: the one frequency group this item runs
+        int nbeg = 0, nend = 0, nro[R];      // my source in the next item
+        slot_range(vt + gridDim.x, nbeg, nend, nro);
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
         // my (vertex, channel) entry of x for the gx epilogue: issued now, consumed after the first slab
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            if (NG > 1 && a.gsplit && g != gsel) continue;
             constexpr int MGc = MG;
             const int f0 = g * MGc;
             f32x2 h[R][MG];
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 
             // ---------------------------------------------------------------- gather H for my source
             if constexpr (FACTORED) {
-                if (g > 0) for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);   // walk the slots again
+                if (g > 0 && !a.gsplit) for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);   // walk the slots again
                 auto rec_ptr = [&](const int s) {
                 // when the records fill their 1 KiB chunks exactly the ring is one contiguous array of NR*CR records
                 if constexpr (CR * RECF == 256) return ring + ((s * RECF) & (NR * 256 - 1));
@@ -253,8 +262,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                         }
                     });
                 }
-                if (g + 1 == NG) {
-                    // my source is done: stream the first record chunks of my next tile's source
+                if (g + 1 == NG || a.gsplit) {
+                    // my source is done: stream the first record chunks of my next item's source
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
                     for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             const float q = eq * einv2;                   // (i x / |x|^2) sum_f m Im(conj(gxt_f) xt_f)
             gxacc.x += -exs.y * q;
             gxacc.y += exs.x * q;
-            ggx[(size_t)(tile & ((1 << pl) - 1)) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
+            ggx[(size_t)(a.gsplit ? gsel : (tile & ((1 << pl) - 1))) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
         }
         beg = nbeg;
         end = nend;
@@ -463,6 +472,7 @@ struct BwdPlan {
     int IP, KP, KD, ntiles, nv_full, parts_log2, ngw, P, F, slab_floats, slab_stride, fhalf;
     size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes, gxp_bytes, gx_part_stride;
     bool ok, ok_factored;
+    int gsplit;      // BwdArgs::gsplit
 };
 
 inline BwdPlan plan_backward(const fc_dims* d, int halves) {
@@ -484,7 +494,20 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
         p.nv_full = items.nv_full;
     }
     p.gx_part_stride = part_stride((size_t)d->N * d->I);
-    p.gxp_bytes = p.parts_log2 ? (p.gx_part_stride << p.parts_log2) * sizeof(float2) : 0;
+    {   // frequency groups as work items: when half items fill the CUs' rounds better than whole tiles (a FAUST-sized mesh at band
+        // limit 3: 313 tiles on 256 CUs are two rounds, 626 half items three half rounds).  FC_GROUP_SPLIT=0 switches it off.
+        // (r1 = 1 never qualifies: a mesh of up to one round's tiles has its edges split instead, or is one round either way)
+        static const int sw = [] { const char* e = getenv("FC_GROUP_SPLIT"); return e ? atoi(e) : 1; }();      // (2, development: wherever legal)
+        const int ngroups = (p.F * d->R + 31) / 32;
+        const int cus = num_cus();
+        const int r1 = (p.ntiles + cus - 1) / cus, r2 = (2 * p.ntiles + cus - 1) / cus;
+        const bool legal = ngroups == 2 && p.parts_log2 == 0 && p.nv_full == p.ntiles;
+        // measured at 64 channels, band limit 3 (tools/time_kernels.py, 263 ... 875 tiles): the split wins whenever the half items save
+        // half a round (-15 % at two rounds, -8 % at three, -5 % at four) and loses 2-6 % when they do not
+        p.gsplit = (legal && (sw == 2 || (sw == 1 && r2 < 2 * r1 && r1 <= 6))) ? 1 : 0;
+    }
+    const int gx_parts = p.gsplit ? 2 : (1 << p.parts_log2);
+    p.gxp_bytes = gx_parts > 1 ? p.gx_part_stride * gx_parts * sizeof(float2) : 0;
     p.ngw = p.g.KST * p.g.NMT;
     int P = num_cus() / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
     if (P < 1) P = 1;
@@ -521,6 +544,7 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.nv_full = p.nv_full;
     a.parts_log2 = p.parts_log2;
     a.part_stride = (uint32_t)p.gx_part_stride;
+    a.gsplit = p.gsplit;
     a.ngw = p.ngw;
     a.KD = p.KD;
     a.slab_floats = p.slab_floats;
@@ -544,7 +568,8 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
     const size_t lds = FACTORED ? p.lds_data_factored : p.lds_data;
     static bool lds_ok[kMaxDevices] = {};        // per kernel instantiation (this function is a template)
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
-    const int grid = FACTORED ? (p.ntiles < num_cus() ? p.ntiles : num_cus()) : p.ntiles;
+    const int nitems = p.ntiles << p.gsplit;
+    const int grid = FACTORED ? (nitems < num_cus() ? nitems : num_cus()) : nitems;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, gy, sten, g->rowptr, FACTORED ? g->runs : g->nbr, wpk, gx,
                        hdump, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
@@ -560,7 +585,8 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
     float* hdump = reinterpret_cast<float*>(ws);
     // with an edge split the parts write partial gx arrays behind the slabs and the filter partials
     float* gxp = reinterpret_cast<float*>(static_cast<char*>(ws) + p.hdump_bytes + p.gwp_bytes);
-    float2* gx2 = reinterpret_cast<float2*>(p.parts_log2 ? gxp : gx);
+    const int gx_parts = p.gsplit ? 2 : (1 << p.parts_log2);
+    float2* gx2 = reinterpret_cast<float2*>(gx_parts > 1 ? gxp : gx);
     int rc = FC_ERR_UNSUPPORTED;
 #define FC_CASE(RR, BB)                                                                                                \
     if (d->R == RR && d->B == BB)                                                                                      \
@@ -572,8 +598,8 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
                                                             hdump, a, p, stream);
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
-    if (rc != FC_OK || p.parts_log2 == 0) return rc;
-    return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, 1 << p.parts_log2, stream);
+    if (rc != FC_OK || gx_parts == 1) return rc;
+    return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, gx_parts, stream);
 }
 
 

@@ -68,7 +68,8 @@ def run_conv(graph, x, W, gy, dev):
     (4400, 6, 40, 40, 2, 6),       # k = 6*40 = 240 padded to 256: stale bytes in the padding would poison later tiles
     (4400, 6, 48, 48, 2, 5),       # k = 5*48 = 240 padded to 256
     (4400, 6, 8, 16, 1, 3),        # narrow layer: k = 24 padded to 32
-    (5000, 7, 64, 64, 3, 6),       # FAUST shape (C=64, B=3): two frequency groups
+    (5000, 7, 64, 64, 3, 6),       # FAUST shape (C=64, B=3): two frequency groups, run as separate work items in the backward data kernel (313 tiles)
+    (9000, 6, 16, 24, 2, 8),       # eight rings at band limit 2: groups of 3 + 2 frequencies, 563 tiles (separate work items again)
     (4200, 9, 24, 56, 1, 8),       # eight rings
     (8990, 7, 12, 16, 2, 6),       # 562 tiles: more than two workgroups per CU can hold at once (FC_RING=1: half tiles in the last round)
 ], ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d' % s)

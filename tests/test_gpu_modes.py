@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ('test_fused_precomp_graph or test_fieldconv_golden or test_segmentation_net_golden or test_small_cotangent or test_fc_resnet_block_golden or N1000_k20 or N777_k12 or N500_k16 or '
-          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or N5000_k7 or '
+          'test_factored_stencil_path_vs_oracle_and_dense or N6000_k8 or N4400_k6_I40 or N8990 or N5000_k7 or N9000_k6 or '
           'test_config2_record_kernels')
 
 MODES = {
@@ -31,6 +31,7 @@ MODES = {
     'frequency_major_forward': {'FC_RING': '0'},         # the 16-wavefront forward kernels instead of the ring-major ones
     'ring_without_half_tiles': {'FC_RING_HALVES': '0'},
     'ring_without_compact_lds_plans': {'FC_RING_COMPACT': '0'},   # 64 channels at band limit 3 back on the frequency-major forward kernel
+    'frequency_groups_inside_one_work_item': {'FC_GROUP_SPLIT': '0'},   # the backward data kernel walks both groups of a tile itself
     'ring_major_any_size': {'FC_RING': '2'},             # ring-major forward kernels also on meshes of up to 4096 vertices
     'separate_finish_kernels': {'FC_SPLIT_FINISH': '1'},   # fc_backward_finish + fc_filter_param_grads instead of the fused launch
     'no_half_tiles': {'FC_HALF_TILES': '0'},

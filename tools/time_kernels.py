@@ -13,7 +13,7 @@ from fieldconv_amd.graph import SupportGraph
 from fieldconv_amd.transforms import FCPrecomp
 
 kind = sys.argv[1] if len(sys.argv) > 1 else 'geo'
-N, k, C, B, R = 20000, 32, int(os.environ.get('C', 48)), 2, 6
+N, k, C, B, R = int(os.environ.get('N', 20000)), int(os.environ.get('K', 32)), int(os.environ.get('C', 48)), int(os.environ.get('B', 2)), int(os.environ.get('R', 6))
 dev = torch.device('cuda:0')
 data = (sphere_support(N, k) if kind == 'geo' else random_support(N, k)).to(dev)
 edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
