@@ -49,7 +49,9 @@ struct BwdArgs {
     int gsplit;          // 1: the two frequency GROUPS of a tile (shapes with F*R > 32: band limit 3) are separate work items -- item
                          // vt < ntiles runs group 0 of tile vt, item ntiles + t group 1 of tile t -- each with its own walk and its own
                          // partial gx (sum_parts adds the two): a mesh of 1.2 x the CUs' tiles takes 3 rounds of half items instead of 2
-                         // of whole ones.  Only without an edge split and without half tiles (plan_backward)
+                         // of whole ones; on a mesh small enough for an edge split the groups replace its last doubling (half the partial
+                         // H slabs, no contraction done twice).  The partial gx of (group g, edge part p) is array (g << parts_log2) + p.
+                         // Not with half tiles (plan_backward)
     int ngw;             // KST * NMT 16x16 gW tiles per frequency
     int KD;              // row stride (floats) of the H slabs kept for the filter kernel, one row of interleaved
                          // (re, im) pairs per vertex: 2*KP + 8, so that the filter kernel's 8-byte A-fragment reads
@@ -71,22 +73,26 @@ struct BwdArgs {
                          // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump
 };
 
-template <int R, int B>
+// Frequency groups of the gather: NG walks of the edges with MG frequencies (R * MG complex accumulators per lane) each.  NGX forces a
+// group count -- the (6, 2) layer has 30 accumulators and one group; its two-group variant exists for BwdArgs::gsplit (bwd_forced_groups)
+template <int R, int B, int NGX = 0>
 struct BwdShape {
     static constexpr int F = 2 * B + 1;
-    static constexpr int NG = (F * R + 31) / 32;
+    static constexpr int NG = NGX ? NGX : (F * R + 31) / 32;
     static constexpr int MG = (F + NG - 1) / NG;
 };
+// shapes with ONE native group whose two-group kernel is instantiated (the reference's default layer)
+__host__ __device__ constexpr bool bwd_forced_groups(int R, int B) { return R == 6 && B == 2; }
 
 // ------------------------------------------------------------------------------------ data gradient
-template <int R, int B, bool FACTORED, bool SPLIT>
+template <int R, int B, bool FACTORED, bool SPLIT, int NGX = 0>
 __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     const float2* __restrict__ gx_, const float2* __restrict__ ggy, const float* __restrict__ gsten,
     const int32_t* __restrict__ growptr, const int32_t* __restrict__ gnbr, const float* __restrict__ gwpk,
     float2* __restrict__ ggx, float* __restrict__ hdump, const BwdArgs a) {
     constexpr int F = 2 * B + 1;
-    constexpr int NG = BwdShape<R, B>::NG;
-    constexpr int MG = BwdShape<R, B>::MG;
+    constexpr int NG = BwdShape<R, B, NGX>::NG;
+    constexpr int MG = BwdShape<R, B, NGX>::MG;
     constexpr int ROWF = 2 * R * F;
     constexpr int RECF = factored_record_floats(B);
     constexpr int LOG_CR = factored_log_chunk_records(B);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             const float q = eq * einv2;                   // (i x / |x|^2) sum_f m Im(conj(gxt_f) xt_f)
             gxacc.x += -exs.y * q;
             gxacc.y += exs.x * q;
-            ggx[(size_t)(a.gsplit ? gsel : (tile & ((1 << pl) - 1))) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
+            ggx[(size_t)((gsel << pl) + (tile & ((1 << pl) - 1))) * a.part_stride + (size_t)ejn * I + ei] = gxacc;
         }
         beg = nbeg;
         end = nend;
@@ -473,6 +479,7 @@ struct BwdPlan {
     size_t lds_data, lds_data_factored, lds_filter, hdump_bytes, gwp_bytes, gxp_bytes, gx_part_stride;
     bool ok, ok_factored;
     int gsplit;      // BwdArgs::gsplit
+    int ngx;         // 2: the forced two-group instantiation (bwd_forced_groups) runs
 };
 
 inline BwdPlan plan_backward(const fc_dims* d, int halves) {
@@ -483,6 +490,15 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.IP = p.g.MP;
     p.KP = p.g.KP;
     p.parts_log2 = edge_parts_log2(d);
+    // frequency groups as work items (BwdArgs::gsplit).  FC_GROUP_SPLIT=0 switches them off (2, development: wherever legal).
+    static const int gsw = [] { const char* e = getenv("FC_GROUP_SPLIT"); return e ? atoi(e) : 1; }();
+    const int native_groups = (p.F * d->R + 31) / 32;
+    const bool groups = native_groups == 2 || (native_groups == 1 && bwd_forced_groups(d->R, d->B) && halves != 0);
+    p.gsplit = 0;
+    if (groups && gsw && p.parts_log2 > 0) {      // small mesh: the groups instead of the edge split's last doubling
+        p.gsplit = 1;
+        --p.parts_log2;
+    }
     {
         const int nt = (d->N + kTile - 1) / kTile;
         // Half tiles in the last round (tile_items) pay in the forward kernel only: at 4 999 vertices, C = 64, B = 3 the data
@@ -494,19 +510,17 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
         p.nv_full = items.nv_full;
     }
     p.gx_part_stride = part_stride((size_t)d->N * d->I);
-    {   // frequency groups as work items: when half items fill the CUs' rounds better than whole tiles (a FAUST-sized mesh at band
-        // limit 3: 313 tiles on 256 CUs are two rounds, 626 half items three half rounds).  FC_GROUP_SPLIT=0 switches it off.
-        // (r1 = 1 never qualifies: a mesh of up to one round's tiles has its edges split instead, or is one round either way)
-        static const int sw = [] { const char* e = getenv("FC_GROUP_SPLIT"); return e ? atoi(e) : 1; }();      // (2, development: wherever legal)
-        const int ngroups = (p.F * d->R + 31) / 32;
+    if (groups && gsw && !p.gsplit && p.parts_log2 == 0 && p.nv_full == p.ntiles) {
+        // larger meshes: when half items fill the CUs' rounds better than whole tiles (a FAUST-sized mesh at band limit 3: 313 tiles on
+        // 256 CUs are two rounds, 626 half items three half rounds).  Measured at 64 channels, band limit 3 (tools/time_kernels.py,
+        // 263 ... 875 tiles): the split wins whenever the half items save half a round (-15 % at two rounds, -8 % at three, -5 % at four)
+        // and loses 2-6 % when they do not
         const int cus = num_cus();
         const int r1 = (p.ntiles + cus - 1) / cus, r2 = (2 * p.ntiles + cus - 1) / cus;
-        const bool legal = ngroups == 2 && p.parts_log2 == 0 && p.nv_full == p.ntiles;
-        // measured at 64 channels, band limit 3 (tools/time_kernels.py, 263 ... 875 tiles): the split wins whenever the half items save
-        // half a round (-15 % at two rounds, -8 % at three, -5 % at four) and loses 2-6 % when they do not
-        p.gsplit = (legal && (sw == 2 || (sw == 1 && r2 < 2 * r1 && r1 <= 6))) ? 1 : 0;
+        p.gsplit = (gsw == 2 || (r2 < 2 * r1 && r1 <= 6)) ? 1 : 0;
     }
-    const int gx_parts = p.gsplit ? 2 : (1 << p.parts_log2);
+    p.ngx = (p.gsplit && native_groups == 1) ? 2 : 0;
+    const int gx_parts = (1 << p.parts_log2) << p.gsplit;
     p.gxp_bytes = gx_parts > 1 ? p.gx_part_stride * gx_parts * sizeof(float2) : 0;
     p.ngw = p.g.KST * p.g.NMT;
     int P = num_cus() / p.F;                   // filter kernel: one workgroup per CU across the F frequency slices
@@ -561,10 +575,10 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     return a;
 }
 
-template <int R, int B, bool FACTORED, bool SPLIT>
+template <int R, int B, bool FACTORED, bool SPLIT, int NGX = 0>
 static int launch_backward_data(const float2* x, const float2* gy, const float* sten, const fc_csr* g, const float* wpk,
                                 float2* gx, float* hdump, const BwdArgs& a, const BwdPlan& p, hipStream_t stream) {
-    auto kern = fc_backward_data_kernel<R, B, FACTORED, SPLIT>;
+    auto kern = fc_backward_data_kernel<R, B, FACTORED, SPLIT, NGX>;
     const size_t lds = FACTORED ? p.lds_data_factored : p.lds_data;
     static bool lds_ok[kMaxDevices] = {};        // per kernel instantiation (this function is a template)
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
@@ -585,9 +599,19 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
     float* hdump = reinterpret_cast<float*>(ws);
     // with an edge split the parts write partial gx arrays behind the slabs and the filter partials
     float* gxp = reinterpret_cast<float*>(static_cast<char*>(ws) + p.hdump_bytes + p.gwp_bytes);
-    const int gx_parts = p.gsplit ? 2 : (1 << p.parts_log2);
+    const int gx_parts = (1 << p.parts_log2) << p.gsplit;
     float2* gx2 = reinterpret_cast<float2*>(gx_parts > 1 ? gxp : gx);
     int rc = FC_ERR_UNSUPPORTED;
+    if constexpr (SPLIT) {
+        if (p.ngx == 2 && d->R == 6 && d->B == 2) {      // (bwd_forced_groups)
+            rc = factored ? launch_backward_data<6, 2, true, SPLIT, 2>(reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), sten,
+                                                                       g, wpk, gx2, hdump, a, p, stream)
+                          : launch_backward_data<6, 2, false, SPLIT, 2>(reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), sten,
+                                                                        g, wpk, gx2, hdump, a, p, stream);
+            if (rc != FC_OK) return rc;
+            return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, gx_parts, stream);
+        }
+    }
 #define FC_CASE(RR, BB)                                                                                                \
     if (d->R == RR && d->B == BB)                                                                                      \
         rc = factored ? launch_backward_data<RR, BB, true, SPLIT>(reinterpret_cast<const float2*>(x),                  \

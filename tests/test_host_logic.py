@@ -351,6 +351,16 @@ def test_kernel_description_and_gpu_count_need_no_gpu():
     small = _lib.FcDims(1024, 131072, 48, 48, 6, 2)
     assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and b'frequency-major' in buf.value
     assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(100, 10, 48, 48, 9, 2)), 1, buf, len(buf)) == -2
+    if os.environ.get('FC_MFMA') in (None, '') and os.environ.get('FC_GROUP_SPLIT') in (None, ''):
+        # the backward data kernel runs a tile's two frequency groups as separate work items where that fills the CUs' rounds better:
+        # a FAUST-sized mesh at band limit 3 (313 tiles), the reference's 1 024-vertex mesh (instead of the edge split's last doubling:
+        # 2 parts, not 4) -- and not config 2 (1 250 tiles: five rounds either way)
+        groups = b'frequency groups of a tile as separate work items'
+        assert lib.fc_describe_kernels(ctypes.byref(d), 2, buf, len(buf)) == 0 and groups not in buf.value
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(4999, 132257, 64, 64, 6, 3)), 2, buf, len(buf)) == 0 and groups in buf.value
+        assert b'tiles=313 parts=1' in buf.value, buf.value
+        assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and groups in buf.value and b'parts=2' in buf.value, buf.value
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(7500, 200000, 64, 64, 6, 3)), 2, buf, len(buf)) == 0 and groups not in buf.value
     import importlib.util
     spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
