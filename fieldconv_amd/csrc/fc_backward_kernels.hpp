@@ -140,11 +140,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
         e = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) run[q] = 0;
-        const int j = item_vertex(tile_of(vt), wave, a.nv_full, pl, a.N);
+        const int tp = tile_of(vt);                       // (tile << pl) + edge part
+        const int j = item_vertex(tp, wave, a.nv_full, pl, a.N);
         if (vt < nitems && j < a.N) {
             const int rb = growptr[j];
             const int n = growptr[j + 1] - rb;
-            const int part = vt & ((1 << pl) - 1);
+            const int part = tp & ((1 << pl) - 1);
             const int s0 = (n * part) >> pl, s1 = (n * (part + 1)) >> pl;
             b = rb + s0;
             e = rb + s1;
