@@ -357,29 +357,45 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             // consecutive bytes, one store -- three per frequency instead of six (a store costs the CU's memory
                             // path by the instruction, not by the byte: data kernel 165 -> 161 us); the last ring of an odd count alone
                             f32x2* const dst2 = reinterpret_cast<f32x2*>(dst) + wave * (a.KD / 2);
-                            int d0 = 2 * lane;
-                            f32x2 even = f32x2{0.f, 0.f};
+                            // (the launch's constants as compile-time flags for the two default combinations: the selects and
+                            //  branches they remove sit between the loop's 4-instruction conversions)
+                            auto rows = [&](auto known, auto halves_c, auto nt_c) {
+                                constexpr bool kKnown = decltype(known)::value;
+                                const bool keep_halves = kKnown ? decltype(halves_c)::value : (a.dump_halves != 0);
+                                const bool nt = kKnown ? decltype(nt_c)::value : (a.nt_dump != 0);
+                                const int halves = kKnown ? 2 : mg.split;
+                                int oo = o0, d0 = 2 * lane;
+                                f32x2 even = f32x2{0.f, 0.f};
 #pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                f16x2 hi, lo;
-                                split_halves2(h[r][ff], scale, hi, lo);
-                                f32x2 kept = h[r][ff];
-                                if (a.dump_halves) kept = f32x2{__builtin_bit_cast(float, hi), __builtin_bit_cast(float, lo)};
-                                if (lane < O && !(a.dbg & 8)) {
-                                    if (r & 1) {
-                                        const f32x4 two = f32x4{even.x, even.y, kept.x, kept.y};
-                                        if (a.nt_dump) __builtin_nontemporal_store(two, reinterpret_cast<f32x4*>(dst2 + d0));
-                                        else *reinterpret_cast<f32x4*>(dst2 + d0) = two;
-                                    } else if (r == R - 1) {
-                                        if (a.nt_dump) __builtin_nontemporal_store(kept, dst2 + (R - 1) * O + lane);
-                                        else dst2[(R - 1) * O + lane] = kept;
+                                for (int r = 0; r < R; ++r) {
+                                    f16x2 hi, lo;
+                                    split_halves2(h[r][ff], scale, hi, lo);
+                                    f32x2 kept = h[r][ff];
+                                    if (keep_halves) kept = f32x2{__builtin_bit_cast(float, hi), __builtin_bit_cast(float, lo)};
+                                    if (lane < O && (kKnown || !(a.dbg & 8))) {
+                                        if (r & 1) {
+                                            const f32x4 two = f32x4{even.x, even.y, kept.x, kept.y};
+                                            if (nt) __builtin_nontemporal_store(two, reinterpret_cast<f32x4*>(dst2 + d0));
+                                            else *reinterpret_cast<f32x4*>(dst2 + d0) = two;
+                                        } else if (r == R - 1) {
+                                            if (nt) __builtin_nontemporal_store(kept, dst2 + (R - 1) * O + lane);
+                                            else dst2[(R - 1) * O + lane] = kept;
+                                        }
                                     }
+                                    even = kept;
+                                    split_pair_store(row, oo, hi, lo, lane, halves);
+                                    oo += halves * mg.KI;
+                                    if (r & 1) d0 += 2 * O;
+                                    asm volatile("" : "+v"(oo), "+v"(d0));
                                 }
-                                even = kept;
-                                split_pair_store(row, o0, hi, lo, lane, mg.split);
-                                o0 += mg.split * mg.KI;
-                                if (r & 1) d0 += 2 * O;
-                                asm volatile("" : "+v"(o0), "+v"(d0));
+                            };
+                            using yes = std::true_type;
+                            using no = std::false_type;
+                            if (a.dump_halves && mg.split == 2 && !(a.dbg & 8)) {
+                                if (a.nt_dump) rows(yes{}, yes{}, yes{});
+                                else rows(yes{}, yes{}, no{});
+                            } else {
+                                rows(no{}, no{}, no{});
                             }
                         }
                         if (a.tails && lane == 0) {

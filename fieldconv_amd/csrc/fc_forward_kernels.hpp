@@ -153,15 +153,21 @@ __device__ __forceinline__ void forward_phase_b(const f32x2 (&c)[R][MG], int f0,
                 // advanced by a ring per step -- the empty asm keeps hipcc from materialising all R addresses for
                 // the whole kernel.  Lanes in [I, KI) hold copies of channel 0 and land in padding the filter zeroes.
                 lds_u32* const row = (lds_u32*)sp + wave * (g.KS / 2);
-                int o0 = split_pair_offset(lane, g.split);
+                // (the default mode's two halves as a compile-time constant: no branch between the conversions)
+                auto rows = [&](auto two) {
+                    const int halves = decltype(two)::value ? 2 : g.split;
+                    int o0 = split_pair_offset(lane, halves);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    f16x2 hi, lo;
-                    split_halves2(c[r][ff], scale, hi, lo);
-                    split_pair_store(row, o0, hi, lo, lane, g.split);
-                    o0 += g.split * g.KI;
-                    asm volatile("" : "+v"(o0));
-                }
+                    for (int r = 0; r < R; ++r) {
+                        f16x2 hi, lo;
+                        split_halves2(c[r][ff], scale, hi, lo);
+                        split_pair_store(row, o0, hi, lo, lane, halves);
+                        o0 += halves * g.KI;
+                        asm volatile("" : "+v"(o0));
+                    }
+                };
+                if (g.split == 2) rows(std::true_type{});
+                else rows(std::false_type{});
             }
             __syncthreads();
             if (mma_active && !(a.dbg & 2))
