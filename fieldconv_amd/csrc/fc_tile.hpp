@@ -268,8 +268,25 @@ __device__ __forceinline__ void store_partial(float* part, const MmaGeom& g, int
     }
 }
 
-// Fixed-order sum over the k partitions of entry (vertex v, row m).
+// Fixed-order sum over the k partitions of entry (vertex v, row m).  The partition counts of the 48- and 64-channel layers (5 and 4) are
+// unrolled -- all reads in flight, the same order of additions -- behind a wave-uniform dispatch.
+template <int NKP>
+__device__ __forceinline__ float2 sum_partials_n(const float* part, const MmaGeom& g, int v, int m) {
+    float2 p[NKP];
+#pragma unroll
+    for (int q = 0; q < NKP; ++q) p[q] = *reinterpret_cast<const float2*>(part + (size_t)(q * g.MP + m) * kPartStride + 2 * v);
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int q = 0; q < NKP; ++q) {
+        re += p[q].x;
+        im += p[q].y;
+    }
+    return make_float2(re, im);
+}
 __device__ __forceinline__ float2 sum_partials(const float* part, const MmaGeom& g, int v, int m) {
+    if (g.NKP == 5) return sum_partials_n<5>(part, g, v, m);
+    if (g.NKP == 4) return sum_partials_n<4>(part, g, v, m);
+    if (g.NKP == 2) return sum_partials_n<2>(part, g, v, m);       // (the ring-major forward kernel's 8-wavefront workgroups)
     float re = 0.f, im = 0.f;
     for (int q = 0; q < g.NKP; ++q) {
         const float2 p = *reinterpret_cast<const float2*>(part + (size_t)(q * g.MP + m) * kPartStride + 2 * v);
