@@ -47,6 +47,7 @@ TEST_SWITCHES = {
     'FC_DIST_TEST_DEVICE': 'cuda: the distributed test worker runs the HIP kernels (two gloo ranks on one GPU)',
     'FC_DIST_OVERLAP': '0: the distributed test worker without forward / backward overlap',
     'FC_DIST_PLAN_ONLY': '1: the distributed test worker checks partition and halo plan at config-4 size only',
+    'FC_DIST_CONFIG4': '1: the distributed GPU test worker runs config 4\'s per-rank size (20 000 owned vertices per rank)',
 }
 
 PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')

@@ -82,6 +82,52 @@ def plan_at_config4_size():
     dist.destroy_process_group()
 
 
+def check_at_config4_size(rank, world, lo, n_owned, plan, fe, fs, x_all, gy_all, W, y_owned, gx, gW, dev):
+    """The oracle cannot hold the whole 40 000-vertex layer (its (E, I, R, F) temporaries are tens of GB), so:
+    (1) ~100 sampled owned rows (half of them on the rim of the partition) of y and of gx against the oracle on the sub-edge-lists of the UNION mesh that determine them (rows of y
+        depend on their in-edges only, rows of gx on their out-edges -- some of which belong to the other rank: the halo path);
+    (2) every owned row of y and gx, and the all-reduced filter gradient, against the same HIP kernels run in ONE process on the union
+        mesh (itself oracle-checked at this size by tests/test_gpu_fullsize.py): partition, halo exchange and gradient exchange change
+        nothing beyond the order of additions."""
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import SupportGraph
+    g = torch.Generator().manual_seed(77 + rank)
+    # 50 random owned rows and 50 of the owned rows whose features the other rank convolves over (their input gradient arrives through the
+    # transposed exchange) -- which are also rows next to the cut, whose own outputs read halo rows
+    mine = (fe[:, 0] >= lo) & (fe[:, 0] < lo + n_owned)
+    remote_dst = (fe[:, 1] < lo) | (fe[:, 1] >= lo + n_owned)
+    rim = torch.unique(fe[mine & remote_dst, 0])
+    sub = torch.unique(torch.cat((lo + torch.randperm(n_owned, generator=g)[:50], rim[torch.randperm(rim.numel(), generator=g)[:50]])))
+    idx = sub.numpy()
+    Wn = W.detach().numpy()
+    m_in = torch.isin(fe[:, 1], sub)
+    y_ref = orc.fieldconv_forward(x_all.numpy(), fe[m_in].numpy(), fs[m_in].numpy(), Wn)[idx]
+    m_out = torch.isin(fe[:, 0], sub)
+    gx_ref = orc.fieldconv_backward(x_all.numpy(), fe[m_out].numpy(), fs[m_out].numpy(), Wn, gy_all.numpy())[0][idx]
+    frac_remote = float((fe[m_out, 1] < lo).logical_or(fe[m_out, 1] >= lo + n_owned).float().mean())
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    e_y = rel(y_owned.detach().numpy()[idx - lo], y_ref)
+    e_gx = rel(gx.numpy()[idx - lo], gx_ref)
+    # one process, the union mesh
+    graph = SupportGraph(fe.to(dev), fs.to(dev), x_all.shape[0])
+    xs = x_all.to(dev).requires_grad_(True)
+    Ws = W.detach().to(dev).requires_grad_(True)
+    ys = field_conv(xs, Ws, graph)
+    gxs, gWs = torch.autograd.grad(ys, [xs, Ws], grad_outputs=gy_all.to(dev))
+    c_y = rel(y_owned.detach().numpy(), ys.detach().cpu().numpy()[lo:lo + n_owned])
+    c_gx = rel(gx.numpy(), gxs.cpu().numpy()[lo:lo + n_owned])
+    c_gw = rel(gW.numpy(), gWs.cpu().numpy())
+    print(f'rank {rank}: config-4 size n_owned={n_owned} halo={plan.n_halo} edges(union)={fe.shape[0]} sampled rows: err y={e_y:.2e} gx={e_gx:.2e} '
+          f'({100 * frac_remote:.1f} % of the sampled out-edges end on the other rank); against one process on the union mesh: '
+          f'y={c_y:.2e} gx={c_gx:.2e} gW={c_gw:.2e}', flush=True)
+    assert plan.n_halo > 0.02 * n_owned
+    assert e_y < 1e-5 and e_gx < 1e-5
+    assert c_y < 1e-5 and c_gx < 1e-5 and c_gw < 1e-5
+    dist.destroy_process_group()
+
+
 def main():
     dist.init_process_group('gloo')
     if os.environ.get('FC_DIST_PLAN_ONLY') == '1':
@@ -89,13 +135,17 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = os.environ.get('FC_DIST_TEST_DEVICE', 'cpu') == 'cuda'
     dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
-    n_total, k, C, O, B, R = (3000, 12, 24, 16, 2, 6) if on_gpu else (400, 8, 5, 4, 1, 3)
-    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3, interior_first=True)
+    # FC_DIST_CONFIG4=1 (GPU): BASELINE configs[3]'s per-rank size and layer -- 20 000 owned vertices per rank, k = 32, support radius =
+    # 95-percentile, 48 channels, band limit 2, six rings -- checked on sampled rows and against the single-process kernels (below)
+    full = on_gpu and os.environ.get('FC_DIST_CONFIG4') == '1'
+    n_total, k, C, O, B, R = (20000 * world, 32, 48, 48, 2, 6) if full else (3000, 12, 24, 16, 2, 6) if on_gpu else (400, 8, 5, 4, 1, 3)
+    support = 'p95' if full else 'all'
+    data, n_owned, halo_global, bounds = sphere_partition(n_total, world, rank, k=k, seed=3, support=support, interior_first=True)
     n_interior = data.n_interior
     src, dst = data.supp_edges[:, 0], data.supp_edges[:, 1]
     assert 0 < n_interior < n_owned and bool((src[dst < n_interior] < n_owned).all())      # interior targets read owned rows only
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
-    assert edges.shape[0] == n_owned * k
+    assert edges.shape[0] == n_owned * k or full          # (the radius filter of the 95-percentile support drops ~5 % of the edges)
     plan = HaloPlan(n_owned, halo_global, bounds, device=dev)
     lo = int(bounds[rank])
     x_all = features(n_total, C, 1)
@@ -134,12 +184,14 @@ def main():
     # its own targets), mapped back to global vertex ids
     all_e, all_s = [], []
     for r in range(world):
-        dr, n_r, halo_r, _ = sphere_partition(n_total, world, r, k=k, seed=3, interior_first=True)
+        dr, n_r, halo_r, _ = sphere_partition(n_total, world, r, k=k, seed=3, support=support, interior_first=True)
         er, sr, _, _ = FCPrecomp(B, R, dr.epsilon)(dr)
         to_global = torch.cat((torch.arange(int(bounds[r]), int(bounds[r]) + n_r), halo_r))
         all_e.append(to_global[er])
         all_s.append(sr)
     fe, fs = torch.cat(all_e), torch.cat(all_s)
+    if full:
+        return check_at_config4_size(rank, world, lo, n_owned, plan, fe, fs, x_all, gy_all, W, y_owned, gx, torch.view_as_complex(gWr), dev)
     y_ref = orc.fieldconv_forward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy())
     gx_ref, gW_ref = orc.fieldconv_backward(x_all.numpy(), fe.numpy(), fs.numpy(), W.detach().numpy(), gy_all.numpy())
 

@@ -25,6 +25,18 @@ def test_partitioned_fieldconv_two_ranks_one_gpu(overlap):
     assert res.stdout.count('err y=') == 2, res.stdout[-3000:]
 
 
+def test_partitioned_fieldconv_two_ranks_at_config4_per_rank_size():
+    """BASELINE configs[3]'s per-rank problem -- 20 000 owned vertices per rank, k = 32, 95-percentile support, 48 channels, band limit 2
+    -- on two ranks (one GPU, gloo), overlapped exchanges: sampled rows against the oracle on the union mesh, every row and the all-reduced
+    filter gradient against the single-process kernels on the union mesh (tests/_dist_worker.py: check_at_config4_size)."""
+    env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda', FC_DIST_OVERLAP='1', FC_DIST_CONFIG4='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count('config-4 size n_owned=20000') == 2, res.stdout[-3000:]
+
+
 def test_data_parallel_meshes_two_ranks_one_gpu():
     """BASELINE config 5 in miniature: one mesh per rank through the FieldConv module, parameter gradients all-reduced."""
     env = dict(os.environ, OMP_NUM_THREADS='4', MASTER_ADDR='127.0.0.1', FC_DIST_TEST_DEVICE='cuda')
