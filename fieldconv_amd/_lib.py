@@ -24,7 +24,9 @@ class FcCsr(ctypes.Structure):
 class FcFilterParams(ctypes.Structure):
     """fc_filter_params: module parameters and (backward) where their gradients go"""
     _fields_ = [('zonal', ctypes.c_void_p), ('spherical', ctypes.c_void_p), ('phase', ctypes.c_void_p), ('ftype', ctypes.c_int32),
-                ('g_zonal', ctypes.c_void_p), ('g_spherical', ctypes.c_void_p), ('g_phase', ctypes.c_void_p)]
+                ('g_zonal', ctypes.c_void_p), ('g_spherical', ctypes.c_void_p), ('g_phase', ctypes.c_void_p),
+                # rider of the finishing launch: the modReLU's bias-gradient partials summed into g_bias (None / 0: nothing)
+                ('bias_partials', ctypes.c_void_p), ('bias_nparts', ctypes.c_int32), ('g_bias', ctypes.c_void_p)]
 
 
 class FcEpilogue(ctypes.Structure):
@@ -95,6 +97,8 @@ SIGNATURES = {
     'fc_tangent_nonlin_forward': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),
     'fc_tangent_nonlin_backward_workspace_bytes': (_sz, [_c_int32, _c_int32]),
     'fc_tangent_nonlin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
+    'fc_tangent_nonlin_backward_groups': (_c_int32, [_c_int32]),
+    'fc_tangent_nonlin_backward_partial': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
 }
 
 _LIB = None

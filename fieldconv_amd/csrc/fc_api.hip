@@ -43,7 +43,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 7; }
+int fc_abi_version(void) { return 8; }
 
 const char* fc_status_string(int s) {
     switch (s) {
@@ -201,11 +201,14 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
     if (params->ftype < 0 || params->ftype > 2 || !params->zonal || !params->spherical || !params->g_zonal || !params->g_spherical ||
         (params->ftype == 1 && (!params->phase || !params->g_phase)))
         return FC_ERR_BAD_ARGUMENT;
+    if (params->bias_partials && (params->bias_nparts <= 0 || !params->g_bias)) return FC_ERR_BAD_ARGUMENT;
     if (split_finish) {
-        const int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
+        int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
         if (rc != FC_OK) return rc;
-        return fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
-                                     params->g_spherical, params->g_phase, dims, stream);
+        rc = fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
+                                   params->g_spherical, params->g_phase, dims, stream);
+        if (rc != FC_OK || !params->bias_partials) return rc;
+        return fc::bias_partials_reduce_impl(params->bias_partials, params->bias_nparts, dims->O, params->g_bias, static_cast<hipStream_t>(stream));
     }
     return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream));
 }

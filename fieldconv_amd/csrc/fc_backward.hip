@@ -669,7 +669,7 @@ int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const 
     // partial (p, f, k = r*O + o, i) at ((p*F + f)*KP + k)*IP + i
     return reduce_param_grads_impl(gwp, (size_t)p.F * p.KP * p.IP, (size_t)d->O * p.IP, (size_t)p.KP * p.IP, (size_t)p.IP, p.gd.split != 0, p.P, gw_eff,
                                    fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream, o0,
-                                   i0, Ifull);
+                                   i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias);
 }
 
 #define FC_BWD_DATA_ARGS const float*, const float*, const float*, const fc_csr*, const float*, float*, void*, size_t, const fc_dims*, bool, hipStream_t

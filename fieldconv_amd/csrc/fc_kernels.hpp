@@ -61,9 +61,14 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
 // (o0, i0, Ifull: the filter is the block [o0, o0 + O) x [i0, i0 + I) of parameter tensors with Ifull input channels; whole
 // layer: 0, 0, 0)
 // (ring_pairs: the partials' k index is dump_k(r, o) * so instead of r * sr + o * so)
+// (bias_partials / bias_nparts / g_bias: fc_filter_params' rider -- extra workgroups of the same launch sum the modReLU's bias-gradient
+//  partials, bit-identically to tangent_nonlin_gb_reduce_kernel)
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
                             const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
-                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0);
+                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0,
+                            const float* bias_partials = nullptr, int bias_nparts = 0, float* g_bias = nullptr);
+// the rider as a launch of its own (fc_pointwise.hip): g_bias[c] = fixed-order sum over p of partials[p][c]
+int bias_partials_reduce_impl(const float* partials, int nparts, int C, float* g_bias, hipStream_t stream);
 
 // k index of entry (ring r, channel o) in a row of the kept H slabs, hence of the filter-gradient partials.  The split modes keep the
 // rings in PAIRS -- (2p, o) and (2p + 1, o) adjacent -- so that the data kernel stores two entries with one instruction; the last ring

@@ -320,11 +320,25 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     const float2* __restrict__ gwp, const RpStrides st, const int P, float2* __restrict__ gw_out, const float* __restrict__ zonal,
     const float* __restrict__ sph, const float* __restrict__ phase, const int ftype, float* __restrict__ g_zonal,
     float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B, const int po0,
-    const int pi0, const int Ifull) {
+    const int pi0, const int Ifull, const float* __restrict__ bias_partials, const int bias_nparts, float* __restrict__ g_bias,
+    const int bias_block0) {
     // (po0, pi0, Ifull: the filter is the block [po0, po0 + O) x [pi0, pi0 + I) of parameter tensors with Ifull input channels)
     __shared__ float2 part[kRpGroups][kRpPairs * 8 * 7];     // [group][(r*F + f)*16 + pair]
     __shared__ float2 gws[kRpPairs * 8 * 7];                 // [pair][r][f]
     __shared__ float gph[kRpPairs * 8 * (kMaxB + 1)];        // [pair][r][q]
+    if ((int)blockIdx.x >= bias_block0) {
+        // the rider (fc_filter_params::bias_partials): one wavefront per channel -- lanes take every 64th partial in order, then a fixed
+        // butterfly -- exactly tangent_nonlin_gb_reduce_kernel's arithmetic
+        const int lane = threadIdx.x & 63;
+        const int c = ((int)blockIdx.x - bias_block0) * (kRpThreads / 64) + (threadIdx.x >> 6);
+        if (c >= O) return;
+        float s = 0.f;
+        for (int p = lane; p < bias_nparts; p += 64) s += bias_partials[(size_t)p * O + c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) g_bias[c] = s;
+        return;
+    }
     const int F = 2 * B + 1;
     const int nit = (I + kRpPairs - 1) / kRpPairs;
     const int o = blockIdx.x / nit, i0 = (blockIdx.x - o * nit) * kRpPairs;
@@ -384,13 +398,16 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
 // gwp: the partials, P of them, entry (p, r, f, o, i) at gwp[p*sp + r*sr + f*sf + o*so + i]
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
                             const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
-                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull) {
+                            float* g_phase, const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull, const float* bias_partials,
+                            int bias_nparts, float* g_bias) {
     if (d->R > 8 || d->B > kMaxB || kRpPairs * d->R > kRpThreads) return FC_ERR_UNSUPPORTED;
     const int nit = (d->I + kRpPairs - 1) / kRpPairs;
     const RpStrides st{sp, sr, sf, so, ring_pairs ? 1 : 0};
-    hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(d->O * nit), dim3(kRpThreads), 0, stream, reinterpret_cast<const float2*>(gwp), st,
-                       P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph, g_phase, d->O, d->I, d->R, d->B, o0, i0,
-                       Ifull > 0 ? Ifull : d->I);
+    const int main_blocks = d->O * nit;
+    const int bias_blocks = (bias_partials && bias_nparts > 0 && g_bias) ? (d->O + kRpThreads / 64 - 1) / (kRpThreads / 64) : 0;
+    hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(main_blocks + bias_blocks), dim3(kRpThreads), 0, stream,
+                       reinterpret_cast<const float2*>(gwp), st, P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph,
+                       g_phase, d->O, d->I, d->R, d->B, o0, i0, Ifull > 0 ? Ifull : d->I, bias_partials, bias_nparts, g_bias, main_blocks);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -295,6 +295,13 @@ __global__ __launch_bounds__(64) void tangent_nonlin_gb_reduce_kernel(const floa
 
 }  // namespace fc
 
+namespace fc {
+int bias_partials_reduce_impl(const float* partials, int nparts, int C, float* g_bias, hipStream_t stream) {
+    hipLaunchKernelGGL(tangent_nonlin_gb_reduce_kernel, dim3(C), dim3(64), 0, stream, partials, g_bias, nparts, C);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+}  // namespace fc
+
 extern "C" {
 
 namespace {
@@ -360,20 +367,32 @@ size_t fc_tangent_nonlin_backward_workspace_bytes(int32_t N, int32_t C) {
     return (size_t)ngroups * C * sizeof(float);
 }
 
-int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
-                               void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream) {
-    if (!x || !bias || !gy || !gx || !gbias || N <= 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
+int32_t fc_tangent_nonlin_backward_groups(int32_t N) {
+    if (N <= 0) return 0;
+    const int rows = fc::nonlin_rows_per_group(N);
+    return (N + rows - 1) / rows;
+}
+
+int fc_tangent_nonlin_backward_partial(const float* x, const float* bias, const float* gy, float* gx, void* workspace,
+                                       size_t workspace_bytes, int32_t N, int32_t C, void* stream) {
+    if (!x || !bias || !gy || !gx || N <= 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < fc_tangent_nonlin_backward_workspace_bytes(N, C)) return FC_ERR_WORKSPACE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows = fc::nonlin_rows_per_group(N);
     const int ngroups = (N + rows - 1) / rows;
     const int L = C < fc::kNonlinThreads ? fc::kNonlinThreads / C : 1;
-    float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(fc::tangent_nonlin_bwd_kernel, dim3(ngroups), dim3(fc::kNonlinThreads), (size_t)L * C * sizeof(float), s,
-                       reinterpret_cast<const float2*>(x), bias, reinterpret_cast<const float2*>(gy),
-                       reinterpret_cast<float2*>(gx), part, N, C, rows);
-    hipLaunchKernelGGL(fc::tangent_nonlin_gb_reduce_kernel, dim3(C), dim3(64), 0, s, part, gbias, ngroups, C);
+    hipLaunchKernelGGL(fc::tangent_nonlin_bwd_kernel, dim3(ngroups), dim3(fc::kNonlinThreads), (size_t)L * C * sizeof(float),
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), bias, reinterpret_cast<const float2*>(gy),
+                       reinterpret_cast<float2*>(gx), reinterpret_cast<float*>(workspace), N, C, rows);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
+                               void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream) {
+    if (!gbias) return FC_ERR_BAD_ARGUMENT;
+    const int rc = fc_tangent_nonlin_backward_partial(x, bias, gy, gx, workspace, workspace_bytes, N, C, stream);
+    if (rc != FC_OK) return rc;
+    return fc::bias_partials_reduce_impl(reinterpret_cast<const float*>(workspace), fc_tangent_nonlin_backward_groups(N), C, gbias,
+                                         static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -163,7 +163,11 @@ int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s
             rc = fc::backward_filter_impl(xb + ib * bstride, cws, cws_bytes, &d, st);
             if (rc != FC_OK) return rc;
             if (params) {
-                rc = fc::backward_finish_params_impl(gwb, cws, cws_bytes, &d, params, st, ob * blk, ib * blk, I);
+                fc_filter_params block_params = *params;             // (the bias rider belongs to the whole layer: after the blocks)
+                block_params.bias_partials = nullptr;
+                block_params.bias_nparts = 0;
+                block_params.g_bias = nullptr;
+                rc = fc::backward_finish_params_impl(gwb, cws, cws_bytes, &d, &block_params, st, ob * blk, ib * blk, I);
             } else {            // explicit filter: the block's gradient goes into its block of gw_eff (rows o, bi*R*F numbers each)
                 rc = fc::backward_finish_impl(gwb, cws, cws_bytes, &d, st);
                 const int rf = dims->R * (2 * dims->B + 1);
@@ -178,6 +182,10 @@ int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s
         }
         const int rc = fc::copy_block(gx + 2 * (size_t)ib * blk, I, gxb, bi, N, bi, st);
         if (rc != FC_OK) return rc;
+    }
+    if (params && params->bias_partials) {
+        if (params->bias_nparts <= 0 || !params->g_bias) return FC_ERR_BAD_ARGUMENT;
+        return fc::bias_partials_reduce_impl(params->bias_partials, params->bias_nparts, O, params->g_bias, st);
     }
     return FC_OK;
 }

@@ -293,10 +293,12 @@ def _run_forward(lib, x, graph, plan, O, st, pack, addend=None, bias=None, param
     return (y if bias is None else (y, act)), wpk_b
 
 
-def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
+def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bias_sum=None):
     """-> (gx, gw_eff, parameter gradients or None).  params = (zonal, spherical, phase, ftype): also the VJP of the filter
     assembly.  One foreign call for the whole pass (fc_backward_all) unless something has to happen between the kernels: a
-    partitioned mesh's gradient exchange (graph.on_gx) or the benchmark's per-kernel event brackets."""
+    partitioned mesh's gradient exchange (graph.on_gx) or the benchmark's per-kernel event brackets.
+    bias_sum = (partials, n_parts, g_bias): the fused modReLU's bias-gradient partials, summed by the launch that finishes
+    this pass (fc_filter_params' rider; needs params)."""
     O, I, R, F = wshape
     gx = torch.empty_like(x)
     gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
@@ -313,6 +315,8 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
         pgrads = (g_z, g_s, g_p)
         fp = FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, g_z.data_ptr(), g_s.data_ptr(),
                             g_p.data_ptr() if g_p is not None else None)
+        if bias_sum is not None:
+            fp.bias_partials, fp.bias_nparts, fp.g_bias = bias_sum[0].data_ptr(), bias_sum[1], bias_sum[2].data_ptr()
     if graph.on_gx is None and _ONE_CALL and not kernel_timer.enabled:
         check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, plan.records, _p(wpk_b), _p(gx), _p(gw),
                                   ctypes.byref(fp) if fp is not None else None, wsp, nbytes, plan.dref, st), 'fc_backward_all')
@@ -413,10 +417,12 @@ class _FieldConvActFn(torch.autograd.Function):
             g_bias = torch.empty_like(bias)
             nbytes = lib.fc_tangent_nonlin_backward_workspace_bytes(N, O)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            check(lib.fc_tangent_nonlin_backward(_p(pre), _p(bias), _p(g_act), _p(g_pre), _p(g_bias), _p(ws), nbytes, N, O, st),
-                  'fc_tangent_nonlin_backward')
+            # the VJP's first kernel; its bias-gradient partials are summed by the convolution's finishing launch (one launch fewer)
+            check(lib.fc_tangent_nonlin_backward_partial(_p(pre), _p(bias), _p(g_act), _p(g_pre), _p(ws), nbytes, N, O, st),
+                  'fc_tangent_nonlin_backward_partial')
             gx, _, (g_z, g_s, g_p) = _launch_backward(lib, x, g_pre, ctx.graph, wpk_b, plan, ctx.wshape, st,
-                                                      params=(zonal, spherical, phase, ctx.ftype))
+                                                      params=(zonal, spherical, phase, ctx.ftype),
+                                                      bias_sum=(ws, lib.fc_tangent_nonlin_backward_groups(N), g_bias))
         return gx, g_z, g_s, g_p, g_bias, (g_pre if ctx.has_addend else None), None, None, None
 
 

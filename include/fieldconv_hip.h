@@ -189,6 +189,12 @@ typedef struct fc_filter_params {
     float* g_zonal;
     float* g_spherical;
     float* g_phase;
+    /* optional rider of the launch that finishes the backward pass (fc_backward_finish_params / fc_backward_all): the fixed-order sum of
+     * the modReLU's bias-gradient partials -- bias_partials (bias_nparts, O) floats as fc_tangent_nonlin_backward_partial left them --
+     * into g_bias (O), instead of a launch of its own.  NULL / 0: nothing. */
+    const float* bias_partials;
+    int32_t bias_nparts;
+    float* g_bias;
 } fc_filter_params;
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,
                       const fc_filter_params* params, float* wpk_fwd, float* wpk_bwd, float* y, void* workspace,
@@ -267,6 +273,12 @@ int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32
 size_t fc_tangent_nonlin_backward_workspace_bytes(int32_t N, int32_t C);
 int fc_tangent_nonlin_backward(const float* x, const float* bias, const float* gy, float* gx, float* gbias,
                                void* workspace, size_t workspace_bytes, int32_t N, int32_t C, void* stream);
+/* The same VJP without the second launch: gx as above, the per-group partial sums of the bias gradient left in `workspace` as
+ * (fc_tangent_nonlin_backward_groups(N), C) floats for fc_filter_params::bias_partials (a modReLU fused behind a convolution: its
+ * backward pass ends in that convolution's finish launch anyway). */
+int32_t fc_tangent_nonlin_backward_groups(int32_t N);
+int fc_tangent_nonlin_backward_partial(const float* x, const float* bias, const float* gy, float* gx, void* workspace,
+                                       size_t workspace_bytes, int32_t N, int32_t C, void* stream);
 
 /* The same in double precision (complex128 features, float64 bias): the reference's modules run under .double().
  * TangentLin in double precision is fc_cgemm with Wc = Re + i Im built by the caller. */

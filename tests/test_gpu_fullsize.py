@@ -514,8 +514,8 @@ def test_config3_full_size_every_convolution_against_the_oracle(dev):
         fwd_calls.append((x.data_ptr(), H(x), H(y), H(addend) if addend is not None else None))
         return out
 
-    def spy_b(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None):
-        res = orig_b(lib, x, gy, graph, wpk_b, plan, wshape, st, params=params)
+    def spy_b(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, **kw):
+        res = orig_b(lib, x, gy, graph, wpk_b, plan, wshape, st, params=params, **kw)
         bwd_calls[x.data_ptr()] = (H(gy), H(res[0]), H(res[1]))
         return res
 
