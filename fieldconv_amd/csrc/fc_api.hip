@@ -192,16 +192,24 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
-int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
-                              const fc_filter_params* params, void* stream) {
+static int check_finish_params(const float* gw_eff, const fc_filter_params* params, const fc_dims* dims) {
     if (!gw_eff || !params || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    // the partials' fixed-order sum and the parameter-gradient chain in ONE launch (FC_SPLIT_FINISH=1: the two kernels)
-    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     if (params->ftype < 0 || params->ftype > 2 || !params->zonal || !params->spherical || !params->g_zonal || !params->g_spherical ||
         (params->ftype == 1 && (!params->phase || !params->g_phase)))
         return FC_ERR_BAD_ARGUMENT;
     if (params->bias_partials && (params->bias_nparts <= 0 || !params->g_bias)) return FC_ERR_BAD_ARGUMENT;
+    return FC_OK;
+}
+
+int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
+                              const fc_filter_params* params, void* stream) {
+    {
+        const int rc = check_finish_params(gw_eff, params, dims);
+        if (rc != FC_OK) return rc;
+    }
+    // the partials' fixed-order sum and the parameter-gradient chain in ONE launch (FC_SPLIT_FINISH=1: the two kernels)
+    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     if (split_finish) {
         int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
         if (rc != FC_OK) return rc;
@@ -217,13 +225,26 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream) {
     if (!gw_eff) return FC_ERR_BAD_ARGUMENT;
-    int rc = records ? fc_backward_data_factored(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, records, stream)
-                     : fc_backward_data(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, stream);
+    // With parameters the pass ends in ONE launch (fc_backward_finish_params' kernel): when tiles are shared, the sum of the data kernel's
+    // partial gx arrays rides there too instead of a launch of its own between the kernels (nobody reads gx before this call returns)
+    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
+    const bool defer = params != nullptr && !split_finish;
+    int rc = check_bwd(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, dims);
+    if (rc != FC_OK) return rc;
+    if (records) {
+        if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
+        if (dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
+    } else if (dims->E > 0 && !by_source->nbr) return FC_ERR_BAD_ARGUMENT;
+    rc = fc::backward_data_impl(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, workspace, workspace_bytes, dims, records != 0,
+                                static_cast<hipStream_t>(stream), defer);
     if (rc != FC_OK) return rc;
     rc = fc_backward_filter(x, workspace, workspace_bytes, dims, records, stream);
     if (rc != FC_OK) return rc;
     if (!params) return fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
-    return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
+    if (!defer) return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
+    rc = check_finish_params(gw_eff, params, dims);
+    if (rc != FC_OK) return rc;
+    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, gx);
 }
 
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,

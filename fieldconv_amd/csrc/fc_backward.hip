@@ -661,25 +661,29 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
 }
 
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
-                                int o0, int i0, int Ifull) {
+                                int o0, int i0, int Ifull, float* gx_deferred) {
     const BwdPlan p = plan_backward(d, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes);
+    // the data kernel's partial gx arrays (backward_data_impl with defer_gx_sum), added here
+    const int gx_nparts = gx_deferred ? (1 << p.parts_log2) << p.gsplit : 1;
+    const float* gxp = gx_nparts > 1 ? reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes + p.gwp_bytes) : nullptr;
     // partial (p, f, k = r*O + o, i) at ((p*F + f)*KP + k)*IP + i
     return reduce_param_grads_impl(gwp, (size_t)p.F * p.KP * p.IP, (size_t)d->O * p.IP, (size_t)p.KP * p.IP, (size_t)p.IP, p.gd.split != 0, p.P, gw_eff,
                                    fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d, stream, o0,
-                                   i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias);
+                                   i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias, gxp, gx_deferred, (size_t)d->N * d->I,
+                                   p.gx_part_stride, gx_nparts);
 }
 
-#define FC_BWD_DATA_ARGS const float*, const float*, const float*, const fc_csr*, const float*, float*, void*, size_t, const fc_dims*, bool, hipStream_t
+#define FC_BWD_DATA_ARGS const float*, const float*, const float*, const fc_csr*, const float*, float*, void*, size_t, const fc_dims*, bool, hipStream_t, bool
 template int backward_data_impl_mode<false>(FC_BWD_DATA_ARGS);
 extern template int backward_data_impl_mode<true>(FC_BWD_DATA_ARGS);
 
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
-                       void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
-    return split_mode() ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream)
-                        : backward_data_impl_mode<false>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream);
+                       void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum) {
+    return split_mode() ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum)
+                        : backward_data_impl_mode<false>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum);
 }
 
 }  // namespace fc

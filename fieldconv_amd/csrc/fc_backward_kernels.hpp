@@ -608,7 +608,7 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
 
 template <bool SPLIT>
 int backward_data_impl_mode(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
-                            void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream) {
+                            void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum) {
     const BwdPlan p = plan_backward(d, SPLIT ? split_mode() : 0);
     if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes + p.gxp_bytes) return FC_ERR_WORKSPACE;
@@ -625,7 +625,7 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
                                                                        g, wpk, gx2, hdump, a, p, stream)
                           : launch_backward_data<6, 2, false, SPLIT, 2>(reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), sten,
                                                                         g, wpk, gx2, hdump, a, p, stream);
-            if (rc != FC_OK) return rc;
+            if (rc != FC_OK || defer_gx_sum) return rc;
             return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, gx_parts, stream);
         }
     }
@@ -639,7 +639,7 @@ int backward_data_impl_mode(const float* x, const float* gy, const float* sten, 
                                                             hdump, a, p, stream);
     FC_FOR_EACH_SHAPE(FC_CASE)
 #undef FC_CASE
-    if (rc != FC_OK || gx_parts == 1) return rc;
+    if (rc != FC_OK || gx_parts == 1 || defer_gx_sum) return rc;
     return sum_parts(gxp, gx, (size_t)d->N * d->I, p.gx_part_stride, gx_parts, stream);
 }
 

@@ -36,8 +36,10 @@ int forward_impl(const float* x, const float* sten, const fc_csr* g, const float
                  const fc_dims* d, int kind, void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream);
 size_t forward_workspace_bytes(const fc_dims* d, int kind);
 size_t backward_workspace_bytes(const fc_dims* d);
+// (defer_gx_sum: when tiles are shared -- edge parts, frequency groups -- the partial gx arrays stay in the workspace and the launch that
+//  finishes the pass adds them: backward_finish_params_impl's gx_deferred)
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
-                       void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream);
+                       void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum = false);
 int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
 // records != 0: images for the record-driven entry points (fc_forward_factored / _geometric, fc_backward_fused)
@@ -62,11 +64,13 @@ int filter_param_grads_impl(const float* gw_eff, const float* zonal, const float
 // layer: 0, 0, 0)
 // (ring_pairs: the partials' k index is dump_k(r, o) * so instead of r * sr + o * so)
 // (bias_partials / bias_nparts / g_bias: fc_filter_params' rider -- extra workgroups of the same launch sum the modReLU's bias-gradient
-//  partials, bit-identically to tangent_nonlin_gb_reduce_kernel)
+//  partials, bit-identically to tangent_nonlin_gb_reduce_kernel; gx_parts ...: a second rider, the deferred sum of the backward data
+//  kernel's partial gx arrays -- gx_count complex numbers, gx_stride apart, fc_sum_parts_kernel's arithmetic)
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
                             const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
                             float* g_phase, const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0,
-                            const float* bias_partials = nullptr, int bias_nparts = 0, float* g_bias = nullptr);
+                            const float* bias_partials = nullptr, int bias_nparts = 0, float* g_bias = nullptr,
+                            const float* gx_parts = nullptr, float* gx = nullptr, size_t gx_count = 0, size_t gx_stride = 0, int gx_nparts = 0);
 // the rider as a launch of its own (fc_pointwise.hip): g_bias[c] = fixed-order sum over p of partials[p][c]
 int bias_partials_reduce_impl(const float* partials, int nparts, int C, float* g_bias, hipStream_t stream);
 
@@ -77,7 +81,8 @@ __host__ __device__ inline int dump_k(int r, int o, int R, int O, bool pairs) {
     return (pairs && (r | 1) < R) ? (r >> 1) * 2 * O + 2 * o + (r & 1) : r * O + o;
 }
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
-                                int o0 = 0, int i0 = 0, int Ifull = 0);
+                                int o0 = 0, int i0 = 0, int Ifull = 0,
+                                float* gx_deferred = nullptr);
 int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,
                            hipStream_t stream);
 int pack_filter_params_block_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd, float* wpk_bwd,

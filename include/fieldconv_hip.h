@@ -180,7 +180,9 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
  * fc_forward_params = fc_pack_filter_params (wpk_bwd may be NULL; `records` as above) + fc_forward (kind 0) / fc_forward_factored (1) /
  *                     fc_forward_geometric (2), same arguments;
  * fc_backward_all   = fc_backward_data (records 0) or fc_backward_data_factored (1) + fc_backward_filter +
- *                     fc_backward_finish into gw_eff (required) + fc_filter_param_grads when params is not NULL. */
+ *                     fc_backward_finish into gw_eff (required) + fc_filter_param_grads when params is not NULL (then the pass
+ *                     ends in fc_backward_finish_params' single launch, which also adds the data kernel's partial gx arrays when
+ *                     tiles were shared: gx is complete when the call's work is, not between its kernels). */
 typedef struct fc_filter_params {
     const float* zonal;
     const float* spherical;
