@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the FieldConv hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--mode layer|dp] [--support p95|all]
+    python bench.py --gpus N --steps K --warmup W [--mode layer|dp|net] [--support p95|all]
 
 --mode layer (default, the metric of record).  A step = one FieldConv layer forward + backward (input gradient,
 filter-parameter gradients, the filter assembly and its autograd chain included) on a synthetic sphere mesh of
@@ -17,6 +17,11 @@ the correspondence network's topology (reference correspondence.ipynb: LiftBlock
 TangentPerceptron meta-residuals, ECHOBlock) at C = 64, band_limit 3; a step = forward + loss + backward + ONE
 bucketed all-reduce of all parameter gradients (fieldconv_amd.dist.GradientBuckets).  value = edges x convolutions per
 second over all ranks.
+
+--mode net (BASELINE configs[2]).  The segmentation network's topology (reference segmentation.ipynb: LiftBlock, four
+FCResNetBlocks, ECHOBlock) forward + loss + backward on a 1 024-vertex mesh with ~128 neighbours, launched eagerly through
+the block-level entry points (one foreign call per block and pass); extras: the step replayed as one HIP graph, composed
+of per-operator calls, and on a different mesh every step with the preprocessing inside.
 
 Inputs are resident in HBM before the timed region; support-graph preprocessing is done once outside it and reported
 separately, as it is shared by every convolution of a network.  Rank 0 prints one JSON line (README / DESIGN.md).
@@ -458,6 +463,216 @@ def run_dp(args, world, rank, dev, use_dist, backend):
     }
 
 
+# ------------------------------------------------------------------------------------------------ mode net (config 3)
+def cpu_baseline_block(N, k, C, B, R, threads, support):
+    """CPU leg of --mode net: ONE FCResNetBlock of the network (2 of its 9 convolutions) forward + backward on the same mesh, composed of
+    the oracle's reference-structured torch pieces (oracle/reference_port_torch.py: materialised (E,C,R,F) product, index-add, broadcast
+    multiply-and-sum; oracle/torch_composites.py: TangentLin / TangentNonLin), torch autograd for the backward pass.  A bounded sample:
+    the whole network is 9 convolutions of this size plus the lift and descriptor blocks (~10 GB of autograd-saved temporaries)."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import FCResNetBlock
+    from oracle import reference_port_torch as port
+    from oracle import torch_composites as tc
+    data = sphere_support(N, k=k, seed=0, support=support)
+    edges, sten, _, _ = tc.FCPrecomp(B, R, data.epsilon)(data)
+    g = torch.Generator().manual_seed(1)
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).requires_grad_(True)
+    gy = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g))
+    blk = FCResNetBlock(C, C, band_limit=B, n_rings=R, ftype=1)            # parameter container only (CPU)
+    params = list(blk.parameters())
+
+    def run():
+        t0 = time.perf_counter()
+        h = tc.tangent_nonlin(port.field_conv(x, edges, sten, blk.conv1.zonal, blk.conv1.spherical, blk.conv1.phase, 1, B), blk.nonlin1.bias)
+        y = tc.tangent_nonlin(tc.tangent_lin(x, blk.res.Re, blk.res.Im)
+                              + port.field_conv(h, edges, sten, blk.conv2.zonal, blk.conv2.spherical, blk.conv2.phase, 1, B), blk.nonlin2.bias)
+        torch.autograd.grad(y, [x] + params, grad_outputs=gy)
+        return time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    run()                                                                   # warm-up (allocator, thread pool)
+    reps, total = 0, 0.0
+    while total < 10.0 and reps < 5:
+        total += run()
+        reps += 1
+    E = int(edges.shape[0])
+    return {'value': 2 * E * reps / total / 1e6, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': f'ONE FCResNetBlock (2 of the network\'s 9 convolutions, edges counted once per convolution) forward + backward on the '
+                      f'{N}-vertex mesh (E={E}, C={C}, B={B}, R={R}), reference-structured torch CPU port (oracle/reference_port_torch.py, '
+                      f'oracle/torch_composites.py), {threads} threads, {reps} repetitions: {total:.1f} s'}
+
+
+def run_net(args, world, rank, dev, use_dist, backend):
+    """BASELINE configs[2]: the segmentation network's topology (reference segmentation.ipynb:165-236: LiftBlock(3 -> 48), four
+    FCResNetBlocks, ECHOBlock(48 -> 8, n_des = 48, n_bins = 3)) forward + loss + backward on a 1 024-vertex mesh with ~128 neighbours per
+    vertex (what sample_n = 1024 / epsilon = 0.2 give, :89,120), launched EAGERLY -- the reference trains with batch size 1 on a different
+    mesh every step (:137), so a captured HIP graph does not cover a training run; the replayed figure is an extra.  With N > 1 ranks every
+    rank holds its own mesh and a replica (one bucketed all-reduce of the gradients per step), as in --mode dp."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.dist import GradientBuckets
+    from fieldconv_amd.functional import kernel_timer
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
+    from fieldconv_amd.transforms import FCPrecomp
+    N, k, nf, B, R, n_cls = args.net_verts, args.net_k, args.channels, args.band_limit, args.n_rings, 8
+    data = sphere_support(N, k=k, seed=300 + rank).to(dev)
+    pre = FCPrecomp(B, R, data.epsilon)
+    torch.manual_seed(1234)
+    net = torch.nn.ModuleDict(dict(
+        lift=LiftBlock(3, nf, n_rings=R, ftype=1),
+        blocks=torch.nn.ModuleList([FCResNetBlock(nf, nf, band_limit=B, n_rings=R) for _ in range(4)]),
+        echo=ECHOBlock(nf, n_cls, n_des=nf, n_bins=3, band_limit=B, n_rings=R))).to(dev)
+    params = list(net.parameters())
+    buckets = GradientBuckets(params) if use_dist else None
+    g = torch.Generator().manual_seed(400 + rank)
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    labels = torch.randint(0, n_cls, (N,), generator=g).to(dev)
+    n_convs = 2 * len(net['blocks']) + 1
+
+    def forward_loss(d, p_, lab):
+        edges, sten, ln, wxp = pre(d)                          # runs every forward in the reference, too (memoised per mesh)
+        x = net['lift'](p_, edges, sten[..., B:B + 2])
+        for blk in net['blocks']:
+            x = blk(x, edges, sten)
+        logits = net['echo'](x, edges, sten, ln, wxp)
+        return torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), lab)
+
+    def step():
+        loss = forward_loss(data, pos, labels)
+        if buckets is None:
+            return (loss,) + torch.autograd.grad(loss, params)
+        buckets.begin()
+        loss.backward()
+        buckets.collect()
+        buckets.all_reduce()
+        return (loss,)
+
+    E = int(pre(data)[0].shape[0])
+    harvested = {}
+
+    def arm_timer():
+        # nine convolutions per step, every 4th launch of each kernel family bracketed (4 and 9 are coprime: every layer is sampled
+        # equally often).  While the timer is armed the blocks run as per-operator calls (the brackets go around single kernels): the
+        # same kernels, another host path -- which is why this pass is separate from the timed region
+        kernel_timer.reset(pairs=3 * (args.steps * n_convs // 4 + 2))
+        kernel_timer.stride = 4
+        kernel_timer.enabled = True
+
+    def harvest(tag):
+        kernel_timer.enabled = False
+        harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
+
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
+                               settle=not args.cold)
+    E_total = sum_over_ranks(E, use_dist, dev, backend)
+    identity = run_identity(use_dist, dev, backend, dev.index, {'vertices': N, 'edges': E})
+    if rank != 0:
+        return None
+    F = 2 * B + 1
+    fwd_b, bwd_b = algorithmic_bytes(N, E, nf, nf, R, F)       # every one of the nine convolutions is nf -> nf on this mesh
+    wb = 8 * nf * nf * R * F
+    contract = {'fc_forward': fwd_b, 'fc_backward_data': bwd_b - wb - 8 * N * nf, 'fc_backward_filter': wb + 8 * N * nf}
+
+    def kernel_report(kt):
+        per = {}
+        for name, nbytes in contract.items():
+            if name in kt:
+                sec = kt[name] * 1e-3
+                per[name] = {'avg_ms': kt[name], 'algorithmic_bytes_per_launch': nbytes, 'launches_per_step': n_convs,
+                             'GBps': nbytes / sec / 1e9, 'hbm_frac': nbytes / sec / 1e9 / HBM_PEAK_GBS}
+        return per
+
+    per_kernel = kernel_report(harvested.get('literal', {}))
+    dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
+    roofline = None
+    if dom:
+        conv_ms = sum(v['avg_ms'] for v in per_kernel.values()) * n_convs
+        roofline = {'bound': 'hbm', 'kernel': dom + '_kernel', 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': per_kernel[dom]['hbm_frac'], 'traffic': None, 'avg_launch_ms': per_kernel[dom]['avg_ms'],
+                    'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes_per_launch'],
+                    'algorithmic_bytes_per_step_all_convolutions': n_convs * (fwd_b + bwd_b),
+                    'convolution_kernels_ms_per_step': conv_ms,
+                    'note': f'mean over the {n_convs} FieldConv layers of the network, all {nf} -> {nf} on this mesh (HIP events around every '
+                            '4th launch of each kernel family in the instrumented pass behind the timed region; algorithmic bytes of SURVEY '
+                            '8(d) per convolution); at 64 tiles of 16 vertices the kernels are launch-size bound -- up to 8 workgroups '
+                            'share a tile (edge split) -- not bandwidth bound; traffic: no counter pass is committed for this mode'}
+    settled = None
+    if info['settled'] is not None:
+        t_set, n_extra = info['settled']
+        settled = {'value': E_total * n_convs / (t_set / args.steps) / 1e6, 'unit': 'Medges/s', 'ms_per_step': t_set / args.steps * 1e3,
+                   'extra_untimed_steps': n_extra + args.warmup + args.steps,
+                   'kernel_us': {k_: round(v['avg_ms'] * 1e3, 1) for k_, v in kernel_report(harvested.get('settled', {})).items()},
+                   'note': 'the same warmup + steps again after extra_untimed_steps more steps (sustained clock): an extra'}
+    out = {
+        'metric': 'FieldConv fwd+bwd Medges/s (config 3: segmentation-net topology, 1 024 verts, k~128, C=48, M=2; edges x 9 convolutions)',
+        'value': E_total * n_convs / (elapsed / args.steps) / 1e6, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[2] shape: segmentation-net topology (LiftBlock 3->{nf}, 4 FCResNetBlocks, ECHOBlock {nf}->{n_cls} '
+                               f'with n_des={nf}, n_bins=3; {sum(p.numel() for p in params)} parameters) forward + loss + backward on one {N}-vertex '
+                               f'mesh per GPU, k={k} ({E} support edges), band_limit={B}, n_rings={R}, launched eagerly through the block-level '
+                               f'entry points; edges counted once per FieldConv ({n_convs} per network)',
+                   'verts_per_gpu': N, 'edges_per_mesh_rank0': E, 'convs_per_step': n_convs,
+                   'parallelism': 'single GPU' if world == 1 and not use_dist else f'data-parallel x{world}: one mesh per GPU, one bucketed '
+                                  f'all-reduce of {4 * buckets.flat.numel()} gradient bytes per step over RCCL',
+                   'step_launch': 'eager (a training run sees a different mesh every step: reference segmentation.ipynb:137)',
+                   'env': env_report()},
+        'ranks': identity, 'roofline': roofline, 'kernels': per_kernel, 'settled': settled, 'protocol': PROTOCOL_NOTE,
+    }
+    if world == 1 and not use_dist and not args.no_extras:
+        def timeit(fn, n_warm=10, n=50):
+            for _ in range(n_warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        # (1) the same step replayed as one HIP graph: the GPU-side floor of this schedule
+        try:
+            from fieldconv_amd.utils import StepGraph
+            sg = StepGraph(lambda: step())
+            out['graph_replay'] = {'ms_per_step': timeit(sg.replay, 20, 100),
+                                   'note': 'the same forward + loss + backward captured once and replayed (fieldconv_amd.utils.StepGraph): one '
+                                           'mesh only -- not what a training run over a dataset can use'}
+            out['eager_over_replay'] = out['ms_per_step'] / out['graph_replay']['ms_per_step']
+        except Exception as exc:                      # noqa: BLE001
+            out['graph_replay'] = {'error': repr(exc)[:200]}
+        # (2) the per-operator host path (FIELDCONV_BLOCK_CALLS=0: ~80 foreign calls per step instead of 12)
+        os.environ['FIELDCONV_BLOCK_CALLS'] = '0'
+        try:
+            out['per_operator_calls'] = {'ms_per_step': timeit(step), 'note': 'the same step with every block composed of per-operator autograd '
+                                                                              'nodes and foreign calls (FIELDCONV_BLOCK_CALLS=0)'}
+        finally:
+            del os.environ['FIELDCONV_BLOCK_CALLS']
+        # (3) a DIFFERENT mesh every step, preprocessing included: what the reference's training loop does (segmentation.ipynb:276-317)
+        meshes = []
+        for i in range(8):
+            d_i = sphere_support(N, k=k, seed=500 + i).to(dev)
+            gi = torch.Generator().manual_seed(600 + i)
+            meshes.append((d_i, torch.randn(N, 3, generator=gi).to(dev), torch.randint(0, n_cls, (N,), generator=gi).to(dev)))
+        from fieldconv_amd.graph import clear_cache
+        turn = [0]
+
+        def fresh_step():
+            d_i, p_i, l_i = meshes[turn[0] % len(meshes)]
+            turn[0] += 1
+            pre._memo = None
+            clear_cache()                               # every step builds its mesh's support graph anew
+            return torch.autograd.grad(forward_loss(d_i, p_i, l_i), params)
+        out['new_mesh_every_step'] = {'ms_per_step': timeit(fresh_step, 16, 48),
+                                      'note': 'eight meshes of the same size in turn, FCPrecomp + support-graph build (fc_precomp_mark, one '
+                                              'synchronisation, fc_precomp_graph) inside every step, no cache hit'}
+    if world == 1 and not args.no_cpu_baseline:
+        threads = max(1, (os.cpu_count() or 2) // 2)
+        try:
+            out['cpu_baseline'] = cpu_baseline_block(N, k, nf, B, R, threads, 'all')
+        except Exception as exc:
+            out['cpu_baseline'] = {'value': None, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port', 'sample': f'failed: {type(exc).__name__}: {exc}'}
+    else:
+        out['cpu_baseline'] = None
+    return out
+
+
 # ------------------------------------------------------------------------------------------ mode layer (the metric)
 def run_layer(args, world, rank, dev, use_dist, backend):
     from fieldconv_amd.data import sphere_partition
@@ -789,7 +1004,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)       # 0.4 ms each: long enough for steady clocks and a full launch queue
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--mode', default='layer', choices=['layer', 'dp'])
+    ap.add_argument('--mode', default='layer', choices=['layer', 'dp', 'net'])
     ap.add_argument('--verts', type=int, default=20000, help='vertices per GPU (mode layer)')
     ap.add_argument('--k', type=int, default=32)
     ap.add_argument('--channels', type=int, default=48)
@@ -799,6 +1014,8 @@ def main():
     ap.add_argument('--dp-k', type=int, default=28)
     ap.add_argument('--dp-channels', type=int, default=64)
     ap.add_argument('--dp-band-limit', type=int, default=3)
+    ap.add_argument('--net-verts', type=int, default=1024, help='vertices per mesh (mode net: the reference samples 1 024 points)')
+    ap.add_argument('--net-k', type=int, default=128, help='neighbours per vertex (mode net)')
     ap.add_argument('--support', default='p95', choices=['p95', 'all'],
                     help="support radius: 'p95' = 95-percentile of the k-NN distances (SURVEY 8(d) G-geo: FCPrecomp drops 5 %% of the "
                          "edges, every ring populated); 'all' = above every k-NN distance (round-1 mesh: E = N*k, outer rings empty)")
@@ -853,7 +1070,7 @@ def main():
     if use_dist:
         init_dist(dev, backend)
 
-    out = (run_dp if args.mode == 'dp' else run_layer)(args, world, rank, dev, use_dist, backend)
+    out = {'dp': run_dp, 'net': run_net, 'layer': run_layer}[args.mode](args, world, rank, dev, use_dist, backend)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -33,7 +33,32 @@ class FcEpilogue(ctypes.Structure):
     _fields_ = [('addend', _vp), ('modrelu_bias', _vp), ('activated', _vp)]
 
 
+class FcMesh(ctypes.Structure):
+    """fc_mesh: one mesh's support graph as the block-level entry points take it"""
+    _fields_ = [('N', _c_int32), ('E', _c_int32), ('R', _c_int32), ('B', _c_int32), ('kind', _c_int32),
+                ('by_target', ctypes.POINTER(FcCsr)), ('by_source', ctypes.POINTER(FcCsr)), ('fwd', _vp), ('bwd', _vp)]
+
+
+class FcResnetBlockParams(ctypes.Structure):
+    _fields_ = [('C_in', _c_int32), ('C_mid', _c_int32), ('C_out', _c_int32), ('conv1', FcFilterParams), ('conv2', FcFilterParams),
+                ('bias1', _vp), ('bias2', _vp), ('res_re', _vp), ('res_im', _vp),
+                ('g_bias1', _vp), ('g_bias2', _vp), ('g_res_re', _vp), ('g_res_im', _vp)]
+
+
+class FcEchoBlockParams(ctypes.Structure):
+    _fields_ = [('C_in', _c_int32), ('n_des', _c_int32), ('n_bins', _c_int32), ('conv', FcFilterParams), ('bias', _vp), ('g_bias', _vp)]
+
+
+class FcLiftBlockParams(ctypes.Structure):
+    _fields_ = [('C_in', _c_int32), ('C_out', _c_int32), ('ftype', _c_int32), ('zonal_ang', _vp), ('zonal_mag', _vp), ('phase', _vp),
+                ('bias', _vp), ('g_zonal_ang', _vp), ('g_zonal_mag', _vp), ('g_phase', _vp), ('g_bias', _vp)]
+
+
 _DP = ctypes.POINTER(FcDims)
+_MP = ctypes.POINTER(FcMesh)
+_RBP = ctypes.POINTER(FcResnetBlockParams)
+_EBP = ctypes.POINTER(FcEchoBlockParams)
+_LBP = ctypes.POINTER(FcLiftBlockParams)
 _CP = ctypes.POINTER(FcCsr)
 _EP = ctypes.POINTER(FcEpilogue)
 _FP = ctypes.POINTER(FcFilterParams)
@@ -99,6 +124,18 @@ SIGNATURES = {
     'fc_tangent_nonlin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
     'fc_tangent_nonlin_backward_groups': (_c_int32, [_c_int32]),
     'fc_tangent_nonlin_backward_partial': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
+    'fc_resnet_block_saved_bytes': (_sz, [_MP, _RBP]),
+    'fc_resnet_block_workspace_bytes': (_sz, [_MP, _RBP, _c_int32]),
+    'fc_resnet_block_forward': (ctypes.c_int, [_vp, _MP, _RBP, _vp, _vp, _sz, _vp, _sz, _vp]),
+    'fc_resnet_block_backward': (ctypes.c_int, [_vp, _vp, _MP, _RBP, _vp, _sz, _vp, _vp, _sz, _vp]),
+    'fc_echo_block_saved_bytes': (_sz, [_MP, _EBP]),
+    'fc_echo_block_workspace_bytes': (_sz, [_MP, _EBP, _c_int32]),
+    'fc_echo_block_forward': (ctypes.c_int, [_vp, _MP, _vp, _vp, _EBP, _vp, _vp, _sz, _vp, _sz, _vp]),
+    'fc_echo_block_backward': (ctypes.c_int, [_vp, _vp, _MP, _vp, _vp, _EBP, _vp, _sz, _vp, _vp, _sz, _vp]),
+    'fc_lift_block_saved_bytes': (_sz, [_MP, _LBP]),
+    'fc_lift_block_workspace_bytes': (_sz, [_MP, _LBP, _c_int32]),
+    'fc_lift_block_forward': (ctypes.c_int, [_vp, _vp, _c_int32, _MP, _vp, _LBP, _vp, _vp, _sz, _vp]),
+    'fc_lift_block_backward': (ctypes.c_int, [_vp, _vp, _c_int32, _MP, _vp, _LBP, _vp, _sz, _vp, _vp, _sz, _vp]),
 }
 
 _LIB = None

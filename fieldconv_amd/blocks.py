@@ -1,0 +1,330 @@
+"""Whole network blocks as ONE autograd node and ONE foreign call per pass.
+
+The reference's networks are stacks of three blocks -- FCResNetBlock (reference nn/fc_resnet_block.py:65-88), ECHOBlock
+(nn/echo_block.py:73-103), LiftBlock (nn/lift_block.py:35-55) -- trained with batch size 1 on a different ~1k-vertex mesh every step
+(segmentation.ipynb:120,137).  At that size the GPU runs a block in ~150 us while a per-operator binding spends ~300 us of host time on
+it: five autograd nodes, a dozen `torch.empty`, sixteen ctypes calls.  The functions below hand a whole block pass to the library's
+block-level entry points (csrc/fc_blocks.hip: fc_resnet_block_forward / _backward, fc_echo_block_*, fc_lift_block_*): same kernels, same
+bits, two foreign calls and two allocations per pass.
+
+Every function returns None when the block-level path does not apply (wide or run-time-path layers, double precision, a partitioned
+mesh's exchange hooks, per-kernel timing, a development switch that selects separate operators); the modules then compose the
+per-operator functions of functional.py as before.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import FcEchoBlockParams, FcFilterParams, FcLiftBlockParams, FcMesh, FcResnetBlockParams, check
+from . import functional as Fn
+
+def enabled():
+    """False under the development switches that ask for separate operators / calls / no edge split (read per call: tests flip them),
+    and while the benchmark brackets single kernels with events"""
+    env = os.environ
+    return (env.get('FIELDCONV_BLOCK_CALLS', '1') != '0' and Fn._ONE_CALL and env.get('FIELDCONV_NO_FUSED_EPILOGUE', '0') != '1'
+            and env.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1' and not Fn.kernel_timer.enabled)
+
+
+def _plain_graph(graph):
+    """no exchange hooks, no restricted targets: nothing has to happen between the kernels of a pass"""
+    return graph.on_gx is None and graph.forward_split is None and graph.n_targets == graph.N
+
+
+class _Mesh:
+    """fc_mesh of a support graph (cached on the graph per band limit; keeps the grouping structs alive)"""
+    __slots__ = ('csr_t', 'csr_s', 'struct', 'ref')
+
+    def __init__(self, graph, B):
+        self.csr_t = Fn._csr(graph.rowptr_t, graph.nbr_t, graph.runs_t)
+        self.csr_s = Fn._csr(graph.rowptr_s, graph.nbr_s, graph.runs_s)
+        if graph.geo_t is not None:
+            kind, fwd, bwd = 2, graph.geo_t, graph.rec_s
+        elif graph.factored:
+            kind, fwd, bwd = 1, graph.rec_t, graph.rec_s
+        else:
+            kind, fwd, bwd = 0, graph.sten_t, graph.sten_s
+        self.struct = FcMesh(graph.N, graph.E, graph.R, int(B), kind, ctypes.pointer(self.csr_t), ctypes.pointer(self.csr_s),
+                             fwd.data_ptr() if fwd is not None else None, bwd.data_ptr() if bwd is not None else None)
+        self.ref = ctypes.byref(self.struct)
+
+
+def _mesh(graph, B):
+    key = ('mesh', int(B))
+    m = graph._plans.get(key)
+    if m is None:
+        m = graph._plans[key] = _Mesh(graph, B)
+    return m
+
+
+def _filter_params(conv_tensors, ftype, grads=None):
+    zonal, spherical, phase = conv_tensors
+    if grads is None:
+        return FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, None, None, None)
+    return FcFilterParams(zonal.data_ptr(), spherical.data_ptr(), phase.data_ptr(), ftype, grads[0].data_ptr(), grads[1].data_ptr(),
+                          grads[2].data_ptr() if grads[2] is not None else None)
+
+
+def _carve(flat, shapes):
+    """views of one flat float32 buffer, one per shape (None entries stay None and take no room)"""
+    out, off = [], 0
+    for shp in shapes:
+        if shp is None:
+            out.append(None)
+            continue
+        n = 1
+        for d in shp:
+            n *= d
+        out.append(flat[off:off + n].view(shp))
+        off += (n + 3) // 4 * 4             # 16-byte aligned pieces
+    return out
+
+
+def _carve_size(shapes):
+    total = 0
+    for shp in shapes:
+        if shp is not None:
+            n = 1
+            for d in shp:
+                n *= d
+            total += (n + 3) // 4 * 4
+    return total
+
+
+def _u8(nbytes, dev):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+
+
+# ----------------------------------------------------------------------------------------------------------------- FCResNetBlock
+class _ResnetBlockFn(torch.autograd.Function):
+    """reference nn/fc_resnet_block.py:84-88 as fc_resnet_block_forward / fc_resnet_block_backward"""
+
+    @staticmethod
+    def forward(ctx, x, z1, s1, p1, b1, z2, s2, p2, b2, re_w, im_w, ftype, B, graph):
+        lib = _lib.load()
+        x = x.contiguous()
+        tens = [t.contiguous() for t in (z1, s1, p1, b1, z2, s2, p2, b2, re_w, im_w)]
+        z1, s1, p1, b1, z2, s2, p2, b2, re_w, im_w = tens
+        C_mid, C_in, C_out = z1.shape[0], z1.shape[1], z2.shape[0]
+        mesh = _mesh(graph, B)
+        bp = FcResnetBlockParams(C_in, C_mid, C_out, _filter_params((z1, s1, p1), ftype), _filter_params((z2, s2, p2), ftype),
+                                 b1.data_ptr(), b2.data_ptr(), re_w.data_ptr(), im_w.data_ptr(), None, None, None, None)
+        key = ('resnet', C_in, C_mid, C_out, int(B))
+        sizes = graph._plans.get(key)
+        if sizes is None:
+            bref = ctypes.byref(bp)
+            sizes = graph._plans[key] = (lib.fc_resnet_block_saved_bytes(mesh.ref, bref), lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 0),
+                                         lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 1))
+        dev = x.device
+        with Fn._on(dev):
+            out = torch.empty((graph.N, C_out), dtype=torch.complex64, device=dev)
+            saved = _u8(sizes[0], dev)
+            ws = _u8(sizes[1], dev)
+            check(lib.fc_resnet_block_forward(Fn._p(x), mesh.ref, ctypes.byref(bp), Fn._p(out), Fn._p(saved), sizes[0], Fn._p(ws), sizes[1],
+                                              Fn._stream()), 'fc_resnet_block_forward')
+        ctx.save_for_backward(x, saved, *tens)
+        ctx.graph, ctx.ftype, ctx.B, ctx.sizes = graph, ftype, B, sizes
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        x, saved, z1, s1, p1, b1, z2, s2, p2, b2, re_w, im_w = ctx.saved_tensors
+        graph, ftype, sizes = ctx.graph, ctx.ftype, ctx.sizes
+        C_mid, C_in, C_out = z1.shape[0], z1.shape[1], z2.shape[0]
+        g_out = g_out.contiguous()
+        mesh = _mesh(graph, ctx.B)
+        dev = x.device
+        has_phase = ftype == 1
+        shapes = [z1.shape, s1.shape, p1.shape if has_phase else None, b1.shape, z2.shape, s2.shape, p2.shape if has_phase else None,
+                  b2.shape, re_w.shape, im_w.shape]
+        with Fn._on(dev):
+            gx = torch.empty_like(x)
+            flat = torch.empty(_carve_size(shapes), dtype=torch.float32, device=dev)
+            g_z1, g_s1, g_p1, g_b1, g_z2, g_s2, g_p2, g_b2, g_re, g_im = _carve(flat, shapes)
+            ws = _u8(sizes[2], dev)
+            bp = FcResnetBlockParams(C_in, C_mid, C_out, _filter_params((z1, s1, p1), ftype, (g_z1, g_s1, g_p1)),
+                                     _filter_params((z2, s2, p2), ftype, (g_z2, g_s2, g_p2)), b1.data_ptr(), b2.data_ptr(),
+                                     re_w.data_ptr(), im_w.data_ptr(), g_b1.data_ptr(), g_b2.data_ptr(), g_re.data_ptr(), g_im.data_ptr())
+            check(lib.fc_resnet_block_backward(Fn._p(x), Fn._p(g_out), mesh.ref, ctypes.byref(bp), Fn._p(saved), sizes[0], Fn._p(gx), Fn._p(ws),
+                                               sizes[2], Fn._stream()), 'fc_resnet_block_backward')
+        return gx, g_z1, g_s1, g_p1, g_b1, g_z2, g_s2, g_p2, g_b2, g_re, g_im, None, None, None
+
+
+def _conv_ok(conv, graph, x, channels=None):
+    """the block-level entry points take what the fused-epilogue path takes: compiled (n_rings, band_limit), float32, one channel block.
+    x: the block's input; `channels`: the width this convolution sees when it is not the block's first"""
+    if x.dtype != torch.complex64 or x.dim() != 2 or x.shape[0] != graph.N or (x.shape[1] if channels is None else channels) != conv.in_channels:
+        return False
+    key = ('block_ok', conv.in_channels, conv.out_channels, conv.B, conv.R)
+    ok = graph._plans.get(key)
+    if ok is None:          # a property of (graph, layer shape): decided once
+        ok = not Fn._run_time_path(x, graph) and conv.R == graph.R and 2 * conv.B + 1 == graph.F
+        if ok:
+            blk = Fn._channel_block(graph, conv.in_channels, conv.out_channels, conv.B)
+            ok = conv.in_channels <= blk and conv.out_channels <= blk
+        graph._plans[key] = ok
+    return ok
+
+
+def resnet_block(block, x, graph):
+    """FCResNetBlock.forward through the block-level entry points, or None when they do not apply"""
+    if not (enabled() and Fn.on_device(x) and _plain_graph(graph)):
+        return None
+    c1, c2 = block.conv1, block.conv2
+    if c1.ftype != c2.ftype or c1.B != c2.B or not _conv_ok(c1, graph, x) or not _conv_ok(c2, graph, x, c1.out_channels):
+        return None
+    if max(block.res.Re.shape) > Fn.MAX_CHANNELS:
+        return None
+    return _ResnetBlockFn.apply(x, c1.zonal, c1.spherical, c1.phase, block.nonlin1.bias, c2.zonal, c2.spherical, c2.phase,
+                                block.nonlin2.bias, block.res.Re, block.res.Im, int(c1.ftype), int(c1.B), graph)
+
+
+# --------------------------------------------------------------------------------------------------------------------- ECHOBlock
+def _key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.dtype)
+
+
+def echo_slot_order(graph, ln, wxp):
+    """ln / wxp in the slot orders of the two groupings (what fc_echo_forward / fc_echo_backward stream), built once per mesh and kept
+    with the graph: (ln_t, wxp_t, ln_s, wxp_s)."""
+    key = ('echo_slots', _key(ln), _key(wxp))
+    hit = graph._plans.get(key)
+    if hit is None:
+        l64, w64 = ln.to(torch.complex64), wxp.to(torch.complex64)
+        hit = graph._plans[key] = (l64.index_select(0, graph.perm_t).contiguous(), w64.index_select(0, graph.perm_t).contiguous(),
+                                   l64.index_select(0, graph.perm_s).contiguous(), w64.index_select(0, graph.perm_s).contiguous(), (ln, wxp))
+    return hit
+
+
+class _EchoBlockFn(torch.autograd.Function):
+    """reference nn/echo_block.py:93-94: ECHO(modReLU(conv(x))) as fc_echo_block_forward / fc_echo_block_backward"""
+
+    @staticmethod
+    def forward(ctx, x, zonal, spherical, phase, bias, ftype, B, n_des, n_bins, graph, slots):
+        lib = _lib.load()
+        x = x.contiguous()
+        zonal, spherical, phase, bias = zonal.contiguous(), spherical.contiguous(), phase.contiguous(), bias.contiguous()
+        C_in = zonal.shape[1]
+        mesh = _mesh(graph, B)
+        bp = FcEchoBlockParams(C_in, n_des, n_bins, _filter_params((zonal, spherical, phase), ftype), bias.data_ptr(), None)
+        key = ('echo_block', C_in, n_des, n_bins, int(B))
+        sizes = graph._plans.get(key)
+        if sizes is None:
+            bref = ctypes.byref(bp)
+            sizes = graph._plans[key] = (lib.fc_echo_block_saved_bytes(mesh.ref, bref), lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 0),
+                                         lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 1), lib.fc_echo_hist_dim(n_bins))
+        dev = x.device
+        with Fn._on(dev):
+            desc = torch.empty((graph.N, n_des, sizes[3]), dtype=torch.float32, device=dev)
+            saved = _u8(sizes[0], dev)
+            ws = _u8(sizes[1], dev)
+            check(lib.fc_echo_block_forward(Fn._p(x), mesh.ref, Fn._p(slots[0]), Fn._p(slots[1]), ctypes.byref(bp), Fn._p(desc), Fn._p(saved),
+                                            sizes[0], Fn._p(ws), sizes[1], Fn._stream()), 'fc_echo_block_forward')
+        ctx.save_for_backward(x, saved, zonal, spherical, phase, bias)
+        ctx.graph, ctx.ftype, ctx.B, ctx.sizes, ctx.n_des, ctx.n_bins, ctx.slots = graph, ftype, B, sizes, n_des, n_bins, slots
+        return desc
+
+    @staticmethod
+    def backward(ctx, g_desc):
+        lib = _lib.load()
+        x, saved, zonal, spherical, phase, bias = ctx.saved_tensors
+        graph, ftype, sizes, slots = ctx.graph, ctx.ftype, ctx.sizes, ctx.slots
+        g_desc = g_desc.contiguous()
+        mesh = _mesh(graph, ctx.B)
+        dev = x.device
+        shapes = [zonal.shape, spherical.shape, phase.shape if ftype == 1 else None, bias.shape]
+        with Fn._on(dev):
+            gx = torch.empty_like(x)
+            n_flat = _carve_size(shapes)
+            # the module's bias has in_channels entries of which the first n_des act (reference nn/echo_block.py:57,93): the rest get zero
+            flat = (torch.zeros if bias.numel() > ctx.n_des else torch.empty)(n_flat, dtype=torch.float32, device=dev)
+            g_z, g_s, g_p, g_b = _carve(flat, shapes)
+            ws = _u8(sizes[2], dev)
+            bp = FcEchoBlockParams(zonal.shape[1], ctx.n_des, ctx.n_bins, _filter_params((zonal, spherical, phase), ftype, (g_z, g_s, g_p)),
+                                   bias.data_ptr(), g_b.data_ptr())
+            check(lib.fc_echo_block_backward(Fn._p(x), Fn._p(g_desc), mesh.ref, Fn._p(slots[2]), Fn._p(slots[3]), ctypes.byref(bp), Fn._p(saved),
+                                             sizes[0], Fn._p(gx), Fn._p(ws), sizes[2], Fn._stream()), 'fc_echo_block_backward')
+        return gx, g_z, g_s, g_p, g_b, None, None, None, None, None, None
+
+
+def echo_block_descriptors(block, x, graph, ln, wxp):
+    """ECHOBlock's tangent-feature half -- ECHO(modReLU(conv(x))) -> (N, n_des, dS) -- or None when the block-level path does not apply"""
+    if not (enabled() and Fn.on_device(x) and _plain_graph(graph)) or graph.perm_t is None or graph.nbr_t is None:
+        return None
+    conv, n_des, n_bins = block.conv, block.n_des, int(block.echo.n_bins)
+    if not _conv_ok(conv, graph, x):
+        return None
+    blk = _lib.load().fc_echo_channel_block(n_bins)
+    if blk <= 0 or n_des > blk or n_des != conv.out_channels:
+        return None
+    slots = echo_slot_order(graph, ln, wxp)
+    return _EchoBlockFn.apply(x, conv.zonal, conv.spherical, conv.phase, block.nonlin.bias, int(conv.ftype), int(conv.B), int(n_des), n_bins,
+                              graph, slots)
+
+
+# --------------------------------------------------------------------------------------------------------------------- LiftBlock
+class _LiftBlockFn(torch.autograd.Function):
+    """reference nn/lift_block.py:53-55: modReLU(TransField(x)) as fc_lift_block_forward / fc_lift_block_backward"""
+
+    @staticmethod
+    def forward(ctx, x, lift_sten, zonal_ang, zonal_mag, phase, bias, ftype, csr):
+        lib = _lib.load()
+        x = x.contiguous()
+        sten, stride = Fn._TransFieldFn._stencil(lift_sten)
+        zonal_ang, zonal_mag, phase, bias = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous(), bias.contiguous()
+        N, C_in = x.shape
+        C_out, _, R = zonal_ang.shape
+        by_t, by_s = Fn._csr(csr.rowptr_t, csr.nbr_t, None), Fn._csr(csr.rowptr_s, csr.nbr_s, None)
+        mesh = FcMesh(N, csr.E, R, 0, 0, ctypes.pointer(by_t), ctypes.pointer(by_s), None, None)
+        bp = FcLiftBlockParams(C_in, C_out, ftype, zonal_ang.data_ptr(), zonal_mag.data_ptr(), phase.data_ptr(), bias.data_ptr(),
+                               None, None, None, None)
+        nsaved = lib.fc_lift_block_saved_bytes(ctypes.byref(mesh), ctypes.byref(bp))
+        dev = x.device
+        with Fn._on(dev):
+            out = torch.empty((N, C_out), dtype=torch.complex64, device=dev)
+            saved = _u8(nsaved, dev)
+            check(lib.fc_lift_block_forward(Fn._p(x), Fn._p(sten), stride, ctypes.byref(mesh), Fn._p(csr.perm_t), ctypes.byref(bp), Fn._p(out),
+                                            Fn._p(saved), nsaved, Fn._stream()), 'fc_lift_block_forward')
+        ctx.save_for_backward(sten, saved, zonal_ang, zonal_mag, phase, bias)
+        ctx.csr, ctx.ftype, ctx.stride, ctx.dims, ctx.nsaved = csr, ftype, stride, (N, C_in, C_out, R), nsaved
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        sten, saved, zonal_ang, zonal_mag, phase, bias = ctx.saved_tensors
+        csr, ftype = ctx.csr, ctx.ftype
+        N, C_in, C_out, R = ctx.dims
+        g_out = g_out.contiguous()
+        by_t, by_s = Fn._csr(csr.rowptr_t, csr.nbr_t, None), Fn._csr(csr.rowptr_s, csr.nbr_s, None)
+        mesh = FcMesh(N, csr.E, R, 0, 0, ctypes.pointer(by_t), ctypes.pointer(by_s), None, None)
+        dev = g_out.device
+        shapes = [zonal_ang.shape, zonal_mag.shape, phase.shape if ftype != 0 else None, bias.shape]
+        with Fn._on(dev):
+            gx = torch.empty((N, C_in), dtype=torch.float32, device=dev)
+            g_za, g_zm, g_ph, g_b = _carve(torch.empty(_carve_size(shapes), dtype=torch.float32, device=dev), shapes)
+            bp = FcLiftBlockParams(C_in, C_out, ftype, zonal_ang.data_ptr(), zonal_mag.data_ptr(), phase.data_ptr(), bias.data_ptr(),
+                                   g_za.data_ptr(), g_zm.data_ptr(), g_ph.data_ptr() if g_ph is not None else None, g_b.data_ptr())
+            nws = lib.fc_lift_block_workspace_bytes(ctypes.byref(mesh), ctypes.byref(bp), 1)
+            ws = _u8(nws, dev)
+            check(lib.fc_lift_block_backward(Fn._p(g_out), Fn._p(sten), ctx.stride, ctypes.byref(mesh), Fn._p(csr.perm_s), ctypes.byref(bp),
+                                             Fn._p(saved), ctx.nsaved, Fn._p(gx), Fn._p(ws), nws, Fn._stream()), 'fc_lift_block_backward')
+        return gx, None, g_za, g_zm, g_ph, g_b, None, None
+
+
+def lift_block(block, x, supp_edges, lift_sten):
+    """LiftBlock.forward through the block-level entry points, or None when they do not apply"""
+    if not (enabled() and Fn.on_device(x)) or x.dtype != torch.float32 or x.dim() != 2 or lift_sten.dtype != torch.complex64:
+        return None
+    field = block.field
+    O, Cin, R = field.zonalAng.shape
+    if x.shape[1] != Cin or lift_sten.dim() != 3 or lift_sten.shape[1] != R or lift_sten.shape[2] < 2 or R > 8 or Cin > 4 or O > Fn.MAX_CHANNELS:
+        return None
+    if lift_sten.shape[2] > 2:
+        lift_sten = lift_sten[..., :2]
+    from .graph import get_edge_csr
+    csr = get_edge_csr(supp_edges, x.shape[0])
+    return _LiftBlockFn.apply(x, lift_sten, field.zonalAng, field.zonalMag, field.phase, block.nonlin.bias, int(field.ftype), csr)

@@ -93,6 +93,11 @@ bool shape_compiled(int R, int B);
 void describe_forward(const fc_dims* d, int kind, char* buf, size_t n);
 void describe_backward(const fc_dims* d, int records, char* buf, size_t n);
 
+// TangentLin's backward pass (fc_pointwise.hip) with an optional addend of the input gradient (may be gx itself): the block-level
+// entry points (fc_blocks.hip) add the residual branch's input gradient to the convolution's inside this launch
+int tangent_lin_backward_impl(const float* x, const float* gy, const float* re_w, const float* im_w, float* gx, const float* gx_addend,
+                              float* g_re, float* g_im, void* workspace, size_t workspace_bytes, int N, int I, int O, hipStream_t s);
+
 // FCPrecomp's area sums total[dst] += w[src] over the kept edges (csrc/fc_precomp.hip), shared with the fused build
 int precomp_area_sums(const int64_t* edges, const int32_t* keep, const float* w, float* total, int N, int E, hipStream_t s);
 

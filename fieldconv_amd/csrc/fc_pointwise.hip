@@ -19,6 +19,8 @@ namespace fc {
 // fragments are already in flight, and every wavefront then walks blocks of 16 vertices with up to 64
 // outputs accumulated together.  D rows = vertices, columns = outputs: each accumulator row is one
 // 128-byte store.  Loads are unconditional from clamped addresses (no control flow around them).
+// addend (optional, (N,M) complex64, may alias out): out = product + addend -- the block-level backward pass adds the residual
+// branch's input gradient to the convolution's this way instead of a launch of its own.
 constexpr int kLinThreads = 256;
 constexpr int kLinWaves = kLinThreads / kWave;
 constexpr int kLinChunk = 6;      // k blocks (8 complex inputs each) loaded ahead of their MFMAs
@@ -48,8 +50,8 @@ __device__ __forceinline__ void lin_load_fragments(float4 (&a)[kLinChunk], const
 
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* __restrict__ in, const float* __restrict__ wre,
-                                                                  const float* __restrict__ wim, float2* __restrict__ out,
-                                                                  int N, int K, int M, int ldw) {
+                                                                  const float* __restrict__ wim, float2* out,
+                                                                  const float2* addend, int N, int K, int M, int ldw) {
     extern __shared__ float lds[];
     const int KR = round_up(2 * K, 16), KS = slab_stride(KR), MP = round_up(M, 16);
     float* Wr = lds;
@@ -130,7 +132,15 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int no = blk * 16 + 4 * fq + j;
-                    if (no < N && mo < M) out[(size_t)no * M + mo] = make_float2(acc_re[t][j], acc_im[t][j]);
+                    if (no < N && mo < M) {
+                        float2 v = make_float2(acc_re[t][j], acc_im[t][j]);
+                        if (addend) {           // (may be `out` itself: each entry is read and written by this thread only)
+                            const float2 s = addend[(size_t)no * M + mo];
+                            v.x += s.x;
+                            v.y += s.y;
+                        }
+                        out[(size_t)no * M + mo] = v;
+                    }
                 }
             }
         }
@@ -302,27 +312,49 @@ int bias_partials_reduce_impl(const float* partials, int nparts, int C, float* g
 }
 }  // namespace fc
 
-extern "C" {
+extern "C" size_t fc_tangent_lin_backward_workspace_bytes(int32_t N, int32_t I, int32_t O);
 
-namespace {
-int lin_grid(int N) {
-    const int groups = ((N + 15) / 16 + fc::kLinWaves - 1) / fc::kLinWaves;
-    return groups < 4 * fc::num_cus() ? groups : 4 * fc::num_cus();
+namespace fc {
+static int lin_grid(int N) {
+    const int groups = ((N + 15) / 16 + kLinWaves - 1) / kLinWaves;
+    return groups < 4 * num_cus() ? groups : 4 * num_cus();
 }
-int lin_gw_groups(int N) {
+static int lin_gw_groups(int N) {
     const int nblocks = (N + 15) / 16;
-    return nblocks < fc::kLinGwGroups ? nblocks : fc::kLinGwGroups;
+    return nblocks < kLinGwGroups ? nblocks : kLinGwGroups;
 }
-}  // namespace
+
+int tangent_lin_backward_impl(const float* x, const float* gy, const float* re_w, const float* im_w, float* gx, const float* gx_addend,
+                              float* g_re, float* g_im, void* workspace, size_t workspace_bytes, int N, int I, int O, hipStream_t s) {
+    if (!x || !gy || !re_w || !im_w || !gx || !g_re || !g_im || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < fc_tangent_lin_backward_workspace_bytes(N, I, O)) return FC_ERR_WORKSPACE;
+    const size_t lds = 2 * (size_t)lin_plane_floats(I, O) * sizeof(float);
+    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tangent_lin_kernel<true>, dim3(lin_grid(N)), dim3(kLinThreads), lds, s,
+                       reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx),
+                       reinterpret_cast<const float2*>(gx_addend), N, O, I, I);
+    float2* part = reinterpret_cast<float2*>(workspace);
+    const int ng = lin_gw_groups(N);
+    const int pairs = ((O + 15) / 16) * ((I + 15) / 16);
+    const int per_group = pairs < kLinGwPairs ? pairs : kLinGwPairs;
+    hipLaunchKernelGGL(tangent_lin_gw_kernel, dim3(ng, (pairs + per_group - 1) / per_group), dim3(per_group * kWave), 0, s,
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), part, N, I, O);
+    hipLaunchKernelGGL(tangent_lin_gw_reduce_kernel, dim3((O * I + 63) / 64), dim3(256), 0, s, part, g_re, g_im, ng,
+                       O * I);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+}  // namespace fc
+
+extern "C" {
 
 int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w, float* y, int32_t N, int32_t I,
                            int32_t O, void* stream) {
     if (!x || !re_w || !im_w || !y || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
     const size_t lds = 2 * (size_t)fc::lin_plane_floats(O, I) * sizeof(float);
     if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(lin_grid(N)), dim3(fc::kLinThreads), lds,
+    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(fc::lin_grid(N)), dim3(fc::kLinThreads), lds,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w,
-                       reinterpret_cast<float2*>(y), N, I, O, I);
+                       reinterpret_cast<float2*>(y), (const float2*)nullptr, N, I, O, I);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -334,22 +366,8 @@ size_t fc_tangent_lin_backward_workspace_bytes(int32_t N, int32_t I, int32_t O) 
 int fc_tangent_lin_backward(const float* x, const float* gy, const float* re_w, const float* im_w, float* gx,
                             float* g_re, float* g_im, void* workspace, size_t workspace_bytes, int32_t N, int32_t I,
                             int32_t O, void* stream) {
-    if (!x || !gy || !re_w || !im_w || !gx || !g_re || !g_im || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
-    if (!workspace || workspace_bytes < fc_tangent_lin_backward_workspace_bytes(N, I, O)) return FC_ERR_WORKSPACE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = 2 * (size_t)fc::lin_plane_floats(I, O) * sizeof(float);
-    if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<true>, dim3(lin_grid(N)), dim3(fc::kLinThreads), lds, s,
-                       reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx), N, O, I, I);
-    float2* part = reinterpret_cast<float2*>(workspace);
-    const int ng = lin_gw_groups(N);
-    const int pairs = ((O + 15) / 16) * ((I + 15) / 16);
-    const int per_group = pairs < fc::kLinGwPairs ? pairs : fc::kLinGwPairs;
-    hipLaunchKernelGGL(fc::tangent_lin_gw_kernel, dim3(ng, (pairs + per_group - 1) / per_group), dim3(per_group * fc::kWave), 0, s,
-                       reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(gy), part, N, I, O);
-    hipLaunchKernelGGL(fc::tangent_lin_gw_reduce_kernel, dim3((O * I + 63) / 64), dim3(256), 0, s, part, g_re, g_im, ng,
-                       O * I);
-    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+    return fc::tangent_lin_backward_impl(x, gy, re_w, im_w, gx, nullptr, g_re, g_im, workspace, workspace_bytes, N, I, O,
+                                         static_cast<hipStream_t>(stream));
 }
 
 int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32_t N, int32_t C, void* stream) {

@@ -73,6 +73,11 @@ def _require_device(t, what):
                            'there is no CPU fallback')
 
 
+def on_device(t):
+    """True for tensors the kernels can take (a ROCm device tensor)"""
+    return t.is_cuda
+
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _cur_device = getattr(torch._C, '_cuda_getDevice', None)
 

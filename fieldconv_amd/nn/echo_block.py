@@ -1,6 +1,7 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as _fn
 from ..utils.field import softAbs
 from .echo import ECHO
 from .field_conv import FieldConv
@@ -40,8 +41,15 @@ class ECHOBlock(nn.Module):
             raise ValueError('ECHOBlock requires n_des <= in_channels (reference nn/echo_block.py:57,93)')
         # reference behaviour: bias[0, channel index] is gathered per entry, so only the first n_des biases are ever used;
         # the modReLU runs in the convolution's epilogue
-        h = self.conv.forward_act(x, supp_edges, supp_sten, bias[:, : self.n_des])
-        d = self.echo(h, supp_edges, ln, wxp)
+        d = None
+        if _fn.on_device(x) and supp_sten.dim() == 3 and supp_sten.shape[1] == self.conv.R and supp_sten.shape[2] == 2 * self.conv.B + 1:
+            # convolution + modReLU + descriptors as one autograd node and one native call per pass (csrc/fc_blocks.hip)
+            from ..blocks import echo_block_descriptors
+            from ..graph import get_graph
+            d = echo_block_descriptors(self, x, get_graph(supp_edges, supp_sten, x.shape[0]), ln, wxp)
+        if d is None:
+            h = self.conv.forward_act(x, supp_edges, supp_sten, bias[:, : self.n_des])
+            d = self.echo(h, supp_edges, ln, wxp)
         d = d.reshape(d.shape[0], -1)
         d = F.relu(self.lin1(d))
         d = F.relu(self.lin2(d))

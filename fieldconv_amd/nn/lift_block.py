@@ -13,4 +13,8 @@ class LiftBlock(nn.Module):
         self.nonlin = TangentNonLin(out_channels)
 
     def forward(self, x, supp_edges, lift_sten):
+        from ..blocks import lift_block            # one autograd node, one native call per pass (csrc/fc_blocks.hip)
+        out = lift_block(self, x, supp_edges, lift_sten)
+        if out is not None:
+            return out
         return self.nonlin(self.field(x, supp_edges, lift_sten))

@@ -325,6 +325,91 @@ int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, con
                             float* g_zonal_mag, float* g_phase, void* workspace, size_t workspace_bytes, int32_t N,
                             int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride, int32_t ftype, void* stream);
 
+/* ---- whole blocks from ONE call per pass ---------------------------------------------------------------- *
+ * The reference's networks are built from three blocks -- FCResNetBlock (nn/fc_resnet_block.py:65-88), ECHOBlock
+ * (nn/echo_block.py:73-103) and LiftBlock (nn/lift_block.py:35-55) -- and train with batch size 1 on a different ~1k-vertex mesh every
+ * step (segmentation.ipynb:120,137): a binding that crosses into the library once per KERNEL spends more host time per block than the
+ * GPU needs to run it.  The entry points below enqueue a whole block pass -- filter assembly, convolutions with their fused
+ * residual / modReLU epilogues, the TangentLin residual, the descriptor splat, and in the backward pass the complete VJP chain with
+ * every parameter gradient -- from one foreign call, with caller-owned buffers only:
+ *   saved      what the backward pass needs from the forward pass (pre-activations, activations, backward filter images, ...):
+ *              fc_*_saved_bytes() bytes, 256-byte aligned, written by *_forward, read by *_backward, untouched in between
+ *   workspace  scratch of one call: fc_*_workspace_bytes(..., backward) bytes, 256-byte aligned
+ * Same kernels and the same results, bit for bit, as the per-operator calls above in the order the reference applies them. */
+typedef struct fc_mesh {           /* one mesh's support graph as the convolutions consume it */
+    int32_t N, E, R, B;            /* vertices, support edges, n_rings, band_limit of the stencil */
+    int32_t kind;                  /* 0 dense stencil rows, 1 factored records, 2 geometric forward records (factored backward) */
+    const fc_csr* by_target;       /* as for fc_forward* (nbr also read by the ECHO / lift blocks) */
+    const fc_csr* by_source;       /* as for fc_backward_data* */
+    const float* fwd;              /* sten_t / rec_t / geo_t, by kind, in by_target slot order */
+    const float* bwd;              /* sten_s (kind 0) or rec_s, in by_source slot order */
+} fc_mesh;
+
+/* FCResNetBlock: out = modReLU_2(res(x) + conv2(modReLU_1(conv1(x)))), reference nn/fc_resnet_block.py:84-88.
+ * conv1: (C_mid, C_in) filter, conv2: (C_out, C_mid); bias1 (C_mid), bias2 (C_out): the TangentNonLin biases; res_re / res_im
+ * (C_out, C_in): the TangentLin residual.  The g_* members receive the gradients in the backward call (conv*.g_*, g_bias*, g_res_*);
+ * the bias riders of conv1 / conv2 (fc_filter_params::bias_partials ...) are set by the library and ignored on entry. */
+typedef struct fc_resnet_block_params {
+    int32_t C_in, C_mid, C_out;
+    fc_filter_params conv1, conv2;
+    const float* bias1;
+    const float* bias2;
+    const float* res_re;
+    const float* res_im;
+    float* g_bias1;
+    float* g_bias2;
+    float* g_res_re;
+    float* g_res_im;
+} fc_resnet_block_params;
+size_t fc_resnet_block_saved_bytes(const fc_mesh* mesh, const fc_resnet_block_params* p);
+size_t fc_resnet_block_workspace_bytes(const fc_mesh* mesh, const fc_resnet_block_params* p, int32_t backward);
+/* x (N,C_in) c64 -> out (N,C_out) c64 */
+int fc_resnet_block_forward(const float* x, const fc_mesh* mesh, const fc_resnet_block_params* p, float* out, void* saved,
+                            size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* g_out (N,C_out) c64 -> gx (N,C_in) c64 and every parameter gradient of the block */
+int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* mesh, const fc_resnet_block_params* p, const void* saved,
+                             size_t saved_bytes, float* gx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The tangent-feature half of ECHOBlock: desc = ECHO(modReLU(conv(x))), reference nn/echo_block.py:93-94 (the MLP on the descriptors
+ * and the linear residual on |x|, :95-103, are the reference's own nn.Linear layers and stay with the caller).  conv: (n_des, C_in)
+ * filter; bias: the first n_des entries of the module's TangentNonLin bias (:57,93); ln_* / wxp_* (E) c64 in by_target / by_source slot
+ * order as for fc_echo_forward / fc_echo_backward; desc (N, n_des, fc_echo_hist_dim(n_bins)) f32; n_des <= fc_echo_channel_block(n_bins). */
+typedef struct fc_echo_block_params {
+    int32_t C_in, n_des, n_bins;
+    fc_filter_params conv;
+    const float* bias;
+    float* g_bias;
+} fc_echo_block_params;
+size_t fc_echo_block_saved_bytes(const fc_mesh* mesh, const fc_echo_block_params* p);
+size_t fc_echo_block_workspace_bytes(const fc_mesh* mesh, const fc_echo_block_params* p, int32_t backward);
+int fc_echo_block_forward(const float* x, const fc_mesh* mesh, const float* ln_t, const float* wxp_t, const fc_echo_block_params* p,
+                          float* desc, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int fc_echo_block_backward(const float* x, const float* g_desc, const fc_mesh* mesh, const float* ln_s, const float* wxp_s,
+                           const fc_echo_block_params* p, const void* saved, size_t saved_bytes, float* gx, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* LiftBlock: out = modReLU(TransField(x)), reference nn/lift_block.py:53-55.  x (N,C_in) f32, C_in <= 4, C_out <= 64; lift_sten /
+ * sten_stride / slot_to_edge_* as for fc_trans_field_forward / _backward (mesh: N, E, R and the two groupings with nbr; kind, fwd, bwd
+ * are not read); phase / g_phase for ftype != 0 only (phase: zeros otherwise). */
+typedef struct fc_lift_block_params {
+    int32_t C_in, C_out, ftype;
+    const float* zonal_ang;
+    const float* zonal_mag;
+    const float* phase;
+    const float* bias;
+    float* g_zonal_ang;
+    float* g_zonal_mag;
+    float* g_phase;
+    float* g_bias;
+} fc_lift_block_params;
+size_t fc_lift_block_saved_bytes(const fc_mesh* mesh, const fc_lift_block_params* p);
+size_t fc_lift_block_workspace_bytes(const fc_mesh* mesh, const fc_lift_block_params* p, int32_t backward);
+int fc_lift_block_forward(const float* x, const float* lift_sten, int32_t sten_stride, const fc_mesh* mesh, const int64_t* slot_to_edge_t,
+                          const fc_lift_block_params* p, float* out, void* saved, size_t saved_bytes, void* stream);
+int fc_lift_block_backward(const float* g_out, const float* lift_sten, int32_t sten_stride, const fc_mesh* mesh, const int64_t* slot_to_edge_s,
+                           const fc_lift_block_params* p, const void* saved, size_t saved_bytes, float* gx, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- support-graph build (what every FieldConv needs before its first launch on a mesh) ---------------------------- *
  * From the operator's own inputs (reference nn/field_conv.py:104-121): supp_edges (E,2) int64, col 0 = source, col 1 =
  * target; supp_sten (E,R,F) c64 contiguous, F = 2B+1 (NULL: edge grouping only, for the ECHO / TransField entry points)

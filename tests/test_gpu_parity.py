@@ -180,6 +180,12 @@ def test_echo_block_and_lift_block_golden(dev):
     params = dict(m.named_parameters())
     grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev), allow_unused=True)
     assert rel_err(H(grads[0]), c['gx']) < 2e-4          # histogram votes: piecewise-linear, fp32 floor/ceil sensitive
+    # all twelve parameter gradients of the block (convolution filter + phase, modReLU bias, the three MLP layers, the residual)
+    worst = {}
+    for (name, _), gval in zip(params.items(), grads[1:]):
+        assert gval is not None, name
+        worst[name] = rel_err(H(gval), c['g_' + name])
+    assert len(worst) == 12 and max(worst.values()) < 2e-4, worst
     for ft in (0, 1):
         c = load_golden('echo_lift.npz')[f'lift_block_t{ft}']
         m = load_params(LiftBlock(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ft), c).to(dev)
@@ -1116,6 +1122,65 @@ def test_conv_epilogue_fusion_matches_separate_operators(dev, monkeypatch, N, k)
         out[fused] = (y.detach(),) + torch.autograd.grad(y, [xd] + params, grad_outputs=gy)
     for a, b in zip(out[True], out[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('N,k,cin,cout,frontload,B', [(700, 14, 16, 24, False, 2), (9000, 8, 24, 16, True, 2), (200, 96, 48, 48, False, 2),
+                                                      (1024, 128, 48, 48, False, 2), (500, 20, 64, 64, False, 3), (300, 12, 8, 8, True, 1)])
+def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, N, k, cin, cout, frontload, B):
+    """FCResNetBlock / ECHOBlock / LiftBlock through ONE native call per pass (csrc/fc_blocks.hip: fc_resnet_block_*, fc_echo_block_*,
+    fc_lift_block_*; reference nn/fc_resnet_block.py:84-88, nn/echo_block.py:93-103, nn/lift_block.py:53-55) against the same modules
+    composed of per-operator autograd nodes (FIELDCONV_BLOCK_CALLS=0): the same kernels in the same order, so outputs and EVERY gradient
+    agree bit for bit -- frequency-major and ring-major (9000 vertices) forward kernels, the edge split of small meshes (200 / 1024
+    vertices with wide supports), band limits 1-3, both `frontload` settings."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
+    from fieldconv_amd.transforms import FCPrecomp
+    R = 6
+    data = sphere_support(N, k, seed=N).to(dev)
+    edges, sten, ln, wxp = FCPrecomp(B, R, data.epsilon)(data)
+    torch.manual_seed(N)
+    n_des = min(cin, 12 if B == 3 else cin)
+    mods = {'resnet': FCResNetBlock(cin, cout, band_limit=B, n_rings=R, frontload=frontload).to(dev),
+            'echo': ECHOBlock(cin, 7, n_des=n_des, n_bins=2 if B == 3 else 3, band_limit=B, n_rings=R).to(dev),
+            'lift': LiftBlock(3, cout, n_rings=R, ftype=1).to(dev)}
+    with torch.no_grad():
+        mods['resnet'].nonlin1.bias.uniform_(-0.4, 0.1)
+        mods['resnet'].nonlin2.bias.uniform_(-0.4, 0.1)
+        mods['echo'].nonlin.bias.uniform_(-0.4, 0.1)
+        mods['lift'].nonlin.bias.uniform_(-0.4, 0.1)
+    g = torch.Generator().manual_seed(N)
+    x = torch.complex(torch.randn(N, cin, generator=g), torch.randn(N, cin, generator=g))
+    x[torch.rand(N, cin, generator=g) < 0.02] = 0
+    pos = torch.randn(N, 3, generator=g)
+    inputs = {'resnet': lambda: (x.to(dev).requires_grad_(True), edges, sten),
+              'echo': lambda: (x.to(dev).requires_grad_(True), edges, sten, ln, wxp),
+              'lift': lambda: (pos.to(dev).requires_grad_(True), edges, sten[..., B:B + 2])}
+    node = {'resnet': '_ResnetBlockFn', 'echo': '_EchoBlockFn', 'lift': '_LiftBlockFn'}
+    for name, mod in mods.items():
+        params = list(mod.parameters())
+        out = {}
+        for native in (True, False):
+            monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '1' if native else '0')
+            args = inputs[name]()
+            y = mod(*args)
+            seen, todo, found = set(), [y.grad_fn], False
+            while todo:                         # the block-level node is (not) in the autograd graph
+                fn = todo.pop()
+                if fn is None or fn in seen:
+                    continue
+                seen.add(fn)
+                found = found or node[name] in type(fn).__name__
+                todo += [nf for nf, _ in fn.next_functions]
+            assert found == native, (name, native)
+            gen = torch.Generator().manual_seed(1)
+            gy = torch.randn(y.shape, generator=gen)
+            if y.is_complex():
+                gy = torch.complex(gy, torch.randn(y.shape, generator=gen))
+            out[native] = (y.detach(),) + torch.autograd.grad(y, [args[0]] + params, grad_outputs=gy.to(dev), allow_unused=True)
+        for a, b in zip(out[True], out[False]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), name
 
 
 # ------------------------------------------------------------------ double precision (the reference's modules run under .double())

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
-    assert _lib.load(path).fc_abi_version() == 8
+    assert _lib.load(path).fc_abi_version() == 9
 
 
 def test_supported_query_and_sizes_need_no_gpu():
@@ -399,3 +399,85 @@ def test_graph_views_keep_the_cached_graph_clean():
     assert get_graph(edges, bound, N) is view and tuple(bound.shape) == (E, R, F) and torch.equal(bound.materialize(), sten)
     own = SupportGraph(edges, sten, N)                   # a graph of one's own may be changed directly
     assert own.restrict_targets(8).n_targets == 8
+
+
+# ------------------------------------------------------------------ foreign calls per network step
+class _CountingLibrary:
+    """The real library with every ENQUEUEING entry point (the ones that take a stream) replaced by a recorder that returns
+    FC_OK: the host side of a network step -- module dispatch, autograd nodes, buffer carving, struct filling -- runs
+    unchanged on CPU tensors, nothing is launched, and every crossing into the library is counted.  Pure host queries
+    (sizes, fc_supported, ...) pass through to the real functions and are counted as well."""
+
+    def __init__(self, real, header):
+        self.real, self.calls = real, []
+        self.enqueue = set(re.findall(r'\b(fc_[a-z0-9_]+)\s*\([^;]*?void\*\s*stream\)', header, flags=re.S))
+
+    def __getattr__(self, name):
+        fn = getattr(self.real, name)
+        if name in self.enqueue:
+            def rec(*args):
+                self.calls.append(name)
+                return 0
+            return rec
+
+        def passthrough(*args):
+            self.calls.append(name)
+            return fn(*args)
+        return passthrough
+
+
+def test_config3_step_takes_at_most_40_foreign_calls(monkeypatch):
+    """BASELINE configs[2]'s network (LiftBlock, four FCResNetBlocks, ECHOBlock: nine convolutions; reference
+    segmentation.ipynb:196-236) forward + loss + backward: how often does the binding cross into the library?  One call per block and
+    pass = 12, where the per-operator path took ~80 (16 per FCResNetBlock).  The reference trains with batch size 1 on a different
+    ~1k-vertex mesh every step (segmentation.ipynb:120,137), so the host's per-step cost is what a training run sees."""
+    from fieldconv_amd import blocks, functional
+    header = open(os.path.join(ROOT, 'include', 'fieldconv_hip.h')).read()
+    counting = _CountingLibrary(_lib.load(), header)
+    assert {'fc_resnet_block_forward', 'fc_resnet_block_backward', 'fc_forward_params', 'fc_backward_all'} <= counting.enqueue
+    assert 'fc_supported' not in counting.enqueue and 'fc_resnet_block_saved_bytes' not in counting.enqueue
+    monkeypatch.setattr(_lib, 'load', lambda path=None: counting)
+    monkeypatch.setattr(functional, 'on_device', lambda t: True)
+    monkeypatch.setattr(functional, '_on', lambda device: functional._NO_GUARD)
+    monkeypatch.setattr(functional, '_stream', lambda: ctypes.c_void_p(0))
+    for name in ('FIELDCONV_BLOCK_CALLS', 'FIELDCONV_NO_FUSED_EPILOGUE', 'FIELDCONV_NO_EDGE_SPLIT'):
+        monkeypatch.delenv(name, raising=False)
+
+    from fieldconv_amd.data import sphere_support
+    N, k, nf, B, R, n_cls = 300, 24, 48, 2, 6, 8
+    data = sphere_support(N, k)
+    edges, sten, ln, wxp = FCPrecomp(B, R, data.epsilon)(data)
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict(dict(
+        lift=LiftBlock(3, nf, n_rings=R, ftype=1), r1=FCResNetBlock(nf, nf, band_limit=B, n_rings=R),
+        r2=FCResNetBlock(nf, nf, band_limit=B, n_rings=R), r3=FCResNetBlock(nf, nf, band_limit=B, n_rings=R),
+        r4=FCResNetBlock(nf, nf, band_limit=B, n_rings=R), echo=ECHOBlock(nf, n_cls, n_des=48, n_bins=3, band_limit=B, n_rings=R)))
+    params = list(net.parameters())
+    pos = torch.randn(N, 3)
+    labels = torch.randint(0, n_cls, (N,))
+
+    def step():
+        x = net['lift'](pos, edges, sten[..., B:B + 2])
+        for name in ('r1', 'r2', 'r3', 'r4'):
+            x = net[name](x, edges, sten)
+        logits = net['echo'](x, edges, sten, ln, wxp)
+        loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), labels)
+        return torch.autograd.grad(loss, params, allow_unused=True)
+
+    step()                                   # first step on a mesh: plans, sizes and slot orders are computed and cached
+    first = list(counting.calls)
+    counting.calls.clear()
+    grads = step()
+    steady = list(counting.calls)
+    assert all(g is not None for g in grads)
+    enq = [c for c in steady if c in counting.enqueue]
+    assert sorted(enq) == sorted(['fc_lift_block_forward', 'fc_lift_block_backward', 'fc_echo_block_forward', 'fc_echo_block_backward']
+                                 + ['fc_resnet_block_forward', 'fc_resnet_block_backward'] * 4), enq
+    assert len(steady) <= 40, (len(steady), steady)
+    assert len(first) <= 80, (len(first), first)
+    # the per-operator composition of the same step, for the record: several times as many crossings
+    monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '0')
+    monkeypatch.setattr(functional, '_require_device', lambda t, what: None)
+    counting.calls.clear()
+    step()
+    assert len(counting.calls) > 2 * len(steady), (len(counting.calls), len(steady))
