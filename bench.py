@@ -1072,6 +1072,9 @@ def main():
 
     out = {'dp': run_dp, 'net': run_net, 'layer': run_layer}[args.mode](args, world, rank, dev, use_dist, backend)
     if rank == 0:
+        from fieldconv_amd import _lib
+        out['config']['library'] = ('development build (-DFC_DEV_SWITCHES: honours the FC_* switches in config.env)'
+                                    if _lib.load().fc_dev_switches() else 'product build (reads no environment variable)')
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -8,8 +8,10 @@ benchmark the default), and (b) tests/test_host_logic.py can check that no switc
 import os
 
 SWITCHES = {
-    # ---- read by libfieldconv_hip.so (once per process)
+    # ---- read by the binding and handed to the library explicitly (fc_set_mfma_mode)
     'FC_MFMA': 'f32: fp32-MFMA contractions throughout; f16: single halves (reduced precision); default: split halves',
+    # ---- read by libfieldconv_hip_dev.so ONLY (the product library reads no variable; fieldconv_amd/_lib.py loads the development build
+    #      when one of these is set): once per process
     'FC_RING': '0: frequency-major forward kernels for every mesh size; 2: ring-major ones for every size',
     'FC_GROUP_SPLIT': '0: the backward data kernel never runs the two frequency groups of a tile as separate work items; 2 (development): wherever legal',
     'FC_RING_COMPACT': '0: no compact LDS plans (aliased partials, half-size record chunks) for the ring-major forward kernel',
@@ -50,6 +52,10 @@ TEST_SWITCHES = {
     'FC_DIST_PLAN_ONLY': '1: the distributed test worker checks partition and halo plan at config-4 size only',
     'FC_DIST_CONFIG4': '1: the distributed GPU test worker runs config 4\'s per-rank size (20 000 owned vertices per rank)',
 }
+
+# the switches that exist in the development build of the library only (csrc: dev_env under -DFC_DEV_SWITCHES)
+LIBRARY_SWITCHES = ('FC_RING', 'FC_GROUP_SPLIT', 'FC_RING_COMPACT', 'FC_RING_HALVES', 'FC_HALF_TILES', 'FC_FILTER2', 'FC_SPLIT_FINISH',
+                    'FC_EDGE_PARTS_MAX', 'FC_ECHO_WPV', 'FC_STAMP_KERNEL', 'FC_DEBUG', 'FC_DEBUG_BWD')
 
 PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')
 WRONG_RESULTS = ('FC_DEBUG', 'FC_DEBUG_BWD')

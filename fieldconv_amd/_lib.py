@@ -6,7 +6,7 @@ raises.  Nothing under oracle/ is ever imported from here.
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import DEV_LIB_PATH, LIB_PATH
 
 _c_int32 = ctypes.c_int32
 _vp = ctypes.c_void_p
@@ -66,6 +66,8 @@ _FP = ctypes.POINTER(FcFilterParams)
 # name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
 SIGNATURES = {
     'fc_abi_version': (ctypes.c_int, []),
+    'fc_set_mfma_mode': (ctypes.c_int, [_c_int32]),
+    'fc_dev_switches': (ctypes.c_int, []),
     'fc_debug_stamp_buffer': (None, [_vp]),
     'fc_status_string': (ctypes.c_char_p, [ctypes.c_int]),
     'fc_supported': (ctypes.c_int, [_DP]),
@@ -145,12 +147,33 @@ class FieldConvNativeError(RuntimeError):
     pass
 
 
+MFMA_MODES = {'': 0, 'split': 0, 'f32': 1, 'f16': 2}       # FC_MFMA -> fc_mfma_mode
+
+
+def _pick_library():
+    """FIELDCONV_HIP_LIB if given; the development build (-DFC_DEV_SWITCHES) when one of the library's development switches is set
+    in the environment -- the product library does not read any of them -- else the product library."""
+    explicit = os.environ.get('FIELDCONV_HIP_LIB')
+    if explicit:
+        return explicit
+    from ._env import LIBRARY_SWITCHES
+    wanted = sorted(k for k in LIBRARY_SWITCHES if k in os.environ)
+    if wanted:
+        if not os.path.exists(DEV_LIB_PATH):
+            raise FieldConvNativeError(
+                f'{", ".join(wanted)} set, but the development library {DEV_LIB_PATH} is not built: the product library has no '
+                'environment switches; build it with `python -m fieldconv_amd.build --dev` (fieldconv_amd.build.build_dev())')
+        return DEV_LIB_PATH
+    return LIB_PATH
+
+
 def load(path=None):
-    """dlopen the library and bind every entry point; raises if it is not built."""
+    """dlopen the library and bind every entry point; raises if it is not built.  The arithmetic mode is passed on explicitly
+    (FC_MFMA -> fc_set_mfma_mode): the library itself reads no environment variable."""
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    path = path or os.environ.get('FIELDCONV_HIP_LIB', LIB_PATH)
+    path = path or _pick_library()
     if not os.path.exists(path):
         raise FieldConvNativeError(
             f'{path} not found: build it with `python -m fieldconv_amd.build` '
@@ -160,6 +183,11 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
+    mode = os.environ.get('FC_MFMA', '')
+    if mode not in MFMA_MODES:
+        raise FieldConvNativeError(f"FC_MFMA={mode!r}: expected one of 'split' (default), 'f32', 'f16'")
+    if lib.fc_set_mfma_mode(MFMA_MODES[mode]) != 0:
+        raise FieldConvNativeError('fc_set_mfma_mode failed')
     _LIB = lib
     return lib
 

@@ -39,6 +39,11 @@ def _source_digest():
 
 
 DIGEST_PATH = LIB_PATH + '.src.sha256'
+# The same sources compiled with -DFC_DEV_SWITCHES: the FC_* development variables (fieldconv_amd/_env.py: LIBRARY_SWITCHES) exist in
+# this library only.  The binding loads it instead of the product library when one of them is set (fieldconv_amd/_lib.py).
+DEV_LIB_PATH = os.path.join(OUT_DIR, 'libfieldconv_hip_dev.so')
+DEV_DIGEST_PATH = DEV_LIB_PATH + '.src.sha256'
+DEV_FLAGS = ['-DFC_DEV_SWITCHES']
 
 
 def needs_build():
@@ -48,6 +53,24 @@ def needs_build():
         return True
     with open(DIGEST_PATH) as f:
         return f.read().strip() != _source_digest()
+
+
+def dev_needs_build():
+    if not os.path.exists(DEV_LIB_PATH) or not os.path.exists(DEV_DIGEST_PATH):
+        return True
+    with open(DEV_DIGEST_PATH) as f:
+        return f.read().strip() != _source_digest()
+
+
+def build_dev(force=False, verbose=False):
+    """libfieldconv_hip_dev.so: the product sources with the development switches compiled in (tests/test_gpu_modes.py, tools/)."""
+    if not force and not dev_needs_build():
+        return DEV_LIB_PATH
+    path = build_native(force=True, verbose=verbose, _variant=(DEV_LIB_PATH, list(DEV_FLAGS)))
+    with open(DEV_DIGEST_PATH + '.tmp.%d' % os.getpid(), 'w') as f:
+        f.write(_source_digest())
+    os.replace(DEV_DIGEST_PATH + '.tmp.%d' % os.getpid(), DEV_DIGEST_PATH)
+    return path
 
 
 def under_profiler():
@@ -111,3 +134,5 @@ def build_native(force=False, verbose=False, _variant=None):
 
 if __name__ == '__main__':
     print(build_native(force='--force' in sys.argv, verbose=True))
+    if '--dev' in sys.argv:
+        print(build_dev(force='--force' in sys.argv, verbose=True))

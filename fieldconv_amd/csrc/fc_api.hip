@@ -45,6 +45,14 @@ void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<uns
 
 int fc_abi_version(void) { return 9; }
 
+int fc_dev_switches(void) { return fc::kDevSwitches ? 1 : 0; }
+
+int fc_set_mfma_mode(int32_t mode) {
+    if (mode < FC_MFMA_SPLIT_F16 || mode > FC_MFMA_F16) return FC_ERR_BAD_ARGUMENT;
+    fc::set_split_mode(mode == FC_MFMA_F32 ? 0 : mode == FC_MFMA_F16 ? 1 : 2);
+    return FC_OK;
+}
+
 const char* fc_status_string(int s) {
     switch (s) {
         case FC_OK: return "ok";
@@ -209,7 +217,7 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
         if (rc != FC_OK) return rc;
     }
     // the partials' fixed-order sum and the parameter-gradient chain in ONE launch (FC_SPLIT_FINISH=1: the two kernels)
-    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
+    static const bool split_finish = [] { const char* e = fc::dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     if (split_finish) {
         int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
         if (rc != FC_OK) return rc;
@@ -227,7 +235,7 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     if (!gw_eff) return FC_ERR_BAD_ARGUMENT;
     // With parameters the pass ends in ONE launch (fc_backward_finish_params' kernel): when tiles are shared, the sum of the data kernel's
     // partial gx arrays rides there too instead of a launch of its own between the kernels (nobody reads gx before this call returns)
-    static const bool split_finish = [] { const char* e = getenv("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
+    static const bool split_finish = [] { const char* e = fc::dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     const bool defer = params != nullptr && !split_finish;
     int rc = check_bwd(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;

@@ -590,7 +590,7 @@ size_t backward_workspace_bytes(const fc_dims* d) {
 template <int T>
 static int launch_backward_filter(const float2* x, const float* hdump, float2* gwp, const BwdArgs& a, const BwdPlan& p,
                                   const fc_dims* d, hipStream_t stream) {
-    static const bool half2 = !(getenv("FC_FILTER2") && atoi(getenv("FC_FILTER2")) == 0);      // FC_FILTER2=0: the LDS-staged kernel (development)
+    static const bool half2 = !(dev_env("FC_FILTER2") && atoi(dev_env("FC_FILTER2")) == 0);      // FC_FILTER2=0: the LDS-staged kernel (development)
     static bool ok_half2[kMaxDevices] = {}, ok_half[kMaxDevices] = {}, ok_f32[kMaxDevices] = {};      // per T (this function is a template)
     if (p.fhalf && half2) {
         const size_t lds2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
@@ -640,7 +640,7 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
 void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
     const BwdPlan p = plan_backward(d, split_mode());
     const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
-    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
     snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d%s; %s; %s", records ? "records" : "dense rows", mode, p.ntiles,
              1 << p.parts_log2, p.gsplit ? " (the two frequency groups of a tile as separate work items)" : "",
              p.fhalf ? (staged ? "fc_backward_filter_half_kernel (LDS-staged slabs)" : "fc_backward_filter_half2_kernel (register-fed rows)")

@@ -508,7 +508,7 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     p.KP = p.g.KP;
     p.parts_log2 = edge_parts_log2(d);
     // frequency groups as work items (BwdArgs::gsplit).  FC_GROUP_SPLIT=0 switches them off (2, development: wherever legal).
-    static const int gsw = [] { const char* e = getenv("FC_GROUP_SPLIT"); return e ? atoi(e) : 1; }();
+    static const int gsw = [] { const char* e = dev_env("FC_GROUP_SPLIT"); return e ? atoi(e) : 1; }();
     const int native_groups = (p.F * d->R + 31) / 32;
     const bool groups = native_groups == 2 || (native_groups == 1 && bwd_forced_groups(d->R, d->B) && halves != 0);
     p.gsplit = 0;
@@ -521,7 +521,7 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
         // Half tiles in the last round (tile_items) pay in the forward kernel only: at 4 999 vertices, C = 64, B = 3 the data
         // kernel gains 3.6 us and the filter kernel loses 4.9 (57 more, half-empty slabs to stream): FC_HALF_TILES=2 turns them
         // on here as well.
-        static const bool bwd_halves = getenv("FC_HALF_TILES") && atoi(getenv("FC_HALF_TILES")) == 2;
+        static const bool bwd_halves = dev_env("FC_HALF_TILES") && atoi(dev_env("FC_HALF_TILES")) == 2;
         const TileItems items = tile_items(nt, bwd_halves ? num_cus() : 0, p.parts_log2);
         p.ntiles = items.nv_total;                                             // work items: one set of H slabs each
         p.nv_full = items.nv_full;
@@ -550,7 +550,7 @@ inline BwdPlan plan_backward(const fc_dims* d, int halves) {
     const int stride_tails = round_up(p.slab_floats + 2 * kTile + 2 * p.IP, 256);
     const size_t lds_half = (size_t)(2 * stride_tails + (kTile * filter_image_stride(p.KP) + 6 * p.IP * kXbStride) / 2 + 4) * sizeof(float);
     // (the register-fed half2 kernel needs two images and no fp32 slab in LDS; FC_FILTER2=0 selects the LDS-staged one)
-    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
     const size_t lds_half2 = (size_t)(2 * kTile * filter_image_stride(p.KP) + 2 * 6 * p.IP * kXbStride + 8) * sizeof(_Float16) + 16;
     p.fhalf = (halves != 0 && p.IP <= 64 && p.KP <= 512 && (staged ? lds_half : lds_half2) <= kMaxLds) ? 1 : 0;
     p.slab_stride = p.fhalf ? stride_tails : round_up(p.slab_floats, 256);
@@ -581,13 +581,13 @@ inline BwdArgs make_args(const fc_dims* d, const BwdPlan& p) {
     a.slab_floats = p.slab_floats;
     a.slab_stride = p.slab_stride;
     a.tails = p.fhalf;
-    static const bool staged = [] { const char* e = getenv("FC_FILTER2"); return e && atoi(e) == 0; }();
+    static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
     a.dump_halves = (p.fhalf && p.gd.split == 2 && !staged) ? 1 : 0;
     a.nt_dump = p.hdump_bytes > ((size_t)192 << 20) ? 1 : 0;
-    static const int dbg = [] { const char* e = getenv("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
-    static const int who = [] { const char* e = getenv("FC_STAMP_KERNEL"); return (e && e[0] == 'd') ? 1 : 2; }();
+    static const int who = [] { const char* e = dev_env("FC_STAMP_KERNEL"); return (e && e[0] == 'd') ? 1 : 2; }();
     a.stamp_who = who;
     return a;
 }

@@ -11,9 +11,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace fc {
+
+// Development switches (the FC_* variables of fieldconv_amd/_env.py: older kernel families for A/B runs, phase skipping, stamps) exist
+// only in a library compiled with -DFC_DEV_SWITCHES (fieldconv_amd.build.build_dev: libfieldconv_hip_dev.so).  The product library never
+// reads the environment -- a stray variable in a C-ABI consumer's process cannot change which kernels run -- and dev_env() folds to
+// "not set", so every switch takes its default at compile time.  The arithmetic mode (FC_MFMA) is an explicit call: fc_set_mfma_mode.
+#ifdef FC_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return getenv(name); }
+constexpr bool kDevSwitches = true;
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+constexpr bool kDevSwitches = false;
+#endif
 
 constexpr int kWave = 64;
 constexpr int kTile = 16;        // vertices per tile == MFMA N

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
 
 // wavefronts per vertex: spread large supports over the workgroup when the mesh alone cannot fill the chip
 static int echo_waves_per_vertex(int N, int E) {
-    static const int forced = [] { const char* e = getenv("FC_ECHO_WPV"); return e ? atoi(e) : 0; }();       // development, read once
+    static const int forced = [] { const char* e = dev_env("FC_ECHO_WPV"); return e ? atoi(e) : 0; }();       // development, read once
     if (forced) return forced;
     const long deg = N > 0 ? (long)E / N : 0;
     if (deg >= 64 && N < 65536) return 4;

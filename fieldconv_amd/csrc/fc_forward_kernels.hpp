@@ -536,7 +536,7 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     a.part_stride = (uint32_t)forward_part_stride(d);
     a.epi = make_epi(epi);
     a.wpk_bytes = (uint32_t)(packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, a.g.split) * sizeof(float));
-    static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();       // read once per process
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG"); return e ? atoi(e) : 0; }();       // read once per process
     a.dbg = dbg;
     a.ring_chunks = factored ? kRingChunks : 0;
     const size_t ring = (size_t)kWaves * a.ring_chunks * 1024;

@@ -9,7 +9,7 @@ namespace fc {
 // two-halves mode; FC_RING=0 keeps the frequency-major ones (one 16-wavefront workgroup per CU; also what FC_MFMA=f32 / f16
 // run).  Read once per process.  Config 2 on MI355X: 138 us against 150 us.
 bool ring_enabled() {
-    static const bool on = [] { const char* e = getenv("FC_RING"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = dev_env("FC_RING"); return !(e && atoi(e) == 0); }();
     return on && split_mode() == 2;
 }
 
@@ -19,7 +19,7 @@ bool ring_enabled() {
 // 66 us between 4097 and 8192 vertices, 91 against 94 up to 12288 (tools/ring_threshold.py).  FC_RING=2 forces the
 // ring-major kernels for any size (tests).
 bool forward_ring_fits(const fc_dims* d) {
-    static const bool force = [] { const char* e = getenv("FC_RING"); return e && atoi(e) == 2; }();
+    static const bool force = [] { const char* e = dev_env("FC_RING"); return e && atoi(e) == 2; }();
     if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
     return force || (d->N + kTile - 1) / kTile > num_cus();
 }
@@ -69,7 +69,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.alias_part = p.alias;
     a.wpk_bytes = (uint32_t)(packed_ring_image_floats(d->O, F, d->I, d->R, p.g.split) * sizeof(float));
     a.slab_bytes_w = (uint32_t)(2 * p.g.split * p.g.MP * p.g.KP * 2);
-    static const int dbg = [] { const char* e = getenv("FC_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
     const int nvt = a.ntiles << a.parts_log2;
@@ -78,7 +78,7 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     const int rem = nvt % grid;
     a.nv_full = nvt;
     a.nv_total = nvt;
-    static const bool halves = !(getenv("FC_RING_HALVES") && atoi(getenv("FC_RING_HALVES")) == 0);
+    static const bool halves = !(dev_env("FC_RING_HALVES") && atoi(dev_env("FC_RING_HALVES")) == 0);
     if (halves && a.parts_log2 == 0 && rem > 0 && 2 * rem <= grid) {
         a.nv_full = nvt - rem;
         a.nv_total = a.nv_full + 2 * rem;

@@ -460,7 +460,7 @@ inline RingPlan plan_ring(int M, int F, int channels, int halves) {
     p.ok = false;
     p.nr = 0; p.lds = 0; p.logh = 0; p.alias = 0;
     if (halves != 2 || p.g.NMT > kDuoWaves) return p;
-    static const bool compact = !(getenv("FC_RING_COMPACT") && atoi(getenv("FC_RING_COMPACT")) == 0);      // 0: round-3 plans only
+    static const bool compact = !(dev_env("FC_RING_COMPACT") && atoi(dev_env("FC_RING_COMPACT")) == 0);      // 0: round-3 plans only
     const int tries[4][3] = {{4, 0, 0}, {2, 0, 0}, {2, 0, 1}, {2, 1, 1}};       // nr, logh, alias
     for (int t = 0; t < (compact ? 4 : 2); ++t) {
         if (tries[t][1] && F < 5) continue;

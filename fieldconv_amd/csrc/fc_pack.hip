@@ -222,15 +222,11 @@ int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, c
     return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, records, stream, o0, i0, Ifull);
 }
 
-int split_mode() {
-    static const int mode = [] {
-        const char* e = getenv("FC_MFMA");
-        if (e && e[0] == 'f' && e[1] == '3' && e[2] == '2') return 0;
-        if (e && e[0] == 'f' && e[1] == '1' && e[2] == '6') return 1;
-        return 2;
-    }();
-    return mode;
-}
+// Arithmetic mode of the contractions: 2 = split halves (default, fp32-grade), 0 = fp32 MFMA, 1 = single f16 halves (reduced
+// precision).  Process-wide and EXPLICIT (fc_set_mfma_mode); the library does not read FC_MFMA from the environment.
+static int g_split_mode = 2;
+int split_mode() { return g_split_mode; }
+void set_split_mode(int mode) { g_split_mode = mode; }
 
 // One thread per (o, i, r): reads gW_eff[o,i,r,:] (F complex) and writes the parameter gradients of
 // its ring; the phase gradient sums over the rings of (o,i) through LDS in a fixed order.

@@ -63,6 +63,7 @@ __host__ __device__ inline int slab_floats(const MmaGeom& g) { return g.split ? 
 // Halves per operand the library runs with: 2 (split mode, default), 0 with FC_MFMA=f32 (fp32 MFMA),
 // 1 with FC_MFMA=f16 (reduced precision).
 int split_mode();
+void set_split_mode(int mode);
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -388,7 +389,7 @@ struct TileItems {
     int nv_full, nv_total;
 };
 inline TileItems tile_items(int ntiles, int grid, int parts_log2) {
-    static const bool on = !(getenv("FC_HALF_TILES") && atoi(getenv("FC_HALF_TILES")) == 0);
+    static const bool on = !(dev_env("FC_HALF_TILES") && atoi(dev_env("FC_HALF_TILES")) == 0);
     TileItems t;
     t.nv_full = t.nv_total = ntiles << parts_log2;
     if (!on || parts_log2 != 0 || grid <= 0) return t;
@@ -413,7 +414,7 @@ inline int edge_parts_log2(const fc_dims* d) {
     if (d->N <= 0) return 0;
     const int ntiles = (d->N + kTile - 1) / kTile;
     const long deg = (long)d->E / d->N;
-    static const int cap = [] { const char* e = getenv("FC_EDGE_PARTS_MAX"); return e ? atoi(e) : 3; }();       // read once per process
+    static const int cap = [] { const char* e = dev_env("FC_EDGE_PARTS_MAX"); return e ? atoi(e) : 3; }();       // read once per process
     int pl = 0;
     while (pl < cap && (ntiles << (pl + 1)) <= num_cus() && (deg >> (pl + 1)) >= 8) ++pl;
     return pl;

@@ -54,6 +54,17 @@ typedef struct fc_csr {
 } fc_csr;
 
 int fc_abi_version(void);
+/* Arithmetic of the three contractions (forward, input gradient, filter gradient).  Process-wide, set EXPLICITLY -- the library reads no
+ * environment variable: FC_MFMA_SPLIT_F16 (default) carries every operand as two f16 halves with power-of-two row scales on
+ * v_mfma_f32_16x16x32_f16, fp32 accumulation (fp32-grade: 2^-22 of the row maximum); FC_MFMA_F32 runs v_mfma_f32_16x16x4_f32 on fp32
+ * operands throughout; FC_MFMA_F16 drops the low halves (reduced precision, ~3e-4).  Packed filter images, workspaces and kernels all
+ * follow the mode: set it before the first size query / packing call and do not change it between a packing call and the launches that use
+ * its images. */
+typedef enum fc_mfma_mode { FC_MFMA_SPLIT_F16 = 0, FC_MFMA_F32 = 1, FC_MFMA_F16 = 2 } fc_mfma_mode;
+int fc_set_mfma_mode(int32_t mode);
+/* 1 when this library was compiled with -DFC_DEV_SWITCHES (libfieldconv_hip_dev.so: the FC_* development variables of
+ * fieldconv_amd/_env.py select older kernel families, skip phases, write stamps); the product library returns 0 and reads no variable. */
+int fc_dev_switches(void);
 /* Development only (tools/stamps.py): a device buffer of 16 x 256 uint64 that the record-driven kernels fill with in-kernel
  * time stamps of workgroup 0 (label << 56 | s_memtime), or NULL to switch the stamps off (the default).  Process-wide. */
 void fc_debug_stamp_buffer(void* device_buffer);
@@ -66,8 +77,8 @@ const char* fc_status_string(int status);
  * (fc_forward_wide / fc_backward_wide below). */
 int fc_supported(const fc_dims* dims);
 /* Which kernels a forward + backward pass with these dims launches in this process, as one line of text (kernel family,
- * record kind, MFMA mode, tile counts): the library picks them from the dims, the device's CU count and the development
- * switches it read from the environment, and a benchmark line should say what it timed.  kind: 0 dense rows, 1 factored
+ * record kind, MFMA mode, tile counts): the library picks them from the dims, the device's CU count, the MFMA mode and -- in the
+ * development build only -- its switches, and a benchmark line should say what it timed.  kind: 0 dense rows, 1 factored
  * records, 2 geometric records in the forward pass (factored ones in the backward pass).  No GPU work. */
 int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t buffer_bytes);
 
@@ -79,7 +90,7 @@ int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t 
  *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves,
  *   forward rows o, k = r*ceil8(I) + i;  backward rows i, k = r*ceil8(O) + o, conjugated;
  *   OP = ceil16(rows), KP = ceil32(R * ceil8(channels)).
- * With FC_MFMA=f32 in the environment: F x {re,im} x OP x ceil16(R*channels) floats.
+ * In FC_MFMA_F32 mode (fc_set_mfma_mode): F x {re,im} x OP x ceil16(R*channels) floats.
  * `records`: which family of convolution entry points the images are for -- 0: the dense-stencil ones (fc_forward,
  * fc_backward_data), 1: the record-driven ones (fc_forward_factored, fc_forward_geometric, fc_backward_data_factored).
  * In the default mode the record-driven forward image is RING-major: OP inverse row scales, then

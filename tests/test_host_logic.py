@@ -40,6 +40,21 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert _lib.load(path).fc_abi_version() == 9
 
 
+def test_product_library_reads_no_environment_switch():
+    """The development switches (FC_RING, FC_FILTER2, FC_DEBUG, ...) are compiled into libfieldconv_hip_dev.so only (-DFC_DEV_SWITCHES);
+    the product library contains none of their names -- `strings libfieldconv_hip.so | grep -c '^FC_'` is 0 -- and says so."""
+    from fieldconv_amd import _env
+    from fieldconv_amd.build import build_dev, build_native
+    blob = open(build_native(), 'rb').read()
+    names = set(m.decode() for m in re.findall(rb'FC_[A-Z][A-Z0-9_]{2,}', blob))
+    assert not names, sorted(names)
+    assert ctypes.CDLL(build_native()).fc_dev_switches() == 0
+    dev = open(build_dev(), 'rb').read()
+    dev_names = set(m.decode() for m in re.findall(rb'FC_[A-Z][A-Z0-9_]{2,}', dev))
+    assert set(_env.LIBRARY_SWITCHES) <= dev_names, sorted(set(_env.LIBRARY_SWITCHES) - dev_names)
+    assert ctypes.CDLL(build_dev()).fc_dev_switches() == 1
+
+
 def test_supported_query_and_sizes_need_no_gpu():
     lib = _lib.load()
     d = _lib.FcDims(20000, 640000, 48, 48, 6, 2)
@@ -322,18 +337,24 @@ def test_every_environment_switch_is_registered():
     """fieldconv_amd/_env.py lists every switch the library (getenv in csrc/), the package and bench.py read: bench.py records
     the ones that are set and refuses names it does not know, so an unlisted switch would be refused or go unreported."""
     from fieldconv_amd import _env
-    found = set()
+    found, lib_switches = set(), set()
     for d, _, files in os.walk(os.path.join(ROOT, 'fieldconv_amd')):
         for f in files:
             if f.endswith(('.hip', '.hpp', '.py')) and f != '_env.py':
                 text = open(os.path.join(d, f), errors='ignore').read()
-                found |= set(re.findall(r'getenv\("([A-Z][A-Z_0-9]+)"\)', text))
+                found |= set(re.findall(r'(?:getenv|dev_env)\("([A-Z][A-Z_0-9]+)"\)', text))
+                lib_switches |= set(re.findall(r'dev_env\("([A-Z][A-Z_0-9]+)"\)', text))
                 found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'((?:FC|FIELDCONV|BENCH)_[A-Z_0-9]+)'", text))
     text = open(os.path.join(ROOT, 'bench.py')).read()
     found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'((?:FC|FIELDCONV|BENCH)_[A-Z_0-9]+)'", text))
     assert found, 'no switches parsed'
     assert found <= set(_env.SWITCHES), sorted(found - set(_env.SWITCHES))
     assert set(_env.SWITCHES) <= found, sorted(set(_env.SWITCHES) - found)          # nothing listed that nobody reads any more
+    assert lib_switches == set(_env.LIBRARY_SWITCHES), sorted(lib_switches ^ set(_env.LIBRARY_SWITCHES))
+    # the library sources call getenv in ONE place: dev_env under -DFC_DEV_SWITCHES (csrc/fc_common.hpp)
+    for f in os.listdir(os.path.join(ROOT, 'fieldconv_amd', 'csrc')):
+        text = open(os.path.join(ROOT, 'fieldconv_amd', 'csrc', f)).read()
+        assert text.count('getenv(') == (1 if f == 'fc_common.hpp' else 0), f
     assert _env.unknown({'FC_MFMA': 'f32', 'FC_TYPO': '1', 'PATH': 'x'}) == ['FC_TYPO']
     assert _env.active({'FC_MFMA': 'f32', 'HOME': 'x'}) == {'FC_MFMA': 'f32'}
 
