@@ -77,8 +77,9 @@ SIGNATURES = {
     'fc_wide_workspace_bytes': (ctypes.c_size_t, [_DP, _c_int32, _c_int32, _c_int32]),
     'fc_forward_wide': (ctypes.c_int, [_vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _vp, ctypes.c_size_t, _DP, _c_int32, _c_int32, _vp]),
     'fc_backward_wide': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _DP, _c_int32, _vp]),
+    'fc_cgemm_workspace_bytes': (ctypes.c_size_t, [_c_int32, _c_int32, _c_int32, _c_int32]),
     'fc_cgemm': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                                _c_int32, ctypes.c_double, _c_int32, _vp]),
+                                _c_int32, ctypes.c_double, _c_int32, _vp, ctypes.c_size_t, _vp]),
     'fc_tangent_nonlin_forward_f64': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),
     'fc_tangent_nonlin_backward_workspace_bytes_f64': (ctypes.c_size_t, [_c_int32, _c_int32]),
     'fc_tangent_nonlin_backward_f64': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _c_int32, _c_int32, _vp]),

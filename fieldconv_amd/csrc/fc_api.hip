@@ -29,7 +29,7 @@ static bool dims_supported(const fc_dims* d) {
 
 // The factored kernels address feature rows with 32-bit byte offsets formed by a 24-bit multiply: N * C * 8 must stay
 // below 4 GiB (8 million vertices at 64 channels) and N below 2^24.
-static bool rows_fit_32bit(const fc_dims* d) {
+bool rows_fit_32bit(const fc_dims* d) {
     const uint64_t c = (uint64_t)(d->I > d->O ? d->I : d->O);
     return (uint64_t)d->N * c * 8 < (1ull << 32) && d->N < (1 << 24);
 }
@@ -69,7 +69,7 @@ int fc_supported(const fc_dims* dims) { return fc::dims_supported(dims) ? 1 : 0;
 int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t buffer_bytes) {
     if (!buffer || buffer_bytes < 2 || kind < 0 || kind > 2 || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    char fwd[256], bwd[384];
+    char fwd[256], bwd[768];
     fc::describe_forward(dims, kind, fwd, sizeof(fwd));
     fc::describe_backward(dims, kind != 0, bwd, sizeof(bwd));
     snprintf(buffer, buffer_bytes, "%s; %s", fwd, bwd);
@@ -239,6 +239,10 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     const bool defer = params != nullptr && !split_finish;
     int rc = check_bwd(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;
+    if (params) {           // before anything is enqueued: a bad params struct must not leave gx half-finished in the workspace
+        rc = check_finish_params(gw_eff, params, dims);
+        if (rc != FC_OK) return rc;
+    }
     if (records) {
         if (dims->E > 0 && !by_source->runs) return FC_ERR_BAD_ARGUMENT;
         if (dims->R > 8 || !fc::rows_fit_32bit(dims)) return FC_ERR_UNSUPPORTED;
@@ -250,8 +254,6 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     if (rc != FC_OK) return rc;
     if (!params) return fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
     if (!defer) return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
-    rc = check_finish_params(gw_eff, params, dims);
-    if (rc != FC_OK) return rc;
     return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, gx);
 }
 

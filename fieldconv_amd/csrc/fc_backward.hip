@@ -641,11 +641,22 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
     const BwdPlan p = plan_backward(d, split_mode());
     const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
     static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
-    snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d%s; %s; %s", records ? "records" : "dense rows", mode, p.ntiles,
+    static const bool split_finish = [] { const char* e = dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
+    // what ends the pass follows the same switches the launches use (fc_api.hip: fc_backward_all / fc_backward_finish_params)
+    const int gx_parts = (1 << p.parts_log2) * (p.gsplit ? 2 : 1);
+    char fin[320];
+    if (split_finish)
+        snprintf(fin, sizeof(fin), "%sfc_backward_finish + fc_filter_param_grads (two launches: the split-finish development switch)",
+                 gx_parts > 1 ? "fc_sum_parts_kernel (the partial gx arrays), " : "");
+    else
+        snprintf(fin, sizeof(fin), "module parameters: fc_backward_finish_params (sum of the partials + parameter chain%s, + a fused modReLU's "
+                 "bias-gradient sum when given) in one launch; explicit filter: %sfc_backward_finish",
+                 gx_parts > 1 ? " + sum of the partial gx arrays" : "", gx_parts > 1 ? "fc_sum_parts_kernel, " : "");
+    snprintf(buf, n, "fc_backward_data_kernel<%s,%s> tiles=%d parts=%d%s; %s; %s; cus=%d", records ? "records" : "dense rows", mode, p.ntiles,
              1 << p.parts_log2, p.gsplit ? " (the two frequency groups of a tile as separate work items)" : "",
              p.fhalf ? (staged ? "fc_backward_filter_half_kernel (LDS-staged slabs)" : "fc_backward_filter_half2_kernel (register-fed rows)")
                      : "fc_backward_filter_kernel (fp32 MFMA)",
-             "fc_backward_finish_params (fused sum + parameter chain)");
+             fin, num_cus());
 }
 
 // Fixed-order sum of the per-workgroup filter-gradient partials left in the workspace.

@@ -10,7 +10,10 @@
 // and TangentLin in double precision.  A complex product is four real ones on v_mfma_f32_16x16x4_f32 /
 // v_mfma_f64_16x16x4_f64 (fp64 runs at the same matrix rate as fp32 on gfx950).  A workgroup of four wavefronts owns a
 // 64 x 64 tile of C, each wavefront a 32 x 32 quarter (2 x 2 MFMA tiles, re and im accumulators); A and B pass through LDS in
-// k chunks of 16 as separate re / im planes.  A correctness path: no split-k, no double buffering.
+// k chunks of 16 as separate re / im planes.  Products whose output is small and whose contraction is long -- the two weight-gradient
+// products (gW = gy^T . conj(contrib), TangentLin's gW = gy^T . conj(x)): M x N = a few 64 x 64 tiles, K = the vertex count -- are split
+// along k over gridDim.z workgroups (fc_cgemm_workspace_bytes > 0): per-slice partials in the caller's workspace, summed in slice order by
+// a second launch (deterministic).  No double buffering: a correctness path.
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
 
@@ -35,8 +38,28 @@ struct GemmArgs {
     long sam, sak, sbk, sbn;
     int conj_b;
     double alpha;
+    int kchunk;         // k range of one workgroup along gridDim.z (a multiple of kGemmK; >= K: no split)
 };
 
+// how many k slices a product is cut into: only when the output tiles cannot occupy the CUs and the contraction is long
+static int cgemm_ksplit(int M, int N, int K, int* kchunk) {
+    const long tiles = (long)((M + kGemmTile - 1) / kGemmTile) * ((N + kGemmTile - 1) / kGemmTile);
+    const int cus = num_cus();
+    int slices = 1;
+    if (tiles * 2 <= cus && K >= 2048) {
+        long want = (2L * cus) / tiles;                      // about two workgroups per CU
+        const long by_len = (K + 511) / 512;                 // at least 512 k entries per slice
+        slices = (int)(want < by_len ? want : by_len);
+        if (slices > 256) slices = 256;
+        if (slices < 1) slices = 1;
+    }
+    int chunk = ((K + slices - 1) / slices + kGemmK - 1) / kGemmK * kGemmK;
+    if (chunk < kGemmK) chunk = kGemmK;
+    *kchunk = chunk;
+    return (K + chunk - 1) / chunk > 0 ? (K + chunk - 1) / chunk : 1;
+}
+
+// C: the output, or with gridDim.z > 1 the per-slice partials [z][M][N] (alpha applied by the reduction)
 template <typename T>
 __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                                  const GemmArgs g) {
@@ -54,21 +77,22 @@ __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) { cre[i][j] = V4{0, 0, 0, 0}; cim[i][j] = V4{0, 0, 0, 0}; }
     const bool a_k_fast = g.sak == 1, b_n_fast = g.sbn == 1;
-    for (int k0 = 0; k0 < g.K; k0 += kGemmK) {
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    for (int k0 = kbeg; k0 < kend; k0 += kGemmK) {
         // 64 x 16 elements of A and 16 x 64 of B, four per thread each; the thread index runs along the contiguous direction
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = tid + j * kGemmThreads;
             const int am = a_k_fast ? idx / kGemmK : idx % kGemmTile, ak = a_k_fast ? idx % kGemmK : idx / kGemmTile;
             T re = 0, im = 0;
-            if (m0 + am < g.M && k0 + ak < g.K) {
+            if (m0 + am < g.M && k0 + ak < kend) {
                 const T* p = A + 2 * ((long)(m0 + am) * g.sam + (long)(k0 + ak) * g.sak);
                 re = p[0]; im = p[1];
             }
             a_re[am][ak] = re; a_im[am][ak] = im;
             const int bn = b_n_fast ? idx % kGemmTile : idx / kGemmK, bk = b_n_fast ? idx / kGemmTile : idx % kGemmK;
             re = 0; im = 0;
-            if (n0 + bn < g.N && k0 + bk < g.K) {
+            if (n0 + bn < g.N && k0 + bk < kend) {
                 const T* p = B + 2 * ((long)(k0 + bk) * g.sbk + (long)(n0 + bn) * g.sbn);
                 re = p[0]; im = g.conj_b ? -p[1] : p[1];
             }
@@ -100,7 +124,8 @@ __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restr
     // D layout of the 16x16x4 instructions: lane l holds column l & 15 and, in its register t, row 4 (l >> 4) + t (fp32) or
     // row 4 t + (l >> 4) (fp64: measured on MI355X -- the f64 instruction interleaves the lane groups' rows; test_cgemm_three_layouts)
     constexpr bool kF64 = std::is_same<T, double>::value;
-    const T alpha = (T)g.alpha;
+    const T alpha = gridDim.z > 1 ? (T)1 : (T)g.alpha;
+    C += 2 * (long)blockIdx.z * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -116,19 +141,49 @@ __global__ __launch_bounds__(kGemmThreads) void fc_cgemm_kernel(const T* __restr
             }
 }
 
+// C[idx] = alpha * sum over the slices, in slice order
 template <typename T>
-static int launch_cgemm(const void* A, const void* B, void* C, const GemmArgs& g, hipStream_t stream) {
-    const dim3 grid((g.M + kGemmTile - 1) / kGemmTile, (g.N + kGemmTile - 1) / kGemmTile);
+__global__ void fc_cgemm_reduce_kernel(const T* __restrict__ part, T* __restrict__ C, long count, int slices, T alpha) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;        // real numbers (2 per complex entry)
+    if (idx >= count) return;
+    T s = 0;
+    for (int z = 0; z < slices; ++z) s += part[(long)z * count + idx];
+    C[idx] = alpha * s;
+}
+
+template <typename T>
+static int launch_cgemm(const void* A, const void* B, void* C, GemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) {
+    int kchunk = 0;
+    int slices = cgemm_ksplit(g.M, g.N, g.K, &kchunk);
+    const size_t need = (size_t)slices * g.M * g.N * 2 * sizeof(T);
+    if (slices > 1 && (!ws || ws_bytes < need)) {           // no workspace: the unsplit product (same result up to summation order)
+        slices = 1;
+        kchunk = (g.K + kGemmK - 1) / kGemmK * kGemmK;
+    }
+    g.kchunk = kchunk > 0 ? kchunk : kGemmK;
+    const dim3 grid((g.M + kGemmTile - 1) / kGemmTile, (g.N + kGemmTile - 1) / kGemmTile, slices);
     if (grid.y > 65535u) return FC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(fc_cgemm_kernel<T>, grid, dim3(kGemmThreads), 0, stream, static_cast<const T*>(A), static_cast<const T*>(B),
-                       static_cast<T*>(C), g);
+                       slices > 1 ? static_cast<T*>(ws) : static_cast<T*>(C), g);
+    if (slices > 1) {
+        const long count = 2L * g.M * g.N;
+        hipLaunchKernelGGL(fc_cgemm_reduce_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, static_cast<const T*>(ws),
+                           static_cast<T*>(C), count, slices, (T)g.alpha);
+    }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 }  // namespace fc
 
+extern "C" size_t fc_cgemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+    if (M <= 0 || N <= 0 || K <= 0 || (dtype != FC_F32 && dtype != FC_F64)) return 0;
+    int kchunk = 0;
+    const int slices = fc::cgemm_ksplit(M, N, K, &kchunk);
+    return slices > 1 ? (size_t)slices * M * N * 2 * (dtype == FC_F64 ? sizeof(double) : sizeof(float)) : 0;
+}
+
 extern "C" int fc_cgemm(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak, int64_t sbk,
-                        int64_t sbn, int32_t conj_b, double alpha, int32_t dtype, void* stream) {
+                        int64_t sbn, int32_t conj_b, double alpha, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0 || (dtype != FC_F32 && dtype != FC_F64)) return FC_ERR_BAD_ARGUMENT;
     if (M == 0 || N == 0) return FC_OK;
     fc::GemmArgs g;
@@ -136,6 +191,7 @@ extern "C" int fc_cgemm(const void* A, const void* B, void* C, int32_t M, int32_
     g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn;
     g.conj_b = conj_b ? 1 : 0;
     g.alpha = alpha;
-    return dtype == FC_F64 ? fc::launch_cgemm<double>(A, B, C, g, static_cast<hipStream_t>(stream))
-                           : fc::launch_cgemm<float>(A, B, C, g, static_cast<hipStream_t>(stream));
+    g.kchunk = 0;
+    return dtype == FC_F64 ? fc::launch_cgemm<double>(A, B, C, g, workspace, workspace_bytes, static_cast<hipStream_t>(stream))
+                           : fc::launch_cgemm<float>(A, B, C, g, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }

@@ -89,6 +89,8 @@ int pack_filter_params_block_impl(const float* zonal, const float* sph, const fl
                                   const fc_dims* d, int records, int o0, int i0, int Ifull, hipStream_t stream);
 
 bool shape_compiled(int R, int B);
+// the record-driven kernels form 32-bit row offsets with a 24-bit multiply: N < 2^24 and N * channels * 8 < 4 GiB
+bool rows_fit_32bit(const fc_dims* d);
 // one-line descriptions of the kernels a launch with these dims selects (fc_describe_kernels)
 void describe_forward(const fc_dims* d, int kind, char* buf, size_t n);
 void describe_backward(const fc_dims* d, int records, char* buf, size_t n);

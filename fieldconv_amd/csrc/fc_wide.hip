@@ -75,6 +75,8 @@ int fc_forward_wide(const float* x, const float* sten_or_records, const fc_csr* 
     fc::WidePlan p;
     if (!fc::wide_plan(dims, block, records, p)) return FC_ERR_BAD_ARGUMENT;
     if (!fc_supported(&p.db)) return FC_ERR_UNSUPPORTED;
+    if (!by_target->rowptr || (dims->E > 0 && (!sten_or_records || (records ? !by_target->runs : !by_target->nbr)))) return FC_ERR_BAD_ARGUMENT;
+    if (records && (dims->R > 8 || !fc::rows_fit_32bit(&p.db))) return FC_ERR_UNSUPPORTED;          // the guards of the per-block entry points
     if (!workspace || workspace_bytes < p.total_fwd) return FC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* w = static_cast<char*>(workspace);
@@ -121,6 +123,8 @@ int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s
     fc::WidePlan p;
     if (!fc::wide_plan(dims, block, records, p)) return FC_ERR_BAD_ARGUMENT;
     if (!fc_supported(&p.db)) return FC_ERR_UNSUPPORTED;
+    if (!by_source->rowptr || (dims->E > 0 && (!sten_or_rec_s || (records ? !by_source->runs : !by_source->nbr)))) return FC_ERR_BAD_ARGUMENT;
+    if (records && (dims->R > 8 || !fc::rows_fit_32bit(&p.db))) return FC_ERR_UNSUPPORTED;          // the guards of the per-block entry points
     if (!workspace || workspace_bytes < p.total_bwd) return FC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* w = static_cast<char*>(workspace);

@@ -467,8 +467,11 @@ def _dtype_code(t):
 
 def _cgemm(lib, A, B, C, M, N, K, sam, sak, sbk, sbn, conj_b, alpha):
     """C (M,N) = alpha * A . op(B) on the matrix pipe (csrc/fc_cgemm.hip); strides in complex elements."""
-    check(lib.fc_cgemm(_p(A), _p(B), _p(C), M, N, K, sam, sak, sbk, sbn, 1 if conj_b else 0, float(alpha), _dtype_code(C), _stream()),
-          'fc_cgemm')
+    dt = _dtype_code(C)
+    nbytes = lib.fc_cgemm_workspace_bytes(M, N, K, dt)          # > 0: a small output with a long contraction goes split along k
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=C.device) if nbytes else None
+    check(lib.fc_cgemm(_p(A), _p(B), _p(C), M, N, K, sam, sak, sbk, sbn, 1 if conj_b else 0, float(alpha), dt,
+                       _p(ws) if ws is not None else None, nbytes, _stream()), 'fc_cgemm')
     return C
 
 

@@ -261,11 +261,15 @@ int fc_generic_scatter(const void* x, const void* g_contrib, const void* sten_s,
  *   C[m, n] = alpha * sum_k A[m*sam + k*sak] * op(B[k*sbk + n*sbn]),   op = conj when conj_b != 0,
  * C (M, N) row-major and contiguous, A and B complex arrays addressed with element strides (in complex numbers), all three of
  * dtype FC_F32 (interleaved float pairs) or FC_F64 (double pairs).  With contrib viewed as (n, K = I*R*F) and W_eff as (O, K):
- *   y         = contrib . W_eff^T / F         fc_cgemm(contrib, W, y,  n, O, K,  K, 1,  1, K,  0, 1/F)
- *   g_contrib = gy . conj(W_eff) / F          fc_cgemm(gy, W, gc,      n, K, O,  O, 1,  K, 1,  1, 1/F)
- *   gW_eff    = gy^T . conj(contrib) / F      fc_cgemm(gy, contrib, gW, O, K, n,  1, O,  K, 1,  1, 1/F)            */
+ *   y         = contrib . W_eff^T / F         fc_cgemm(contrib, W, y,  n, O, K,  K, 1,  1, K,  0, 1/F, ...)
+ *   g_contrib = gy . conj(W_eff) / F          fc_cgemm(gy, W, gc,      n, K, O,  O, 1,  K, 1,  1, 1/F, ...)
+ *   gW_eff    = gy^T . conj(contrib) / F      fc_cgemm(gy, contrib, gW, O, K, n,  1, O,  K, 1,  1, 1/F, ...)            */
+/* workspace (optional): fc_cgemm_workspace_bytes(M, N, K, dtype) bytes -- non-zero for products with a small output and a long
+ * contraction (the two weight-gradient products: K = the vertex count), which are then split along k over many workgroups with per-slice
+ * partials summed in slice order; NULL / 0: one workgroup per 64 x 64 output tile walks all of K. */
+size_t fc_cgemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype);
 int fc_cgemm(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
-             int32_t conj_b, double alpha, int32_t dtype, void* stream);
+             int32_t conj_b, double alpha, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- TangentLin.forward, reference nn/tangent_lin.py:27-29 ------------------------------- *
  * y[n,o] = sum_i x[n,i] (Re + i Im)[o,i];  re_w, im_w are (O,I) fp32 row-major. */

@@ -1222,7 +1222,10 @@ def test_cgemm_three_layouts(dtype, dev):
     def rnd(*shape):
         return torch.complex(torch.randn(*shape, generator=g, dtype=torch.float64), torch.randn(*shape, generator=g, dtype=torch.float64))
     tol = 1e-13 if dtype == torch.complex128 else 2e-6
-    for (n, O, K) in ((200, 7, 90), (130, 70, 333), (65, 64, 16), (1, 1, 1)):
+    # (the last two: weight-gradient products with a long contraction -- 128 x 128 outputs over 20 000 / 5 003 vertices -- which
+    #  fc_cgemm splits along k over many workgroups: fc_cgemm_workspace_bytes > 0)
+    assert lib.fc_cgemm_workspace_bytes(128, 128, 20000, 0) > 0 and lib.fc_cgemm_workspace_bytes(20000, 128, 128, 0) == 0
+    for (n, O, K) in ((200, 7, 90), (130, 70, 333), (65, 64, 16), (1, 1, 1), (20000, 128, 128), (5003, 70, 40)):
         A, W, G = rnd(n, K), rnd(O, K), rnd(n, O)
         Ad, Wd, Gd = A.to(dtype).to(dev), W.to(dtype).to(dev), G.to(dtype).to(dev)
         y = torch.empty((n, O), dtype=dtype, device=dev)

@@ -372,7 +372,10 @@ def test_kernel_description_and_gpu_count_need_no_gpu():
     small = _lib.FcDims(1024, 131072, 48, 48, 6, 2)
     assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and b'frequency-major' in buf.value
     assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(100, 10, 48, 48, 9, 2)), 1, buf, len(buf)) == -2
-    if os.environ.get('FC_MFMA') in (None, '') and os.environ.get('FC_GROUP_SPLIT') in (None, ''):
+    # (the split decisions follow the device's CU count, which the description carries: pinned for the MI355X's 256 -- the value the
+    #  library also assumes when no device can be queried -- and not asserted on a part with another count)
+    assert re.search(rb'cus=\d+', buf.value), buf.value
+    if os.environ.get('FC_MFMA') in (None, '') and os.environ.get('FC_GROUP_SPLIT') in (None, '') and b'cus=256' in buf.value:
         # the backward data kernel runs a tile's two frequency groups as separate work items where that fills the CUs' rounds better:
         # a FAUST-sized mesh at band limit 3 (313 tiles), the reference's 1 024-vertex mesh (instead of the edge split's last doubling:
         # 2 parts, not 4) -- and not config 2 (1 250 tiles: five rounds either way)
