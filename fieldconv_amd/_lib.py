@@ -127,6 +127,13 @@ SIGNATURES = {
     'fc_tangent_nonlin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
     'fc_tangent_nonlin_backward_groups': (_c_int32, [_c_int32]),
     'fc_tangent_nonlin_backward_partial': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),
+    'fc_trans_field_forward_generic': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_c_int32] * 7 + [_vp]),
+    'fc_trans_field_backward_generic_workspace_bytes': (_sz, [_c_int32] * 5),
+    'fc_trans_field_backward_generic': (ctypes.c_int, [_vp, _CP, _vp] + [_vp] * 11 + [_vp, _sz] + [_c_int32] * 8 + [_vp]),
+    'fc_echo_hist_dim_generic': (ctypes.c_int, [_c_int32]),
+    'fc_echo_generic_workspace_bytes': (_sz, [_c_int32]),
+    'fc_echo_forward_generic': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz] + [_c_int32] * 5 + [_vp]),
+    'fc_echo_backward_generic': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _vp, _vp, _sz] + [_c_int32] * 5 + [_vp]),
     'fc_resnet_block_saved_bytes': (_sz, [_MP, _RBP]),
     'fc_resnet_block_workspace_bytes': (_sz, [_MP, _RBP, _c_int32]),
     'fc_resnet_block_forward': (ctypes.c_int, [_vp, _MP, _RBP, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -183,22 +183,6 @@ def resnet_block(block, x, graph):
 
 
 # --------------------------------------------------------------------------------------------------------------------- ECHOBlock
-def _key(t):
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.dtype)
-
-
-def echo_slot_order(graph, ln, wxp):
-    """ln / wxp in the slot orders of the two groupings (what fc_echo_forward / fc_echo_backward stream), built once per mesh and kept
-    with the graph: (ln_t, wxp_t, ln_s, wxp_s)."""
-    key = ('echo_slots', _key(ln), _key(wxp))
-    hit = graph._plans.get(key)
-    if hit is None:
-        l64, w64 = ln.to(torch.complex64), wxp.to(torch.complex64)
-        hit = graph._plans[key] = (l64.index_select(0, graph.perm_t).contiguous(), w64.index_select(0, graph.perm_t).contiguous(),
-                                   l64.index_select(0, graph.perm_s).contiguous(), w64.index_select(0, graph.perm_s).contiguous(), (ln, wxp))
-    return hit
-
-
 class _EchoBlockFn(torch.autograd.Function):
     """reference nn/echo_block.py:93-94: ECHO(modReLU(conv(x))) as fc_echo_block_forward / fc_echo_block_backward"""
 
@@ -257,10 +241,9 @@ def echo_block_descriptors(block, x, graph, ln, wxp):
     conv, n_des, n_bins = block.conv, block.n_des, int(block.echo.n_bins)
     if not _conv_ok(conv, graph, x):
         return None
-    blk = _lib.load().fc_echo_channel_block(n_bins)
-    if blk <= 0 or n_des > blk or n_des != conv.out_channels:
+    if not 1 <= n_bins <= 8 or n_des != conv.out_channels:          # (more bins: the run-time ECHO kernels, composed path)
         return None
-    slots = echo_slot_order(graph, ln, wxp)
+    slots = Fn.echo_slot_order(graph, ln, wxp)
     return _EchoBlockFn.apply(x, conv.zonal, conv.spherical, conv.phase, block.nonlin.bias, int(conv.ftype), int(conv.B), int(n_des), n_bins,
                               graph, slots)
 
@@ -270,10 +253,9 @@ class _LiftBlockFn(torch.autograd.Function):
     """reference nn/lift_block.py:53-55: modReLU(TransField(x)) as fc_lift_block_forward / fc_lift_block_backward"""
 
     @staticmethod
-    def forward(ctx, x, lift_sten, zonal_ang, zonal_mag, phase, bias, ftype, csr):
+    def forward(ctx, x, sten, stride, zonal_ang, zonal_mag, phase, bias, ftype, csr):
         lib = _lib.load()
         x = x.contiguous()
-        sten, stride = Fn._TransFieldFn._stencil(lift_sten)
         zonal_ang, zonal_mag, phase, bias = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous(), bias.contiguous()
         N, C_in = x.shape
         C_out, _, R = zonal_ang.shape
@@ -312,19 +294,20 @@ class _LiftBlockFn(torch.autograd.Function):
             ws = _u8(nws, dev)
             check(lib.fc_lift_block_backward(Fn._p(g_out), Fn._p(sten), ctx.stride, ctypes.byref(mesh), Fn._p(csr.perm_s), ctypes.byref(bp),
                                              Fn._p(saved), ctx.nsaved, Fn._p(gx), Fn._p(ws), nws, Fn._stream()), 'fc_lift_block_backward')
-        return gx, None, g_za, g_zm, g_ph, g_b, None, None
+        return gx, None, None, g_za, g_zm, g_ph, g_b, None, None
 
 
 def lift_block(block, x, supp_edges, lift_sten):
     """LiftBlock.forward through the block-level entry points, or None when they do not apply"""
-    if not (enabled() and Fn.on_device(x)) or x.dtype != torch.float32 or x.dim() != 2 or lift_sten.dtype != torch.complex64:
+    if not (enabled() and Fn.on_device(x)) or x.dim() != 2 or lift_sten.dim() != 3:
         return None
     field = block.field
     O, Cin, R = field.zonalAng.shape
-    if x.shape[1] != Cin or lift_sten.dim() != 3 or lift_sten.shape[1] != R or lift_sten.shape[2] < 2 or R > 8 or Cin > 4 or O > Fn.MAX_CHANNELS:
-        return None
+    if x.shape[1] != Cin or lift_sten.shape[1] != R or lift_sten.shape[2] < 2 or not Fn.trans_field_specialised(x, lift_sten, field.zonalAng):
+        return None                     # (wide / float64 shapes: the run-time kernels through the composed path)
     if lift_sten.shape[2] > 2:
         lift_sten = lift_sten[..., :2]
     from .graph import get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
-    return _LiftBlockFn.apply(x, lift_sten, field.zonalAng, field.zonalMag, field.phase, block.nonlin.bias, int(field.ftype), csr)
+    sten, stride = Fn._TransFieldFn._stencil(lift_sten)         # (FCPrecomp's stand-in: the factor table, stride 0)
+    return _LiftBlockFn.apply(x, sten, stride, field.zonalAng, field.zonalMag, field.phase, block.nonlin.bias, int(field.ftype), csr)

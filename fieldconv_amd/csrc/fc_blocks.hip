@@ -203,7 +203,7 @@ struct EchoPlan {
 static bool echo_plan(const fc_mesh* m, const fc_echo_block_params* p, EchoPlan& pl) {
     if (!mesh_valid(m, true) || !p || p->C_in <= 0 || p->n_des <= 0) return false;
     pl.dS = fc_echo_hist_dim(p->n_bins);
-    if (pl.dS == 0 || p->n_des > fc_echo_channel_block(p->n_bins)) return false;
+    if (pl.dS == 0) return false;
     pl.d = conv_dims(m, p->C_in, p->n_des);
     if (!fc_supported(&pl.d)) return false;
     pl.records = m->kind != 0 ? 1 : 0;

@@ -70,7 +70,8 @@ __device__ __forceinline__ float2 echo_frame(float2 x, bool& live) {
 __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
     const float2* __restrict__ x, const float2* __restrict__ ln_t, const float2* __restrict__ wxp_t,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, float2* __restrict__ hist, float* __restrict__ desc,
-    int N, int C, int n, int dS, int wpv) {
+    int N, int C, int n, int dS, int wpv, int ldc, int c0) {
+    // (C channels [c0, c0 + C) of rows with ldc channels: wider inputs run as channel blocks of one entry-point call)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const dmap = reinterpret_cast<int*>(smem);                                  // [kEchoMaxCells]
     float* const hl = reinterpret_cast<float*>(smem) + kEchoMaxCells + 3;           // [waves][C][dS][2]
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
             const int e = min(e0 + u * wpv, end - 1);
             les[u] = ln_t[e];
             wes[u] = wxp_t[e];
-            xs[u] = x[(size_t)nbr[e] * C + cl];
+            xs[u] = x[(size_t)nbr[e] * ldc + c0 + cl];
         }
 #pragma unroll
         for (int u = 0; u < kEchoAhead; ++u) {
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_forward_kernel(
     if (wpv > 1) __syncthreads();
     if (!active) return;
     // the block [C][dS] of this vertex, contiguous in LDS and in the outputs; the vertex's wavefronts share the rows
-    float2* const hout = hist + (size_t)v * CS;
-    float* const dout = desc + (size_t)v * CS;
+    float2* const hout = hist + ((size_t)v * ldc + c0) * dS;
+    float* const dout = desc + ((size_t)v * ldc + c0) * dS;
     const float* const first = hl + (size_t)(wave - sub) * CS * 2;
     for (int idx = sub * kWave + lane; idx < CS; idx += wpv * kWave) {
         float2 h = make_float2(0.f, 0.f);
@@ -168,7 +169,7 @@ __global__ void echo_hist_grad_kernel(const float2* __restrict__ hist, const flo
 __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
     const float2* __restrict__ x, const float2* __restrict__ ln_s, const float2* __restrict__ wxp_s,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr, const float2* __restrict__ gh_all,
-    float2* __restrict__ gx, int N, int C, int n, int dS, int wpv) {
+    float2* __restrict__ gx, int N, int C, int n, int dS, int wpv, int ldc, int c0) {
     __shared__ int dmap[kEchoMaxCells];
     __shared__ float4 s_part[kEchoWaves][kWave];
     const int lane = threadIdx.x & 63;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
     const bool active = j < N;
     const int beg = active ? rowptr[j] : 0, end = active ? rowptr[j + 1] : 0;
     const int cl = lane < C ? lane : 0;
-    const float2 xv = active ? x[(size_t)j * C + cl] : make_float2(1.f, 0.f);
+    const float2 xv = active ? x[(size_t)j * ldc + c0 + cl] : make_float2(1.f, 0.f);
     bool live;
     const float2 fr = echo_frame(xv, live);
     float2 gval = make_float2(0.f, 0.f);        // gradient through the vote values
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
         const float2 le = ln_s[e], we = wxp_s[e];
         const EchoVote vt = echo_rasterize(cmul(le, fr), n);
         const float2 xw = cmul(xv, we);
-        const float2* const ghrow = gh_all + ((size_t)dst * C + cl) * dS;
+        const float2* const ghrow = gh_all + ((size_t)dst * ldc + c0 + cl) * dS;
         float2 acc = make_float2(0.f, 0.f);
         float gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kEchoWaves * kWave) void echo_backward_kernel(
         const float inv2 = 1.f / (xv.x * xv.x + xv.y * xv.y);
         out = make_float2(gval.x - xv.y * gth * inv2, gval.y + xv.x * gth * inv2);
     }
-    if (lane < C) gx[(size_t)j * C + lane] = out;
+    if (lane < C) gx[(size_t)j * ldc + c0 + lane] = out;
 }
 
 // wavefronts per vertex: spread large supports over the workgroup when the mesh alone cannot fill the chip
@@ -262,19 +263,23 @@ int fc_echo_forward(const float* x, const float* ln_t, const float* wxp_t, const
                     int32_t N, int32_t E, int32_t C, int32_t n_bins, void* stream) {
     if (!x || !by_target || !by_target->rowptr || !hist || !desc || N <= 0 || E < 0 || C <= 0) return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!ln_t || !wxp_t || !by_target->nbr)) return FC_ERR_BAD_ARGUMENT;
-    if (C > fc::kWave || n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
+    if (n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
     const int dS = fc::echo_hist_dim(n_bins);
-    const size_t lds = (size_t)(fc::kEchoMaxCells + 3 + fc::kEchoWaves * C * dS * 2) * sizeof(float);
-    if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
+    const int blk = fc_echo_channel_block(n_bins);       // channels per launch: one per lane, a workgroup's histograms in LDS
     auto kern = fc::echo_forward_kernel;
     static bool lds_ok[fc::kMaxDevices] = {};
-    if (!fc::allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
     const int wpv = fc::echo_waves_per_vertex(N, E);
     const int per_wg = fc::kEchoWaves / wpv;
-    hipLaunchKernelGGL(kern, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), lds,
-                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_t),
-                       reinterpret_cast<const float2*>(wxp_t), by_target->rowptr, by_target->nbr, reinterpret_cast<float2*>(hist),
-                       desc, N, C, n_bins, dS, wpv);
+    for (int c0 = 0; c0 < C; c0 += blk) {               // the channels are independent: blocks of `blk`
+        const int cb = C - c0 < blk ? C - c0 : blk;
+        const size_t lds = (size_t)(fc::kEchoMaxCells + 3 + fc::kEchoWaves * cb * dS * 2) * sizeof(float);
+        if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
+        if (!fc::allow_full_lds(reinterpret_cast<const void*>(kern), lds, lds_ok)) return FC_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), lds,
+                           static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_t),
+                           reinterpret_cast<const float2*>(wxp_t), by_target->rowptr, by_target->nbr, reinterpret_cast<float2*>(hist),
+                           desc, N, cb, n_bins, dS, wpv, C, c0);
+    }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -284,7 +289,7 @@ int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, cons
     if (!x || !by_source || !by_source->rowptr || !hist || !g_desc || !gx || !hist_grad_workspace || N <= 0 || E < 0 || C <= 0)
         return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!ln_s || !wxp_s || !by_source->nbr)) return FC_ERR_BAD_ARGUMENT;
-    if (C > fc::kWave || n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
+    if (n_bins < 1 || n_bins > fc::kEchoMaxBins) return FC_ERR_UNSUPPORTED;
     const int dS = fc::echo_hist_dim(n_bins);
     const size_t count = (size_t)N * C * dS;
     float2* const gh = reinterpret_cast<float2*>(hist_grad_workspace);
@@ -292,10 +297,13 @@ int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, cons
                        reinterpret_cast<const float2*>(hist), g_desc, gh, count);
     const int wpv = fc::echo_waves_per_vertex(N, E);
     const int per_wg = fc::kEchoWaves / wpv;
-    hipLaunchKernelGGL(fc::echo_backward_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), 0,
-                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_s),
-                       reinterpret_cast<const float2*>(wxp_s), by_source->rowptr, by_source->nbr, gh, reinterpret_cast<float2*>(gx), N, C,
-                       n_bins, dS, wpv);
+    for (int c0 = 0; c0 < C; c0 += fc::kWave) {         // one channel per lane: blocks of 64
+        const int cb = C - c0 < fc::kWave ? C - c0 : fc::kWave;
+        hipLaunchKernelGGL(fc::echo_backward_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kEchoWaves * fc::kWave), 0,
+                           static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), reinterpret_cast<const float2*>(ln_s),
+                           reinterpret_cast<const float2*>(wxp_s), by_source->rowptr, by_source->nbr, gh, reinterpret_cast<float2*>(gx), N, cb,
+                           n_bins, dS, wpv, C, c0);
+    }
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

@@ -22,8 +22,21 @@ __device__ __forceinline__ float soft_abs(float2 z) { return is_origin(z) ? 0.f 
 struct TfArgs { int N, E, Cin, O, R, ftype, sten_stride; };
 
 // lift_sten rows are addressed through the slot -> edge permutation: no permuted copy of the stencil
-// (row stride in complex elements: 2 for a packed (E,R,2) array, 2B+1 when the caller passes the m = 0 column of the full stencil)
+// (row stride in complex elements: 2 for a packed (E,R,2) array, 2B+1 when the caller passes the m = 0 column of the full stencil;
+//  0: `lsten` is FCPrecomp's (E,8) FACTOR TABLE [q bits, w_q, w_{q+1}, 0, Re c, Im c, cos theta, sin theta] -- the stencil row is
+//  w_r c e^{i m theta} (fc_precomp_graph), so the two columns are s0 = w_r c and s1 = w_r c g and no (E,R,2) array is ever built)
 __device__ __forceinline__ void tf_load_sten(const float2* __restrict__ lsten, int edge, int R, int r, int stride, float2& s0, float2& s1) {
+    if (stride == 0) {
+        const float4* f = reinterpret_cast<const float4*>(lsten) + 2 * (size_t)edge;
+        const float4 a = f[0], b = f[1];
+        const int q = __float_as_int(a.x);
+        const float w = r == q ? a.y : (r == q + 1 ? a.z : 0.f);
+        const float2 c = make_float2(b.x, b.y);
+        const float2 cg = cmul(c, make_float2(b.z, b.w));
+        s0 = make_float2(w * c.x, w * c.y);
+        s1 = make_float2(w * cg.x, w * cg.y);
+        return;
+    }
     const float2* p = lsten + ((size_t)edge * R + r) * stride;
     s0 = p[0];
     s1 = p[1];
@@ -321,7 +334,7 @@ int fc_trans_field_forward(const float* x, const float* lift_sten, const fc_csr*
         return FC_ERR_BAD_ARGUMENT;
     if (E > 0 && (!lift_sten || !by_target->nbr || !slot_to_edge)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::tf_supported(Cin, O, R)) return FC_ERR_UNSUPPORTED;
-    if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
+    if (sten_stride < 2 && sten_stride != 0) return FC_ERR_BAD_ARGUMENT;
     const fc::TfArgs a{N, E, Cin, O, R, 1, sten_stride};
     const int wpv = fc::tf_waves_per_vertex(N, E), per_wg = fc::kTfWaves / wpv;
     hipLaunchKernelGGL(fc::trans_field_forward_kernel, dim3((N + per_wg - 1) / per_wg), dim3(fc::kTfWaves * fc::kWave), 0,
@@ -357,7 +370,7 @@ int fc_trans_field_backward(const float* lift_sten, const fc_csr* by_source, con
     float* g_mag = reinterpret_cast<float*>(w + (size_t)N * IR * 8);
     float* gx_dst = g_mag + (size_t)N * IR;
     float* partial = gx_dst + (size_t)N * Cin;
-    if (sten_stride < 2) return FC_ERR_BAD_ARGUMENT;
+    if (sten_stride < 2 && sten_stride != 0) return FC_ERR_BAD_ARGUMENT;
     const fc::TfArgs a{N, E, Cin, O, R, ftype, sten_stride};
     // persistent wavefronts = parameter-gradient partials: a quarter of the vertices on small meshes
     int waves = (N < 4 * fc::kTfGridWaves) ? ((N + 3) / 4 + fc::kTfWaves - 1) / fc::kTfWaves * fc::kTfWaves : fc::kTfGridWaves;

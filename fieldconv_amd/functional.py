@@ -854,60 +854,115 @@ def tangent_nonlin(x, bias):
     return _TangentNonLinFn.apply(x, bias)
 
 
+def _tkey(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.dtype)
+
+
+def echo_slot_order(csr, ln, wxp, dtype=torch.complex64):
+    """ln / wxp in the slot orders of the two edge groupings (what the ECHO kernels stream): built once per mesh and kept with the
+    grouping (a SupportGraph or an EdgeCSR) -- not four index_selects per forward and backward pass.  -> (ln_t, wxp_t, ln_s, wxp_s)"""
+    key = ('echo_slots', _tkey(ln), _tkey(wxp), dtype)
+    hit = csr._plans.get(key)
+    if hit is None:
+        l, w = ln.to(dtype), wxp.to(dtype)
+        hit = csr._plans[key] = (l.index_select(0, csr.perm_t).contiguous(), w.index_select(0, csr.perm_t).contiguous(),
+                                 l.index_select(0, csr.perm_s).contiguous(), w.index_select(0, csr.perm_s).contiguous(), (ln, wxp))
+    return hit
+
+
 class _EchoFn(torch.autograd.Function):
-    """reference nn/echo.py:94-148 (ECHO.forward)"""
+    """reference nn/echo.py:94-148 (ECHO.forward); any channel count: the entry points launch the channel blocks"""
 
     @staticmethod
-    def forward(ctx, x, ln, wxp, csr, n_bins):
+    def forward(ctx, x, slots, csr, n_bins):
         lib = _lib.load()
         x = x.contiguous()
         N, C = x.shape
         dS = lib.fc_echo_hist_dim(n_bins)
-        if dS == 0:
-            raise ValueError(f'ECHO: n_bins must be in 1..8, got {n_bins}')
         with _on(x.device):
-            ln_t = ln.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
-            wxp_t = wxp.to(torch.complex64).index_select(0, csr.perm_t).contiguous()
             hist = torch.empty((N, C, dS), dtype=torch.complex64, device=x.device)
             desc = torch.empty((N, C, dS), dtype=torch.float32, device=x.device)
             by_t = _csr(csr.rowptr_t, csr.nbr_t, None)
-            check(lib.fc_echo_forward(_p(x), _p(ln_t), _p(wxp_t), ctypes.byref(by_t), _p(hist), _p(desc), N, csr.E, C, n_bins,
+            check(lib.fc_echo_forward(_p(x), _p(slots[0]), _p(slots[1]), ctypes.byref(by_t), _p(hist), _p(desc), N, csr.E, C, n_bins,
                                       _stream()), 'fc_echo_forward')
-        ctx.save_for_backward(x, ln, wxp, hist)
-        ctx.csr, ctx.n_bins = csr, n_bins
+        ctx.save_for_backward(x, hist)
+        ctx.csr, ctx.n_bins, ctx.slots = csr, n_bins, slots
         return desc
 
     @staticmethod
     def backward(ctx, g_desc):
         lib = _lib.load()
-        x, ln, wxp, hist = ctx.saved_tensors
-        csr = ctx.csr
+        x, hist = ctx.saved_tensors
+        csr, slots = ctx.csr, ctx.slots
         N, C = x.shape
         g_desc = g_desc.contiguous()
         with _on(x.device):
-            ln_s = ln.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
-            wxp_s = wxp.to(torch.complex64).index_select(0, csr.perm_s).contiguous()
             gx = torch.empty_like(x)
             gh = torch.empty_like(hist)
             by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
-            check(lib.fc_echo_backward(_p(x), _p(ln_s), _p(wxp_s), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), _p(gh), N, csr.E, C,
+            check(lib.fc_echo_backward(_p(x), _p(slots[2]), _p(slots[3]), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), _p(gh), N, csr.E, C,
                                        ctx.n_bins, _stream()), 'fc_echo_backward')
-        return gx, None, None, None, None
+        return gx, None, None, None
+
+
+class _EchoGenericFn(torch.autograd.Function):
+    """ECHO descriptors outside the specialised kernels' range -- more than 8 raster bins per unit radius, or complex128 features
+    (csrc/fc_lift_echo_generic.hip: run-time loops in the tensors' own precision)"""
+
+    @staticmethod
+    def forward(ctx, x, slots, csr, n_bins):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, C = x.shape
+        dS = lib.fc_echo_hist_dim_generic(n_bins)
+        if dS == 0:
+            raise ValueError(f'ECHO: n_bins must be in 1..1024, got {n_bins}')
+        dt = _dtype_code(x)
+        with _on(x.device):
+            hist = torch.empty((N, C, dS), dtype=x.dtype, device=x.device)
+            desc = torch.empty((N, C, dS), dtype=x.real.dtype, device=x.device)
+            nbytes = lib.fc_echo_generic_workspace_bytes(n_bins)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            by_t = _csr(csr.rowptr_t, csr.nbr_t, None)
+            check(lib.fc_echo_forward_generic(_p(x), _p(slots[0]), _p(slots[1]), ctypes.byref(by_t), _p(hist), _p(desc), _p(ws), nbytes, N,
+                                              csr.E, C, n_bins, dt, _stream()), 'fc_echo_forward_generic')
+        ctx.save_for_backward(x, hist)
+        ctx.csr, ctx.n_bins, ctx.slots = csr, n_bins, slots
+        return desc
+
+    @staticmethod
+    def backward(ctx, g_desc):
+        lib = _lib.load()
+        x, hist = ctx.saved_tensors
+        csr, slots = ctx.csr, ctx.slots
+        N, C = x.shape
+        g_desc = g_desc.contiguous()
+        with _on(x.device):
+            gx = torch.empty_like(x)
+            gh = torch.empty_like(hist)
+            nbytes = lib.fc_echo_generic_workspace_bytes(ctx.n_bins)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
+            check(lib.fc_echo_backward_generic(_p(x), _p(slots[2]), _p(slots[3]), ctypes.byref(by_s), _p(hist), _p(g_desc), _p(gx), _p(gh),
+                                               _p(ws), nbytes, N, csr.E, C, ctx.n_bins, _dtype_code(x), _stream()), 'fc_echo_backward_generic')
+        return gx, None, None, None
 
 
 def echo_descriptors(x, supp_edges, ln, wxp, n_bins):
-    """ECHO descriptors |hist| (N, C, dS) of the tangent field x on the device (reference nn/echo.py:94-148)."""
+    """ECHO descriptors |hist| (N, C, dS) of the tangent field x on the device (reference nn/echo.py:94-148); any channel count, any
+    n_bins; complex64 features (the reference's own ECHO is float32-only) or complex128 (run-time kernels)."""
     _require_device(x, 'echo_descriptors')
-    if x.dtype != torch.complex64 or x.dim() != 2:
-        raise ValueError('echo_descriptors expects complex64 features of shape (N, C)')
+    if x.dtype not in (torch.complex64, torch.complex128) or x.dim() != 2:
+        raise ValueError('echo_descriptors expects complex features of shape (N, C)')
+    n_bins = int(n_bins)
+    if n_bins < 1:
+        raise ValueError(f'ECHO: n_bins must be positive, got {n_bins}')
     from .graph import get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
-    blk = _lib.load().fc_echo_channel_block(int(n_bins))      # one channel per lane, a workgroup's histograms in LDS
-    if blk <= 0:
-        raise ValueError(f'ECHO: n_bins must be in 1..8, got {n_bins}')
-    if x.shape[1] > blk:                   # the channels are independent
-        return torch.cat([_EchoFn.apply(x[:, c0:c0 + blk], ln, wxp, csr, int(n_bins)) for c0 in range(0, x.shape[1], blk)], dim=1)
-    return _EchoFn.apply(x, ln, wxp, csr, int(n_bins))
+    slots = echo_slot_order(csr, ln, wxp, x.dtype)
+    if x.dtype == torch.complex128 or _lib.load().fc_echo_hist_dim(n_bins) == 0:
+        return _EchoGenericFn.apply(x, slots, csr, n_bins)
+    return _EchoFn.apply(x, slots, csr, n_bins)
 
 
 class _TransFieldFn(torch.autograd.Function):
@@ -915,6 +970,12 @@ class _TransFieldFn(torch.autograd.Function):
 
     @staticmethod
     def _stencil(lift_sten):
+        # FCPrecomp's stand-in for supp_sten[..., B:B+2]: the kernels read the (E,8) factor table (sten_stride 0), no (E,R,2) array
+        from .graph import LiftColumns
+        if isinstance(lift_sten, LiftColumns):
+            if lift_sten._dense is None:
+                return lift_sten.factors, 0
+            lift_sten = lift_sten._dense
         # (E,R,2) view of the full stencil (supp_sten[..., B:B+2], reference segmentation.ipynb:204) is read in place
         E, R, two = lift_sten.shape
         st = lift_sten.stride()
@@ -923,12 +984,12 @@ class _TransFieldFn(torch.autograd.Function):
         return lift_sten.contiguous(), 2
 
     @staticmethod
-    def forward(ctx, x, lift_sten, zonal_ang, zonal_mag, phase, csr, ftype):
+    def forward(ctx, x, sten, stride, zonal_ang, zonal_mag, phase, csr, ftype):
+        # (sten, stride) = _TransFieldFn._stencil(lift_sten), resolved by the caller
         lib = _lib.load()
         x = x.contiguous()
         N, Cin = x.shape
         O, _, R = zonal_ang.shape
-        sten, stride = _TransFieldFn._stencil(lift_sten)
         zonal_ang, zonal_mag, phase = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous()
         with _on(x.device):
             y = torch.empty((N, O), dtype=torch.complex64, device=x.device)
@@ -962,34 +1023,85 @@ class _TransFieldFn(torch.autograd.Function):
                                               _p(ang), _p(mag), _p(s1sum), _p(gy), _p(gx), _p(g_za), _p(g_zm),
                                               _p(g_ph) if g_ph is not None else None, _p(ws), nbytes, N, csr.E, Cin, O, R,
                                               ctx.stride, ctx.ftype, _stream()), 'fc_trans_field_backward')
+        return gx, None, None, g_za, g_zm, g_ph, None, None
+
+
+class _TransFieldGenericFn(torch.autograd.Function):
+    """TransField outside the specialised kernels' range -- more than 4 scalar inputs, more than 64 output channels, more than 8 rings,
+    or float64 (the reference's TransField / LiftBlock run under .double()): csrc/fc_lift_echo_generic.hip, run-time loops in the
+    tensors' own precision, one native call per pass (no Python channel loops)."""
+
+    @staticmethod
+    def forward(ctx, x, sten, zonal_ang, zonal_mag, phase, csr, ftype):
+        lib = _lib.load()
+        x = x.contiguous()
+        sten = sten.contiguous()                      # (E, R, >= 2) complex, the x's precision
+        N, Cin = x.shape
+        O, _, R = zonal_ang.shape
+        stride = int(sten.shape[2])
+        zonal_ang, zonal_mag, phase = zonal_ang.contiguous(), zonal_mag.contiguous(), phase.contiguous()
+        cdt = torch.complex128 if x.dtype == torch.float64 else torch.complex64
+        dt = _dtype_code(x)
+        with _on(x.device):
+            y = torch.empty((N, O), dtype=cdt, device=x.device)
+            ang = torch.empty((N, Cin, R), dtype=cdt, device=x.device)
+            mag = torch.empty((N, Cin, R), dtype=x.dtype, device=x.device)
+            s1sum = torch.empty((N, R), dtype=cdt, device=x.device)
+            by_t = _csr(csr.rowptr_t, csr.nbr_t, None)
+            check(lib.fc_trans_field_forward_generic(_p(x), _p(sten), ctypes.byref(by_t), _p(csr.perm_t), _p(zonal_ang), _p(zonal_mag),
+                                                     _p(phase), _p(y), _p(ang), _p(mag), _p(s1sum), N, csr.E, Cin, O, R, stride, dt, _stream()),
+                  'fc_trans_field_forward_generic')
+        ctx.save_for_backward(sten, zonal_ang, zonal_mag, phase, ang, mag, s1sum)
+        ctx.csr, ctx.ftype, ctx.stride, ctx.Cin, ctx.dt = csr, ftype, stride, Cin, dt
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        sten, zonal_ang, zonal_mag, phase, ang, mag, s1sum = ctx.saved_tensors
+        csr, Cin = ctx.csr, ctx.Cin
+        O, _, R = zonal_ang.shape
+        N = ang.shape[0]
+        gy = gy.contiguous()
+        with _on(gy.device):
+            gx = torch.empty((N, Cin), dtype=mag.dtype, device=gy.device)
+            g_za, g_zm = torch.empty_like(zonal_ang), torch.empty_like(zonal_mag)
+            g_ph = torch.empty_like(phase) if ctx.ftype != 0 else None
+            nbytes = lib.fc_trans_field_backward_generic_workspace_bytes(N, Cin, O, R, ctx.dt)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+            by_s = _csr(csr.rowptr_s, csr.nbr_s, None)
+            check(lib.fc_trans_field_backward_generic(_p(sten), ctypes.byref(by_s), _p(csr.perm_s), _p(zonal_ang), _p(zonal_mag), _p(phase),
+                                                      _p(ang), _p(mag), _p(s1sum), _p(gy), _p(gx), _p(g_za), _p(g_zm),
+                                                      _p(g_ph) if g_ph is not None else None, _p(ws), nbytes, N, csr.E, Cin, O, R, ctx.stride,
+                                                      ctx.ftype, ctx.dt, _stream()), 'fc_trans_field_backward_generic')
         return gx, None, g_za, g_zm, g_ph, None, None
 
 
+def trans_field_specialised(x, lift_sten, zonal_ang):
+    """True when the lane-mapped kernels of csrc/fc_trans_field.hip take this call: float32, <= 4 scalar inputs, <= 64 output channels,
+    <= 8 rings"""
+    O, Cin, R = zonal_ang.shape
+    return x.dtype == torch.float32 and lift_sten.dtype == torch.complex64 and Cin <= 4 and O <= MAX_CHANNELS and R <= 8
+
+
 def trans_field(x, supp_edges, lift_sten, zonal_ang, zonal_mag, phase, ftype):
-    """TransField on the device: (N,Cin) real features -> (N,O) complex64 (reference nn/trans_field.py:78-113)."""
+    """TransField on the device: (N,Cin) real features -> (N,O) complex (reference nn/trans_field.py:78-113); float32 / complex64 or,
+    like the reference's module under .double(), float64 / complex128 throughout; any sizes."""
     _require_device(x, 'trans_field')
-    if x.dtype != torch.float32 or x.dim() != 2 or lift_sten.dtype != torch.complex64:
-        raise ValueError('trans_field expects float32 features (N, Cin) and a complex64 stencil (E, R, 2)')
+    if x.dim() != 2 or (x.dtype, lift_sten.dtype) not in ((torch.float32, torch.complex64), (torch.float64, torch.complex128)):
+        raise ValueError('trans_field expects float32 features (N, Cin) with a complex64 stencil (E, R, 2), or float64 with complex128')
+    if zonal_ang.dtype != x.dtype or zonal_mag.dtype != x.dtype or phase.dtype != x.dtype:
+        raise ValueError(f'trans_field: features are {x.dtype} but the filters are {zonal_ang.dtype} (module.double() / .float())')
     O, Cin, R = zonal_ang.shape
     if x.shape[1] != Cin or lift_sten.dim() != 3 or lift_sten.shape[1] != R or lift_sten.shape[2] < 2:
         raise ValueError('trans_field: feature / stencil shapes do not match the zonal filters')
     if lift_sten.shape[2] > 2:          # the reference reads columns 0 and 1 of whatever it is given (classification.ipynb:195
-        lift_sten = lift_sten[..., :2]  # passes the full stencil); a strided view, read in place
-    if R > 8:
-        raise ValueError('trans_field supports at most 8 rings (n_rings 2..8 are compiled)')
-    from .graph import get_edge_csr
+        lift_sten = lift_sten[..., :2]  # passes the full stencil); a strided view, read in place (FCPrecomp's stand-in: materialised)
+    from .graph import LiftColumns, get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
-    if Cin > 4:
-        # The output is a SUM over the input channels of per-channel terms (reference nn/trans_field.py:104-113): more
-        # than four scalar inputs (the kernels' lanes hold (channel, ring) pairs of four channels) run as blocks of four.
-        out = None
-        for i0 in range(0, Cin, 4):
-            part = trans_field(x[:, i0:i0 + 4], supp_edges, lift_sten, zonal_ang[:, i0:i0 + 4], zonal_mag[:, i0:i0 + 4],
-                               phase[:, i0:i0 + 4], ftype)
-            out = part if out is None else out + part
-        return out
-    if O > MAX_CHANNELS:                   # the output channels are independent: blocks of 64 (one per lane)
-        return torch.cat([_TransFieldFn.apply(x, lift_sten, zonal_ang[o0:o0 + MAX_CHANNELS], zonal_mag[o0:o0 + MAX_CHANNELS],
-                                              phase[o0:o0 + MAX_CHANNELS], csr, int(ftype))
-                          for o0 in range(0, O, MAX_CHANNELS)], dim=1)
-    return _TransFieldFn.apply(x, lift_sten, zonal_ang, zonal_mag, phase, csr, int(ftype))
+    if not trans_field_specialised(x, lift_sten, zonal_ang):
+        if isinstance(lift_sten, LiftColumns):
+            lift_sten = lift_sten.materialize()
+        return _TransFieldGenericFn.apply(x, lift_sten, zonal_ang, zonal_mag, phase, csr, int(ftype))
+    sten, stride = _TransFieldFn._stencil(lift_sten)
+    return _TransFieldFn.apply(x, sten, stride, zonal_ang, zonal_mag, phase, csr, int(ftype))

@@ -231,8 +231,8 @@ class FactoredStencil:
         B = (self.F - 1) // 2
         if (self._dense is None and isinstance(idx, tuple) and len(idx) == 2 and idx[0] is Ellipsis and isinstance(idx[1], slice)
                 and idx[1].step in (None, 1) and idx[1].start == B and idx[1].stop == B + 2 and B >= 1):
-            if self._lift is None:
-                self._lift = self.columns(0, 2)
+            if self._lift is None:          # what the notebooks hand to LiftBlock: a stand-in as well (the kernels read the factor table)
+                self._lift = LiftColumns(self)
             return self._lift
         return self.materialize()[idx]
 
@@ -254,6 +254,59 @@ class FactoredStencil:
 
     def __repr__(self):
         return f'FactoredStencil(shape={tuple(self.shape)}, device={self.device}, dense={self._dense is not None})'
+
+
+class LiftColumns:
+    """`supp_sten[..., B:B+2]` of a FactoredStencil -- the stencil columns m = 0, 1 that the notebooks hand to LiftBlock (reference
+    segmentation.ipynb:204) -- without the (E,R,2) tensor: the TransField kernels form both columns from the (E,8) factor table on the
+    fly (fc_trans_field_forward with sten_stride = 0).  Shape / dtype / device of the tensor it stands for; any other use (indexing, torch
+    functions, tensor methods) materialises the two columns once and then behaves like that tensor."""
+
+    def __init__(self, stencil):
+        self.factors = stencil.factors
+        self._stencil = stencil
+        self.shape = torch.Size((int(stencil.shape[0]), stencil.R, 2))
+        self.dtype = torch.complex64
+        self.device = stencil.device
+        self.is_cuda = stencil.is_cuda
+        self.requires_grad = False
+        self._dense = None
+
+    def dim(self):
+        return 3
+
+    ndim = property(lambda self: 3)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def is_complex(self):
+        return True
+
+    def materialize(self):
+        if self._dense is None:
+            self._dense = self._stencil.columns(0, 2)
+        return self._dense
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getattr__(self, name):
+        if name.startswith('__') or name in ('factors', '_stencil', '_dense'):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        unwrap = lambda a: a.materialize() if isinstance(a, (LiftColumns, FactoredStencil)) else a
+        return func(*tuple(unwrap(a) for a in args), **{k: unwrap(v) for k, v in kwargs.items()})
+
+    def __repr__(self):
+        return f'LiftColumns(shape={tuple(self.shape)}, device={self.device}, dense={self._dense is not None})'
 
 
 def _shape_compiled(R, B):
@@ -474,7 +527,7 @@ def get_graph(supp_edges, supp_sten, N):
 class EdgeCSR:
     """The edge list grouped by target and by source, with the permutations that bring per-edge data (ln, wxp) into
     slot order.  Used by the ECHO descriptor kernels, which see the edges but no stencil (reference nn/echo.py:94)."""
-    __slots__ = ('N', 'E', 'rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', '_keep')
+    __slots__ = ('N', 'E', 'rowptr_t', 'nbr_t', 'perm_t', 'rowptr_s', 'nbr_s', 'perm_s', '_keep', '_plans')
 
     def __init__(self, supp_edges, N):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -482,6 +535,7 @@ class EdgeCSR:
         dev = supp_edges.device
         self.N, self.E = int(N), int(supp_edges.shape[0])
         self._keep = supp_edges
+        self._plans = {}           # per-mesh derived data of the users (slot-ordered ln / wxp of the ECHO kernels)
         src = supp_edges[:, 0].to(torch.int64)
         dst = supp_edges[:, 1].to(torch.int64)
 
@@ -510,6 +564,7 @@ class EdgeCSR:
     def from_support_graph(cls, sg, supp_edges):
         g = cls.__new__(cls)
         g.N, g.E, g._keep = sg.N, sg.E, supp_edges
+        g._plans = {}
         g.rowptr_t, g.nbr_t, g.perm_t = sg.rowptr_t, sg.nbr_t, sg.perm_t
         g.rowptr_s, g.nbr_s, g.perm_s = sg.rowptr_s, sg.nbr_s, sg.perm_s
         return g

@@ -307,10 +307,10 @@ int fc_tangent_nonlin_backward_f64(const double* x, const double* bias, const do
 /* ---- ECHO descriptors, reference nn/echo.py:94-148 (ECHO.forward with rasterize :30-61, diskMap :11-27) ---- *
  * hist[n,c,b] = sum over in-edges e of n of the bilinear votes of the point ln[e] * exp(-i angle(x[src_e,c])) in the
  * rasterised disk of (2*n_bins+1)^2 cells, each vote carrying x[src_e,c] * wxp[e]; zero features do not vote; the
- * descriptor is |hist| (zero-safe).  x (N,C) c64, C <= 64; ln_t / wxp_t (E) c64 in by_target slot order; hist
- * (N,C,dS) c64 and desc (N,C,dS) f32 are overwritten, dS = fc_echo_hist_dim(n_bins), 1 <= n_bins <= 8;
- * C <= fc_echo_channel_block(n_bins) per call (64 up to n_bins = 4, then 57, 42, 30, 23: the histograms of a workgroup live in LDS;
- * channels are independent, wider inputs go in blocks).
+ * descriptor is |hist| (zero-safe).  x (N,C) c64, any C; ln_t / wxp_t (E) c64 in by_target slot order; hist
+ * (N,C,dS) c64 and desc (N,C,dS) f32 are overwritten, dS = fc_echo_hist_dim(n_bins), 1 <= n_bins <= 8.  The channels are
+ * independent: a call launches ceil(C / fc_echo_channel_block(n_bins)) channel blocks (64 up to n_bins = 4, then 57, 42, 30, 23: one
+ * channel per lane, the histograms of a workgroup in LDS).  Any n_bins, and double precision: fc_echo_forward_generic below.
  * Backward: by_source groups the edges by source (nbr = targets), ln_s / wxp_s in that slot order; g_desc (N,C,dS) f32;
  * gx (N,C) c64 is overwritten; hist_grad_workspace: N*C*dS complex64 values of scratch. */
 int fc_echo_hist_dim(int32_t n_bins);
@@ -324,7 +324,8 @@ int fc_echo_backward(const float* x, const float* ln_s, const float* wxp_s, cons
 /* ---- TransField (the learned 'gradient' of LiftBlock), reference nn/trans_field.py:78-113, weightContrib* :9-24 ---- *
  * x (N,Cin) f32 scalar features, Cin <= 4; lift_sten: the stencil columns m = 0, 1 (reference segmentation.ipynb:204)
  * in ORIGINAL edge order, element (e,r,j) at complex index (e*R + r)*sten_stride + j -- sten_stride = 2 for a packed
- * (E,R,2) array, 2B+1 for a pointer to column m = 0 of the full (E,R,2B+1) stencil; by_target / by_source: the edges grouped by target / source with
+ * (E,R,2) array, 2B+1 for a pointer to column m = 0 of the full (E,R,2B+1) stencil, 0 when lift_sten is the (E,8) factor table of
+ * fc_precomp_graph (the two columns are then formed on the fly: w_r c and w_r c e^{i theta}; no (E,R,2) array exists); by_target / by_source: the edges grouped by target / source with
  * slot_to_edge (E) int64 giving the original edge of every slot; zonal_ang, zonal_mag (O,Cin,R) f32, phase (O,Cin) f32
  * (zeros for ftype 0); y (N,O) c64, O <= 64.  The forward call also leaves ang (N,Cin,R) c64, mag (N,Cin,R) f32 and
  * s1sum (N,R) c64 for the backward call, which overwrites gx (N,Cin) f32 and the parameter gradients (g_phase for
@@ -388,7 +389,7 @@ int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* 
 /* The tangent-feature half of ECHOBlock: desc = ECHO(modReLU(conv(x))), reference nn/echo_block.py:93-94 (the MLP on the descriptors
  * and the linear residual on |x|, :95-103, are the reference's own nn.Linear layers and stay with the caller).  conv: (n_des, C_in)
  * filter; bias: the first n_des entries of the module's TangentNonLin bias (:57,93); ln_* / wxp_* (E) c64 in by_target / by_source slot
- * order as for fc_echo_forward / fc_echo_backward; desc (N, n_des, fc_echo_hist_dim(n_bins)) f32; n_des <= fc_echo_channel_block(n_bins). */
+ * order as for fc_echo_forward / fc_echo_backward; desc (N, n_des, fc_echo_hist_dim(n_bins)) f32. */
 typedef struct fc_echo_block_params {
     int32_t C_in, n_des, n_bins;
     fc_filter_params conv;
@@ -424,6 +425,32 @@ int fc_lift_block_forward(const float* x, const float* lift_sten, int32_t sten_s
 int fc_lift_block_backward(const float* g_out, const float* lift_sten, int32_t sten_stride, const fc_mesh* mesh, const int64_t* slot_to_edge_s,
                            const fc_lift_block_params* p, const void* saved, size_t saved_bytes, float* gx, void* workspace,
                            size_t workspace_bytes, void* stream);
+
+/* ---- TransField and ECHO outside the specialised kernels' range: any number of scalar inputs / output channels / rings / raster bins,
+ * float32 or float64 (dtype: fc_dtype of every tensor; the reference's TransField / LiftBlock run under .double(), nn/trans_field.py:78-113;
+ * its ECHO and FCPrecomp do not -- both raise a dtype error -- so the float64 ECHO here has no reference counterpart).  Run-time loops, one
+ * thread per output entry, fixed summation order: a correctness path.  Same arguments as the specialised calls; lift_sten is a complex array
+ * (float2 / double2 elements) with sten_stride >= 2 (no factor table); the backward workspace is
+ * fc_trans_field_backward_generic_workspace_bytes(...) bytes; the ECHO calls take fc_echo_generic_workspace_bytes(n_bins) bytes of scratch
+ * (the raster map) and dS = fc_echo_hist_dim_generic(n_bins). */
+int fc_trans_field_forward_generic(const void* x, const void* lift_sten, const fc_csr* by_target, const int64_t* slot_to_edge,
+                                   const void* zonal_ang, const void* zonal_mag, const void* phase, void* y, void* ang, void* mag,
+                                   void* s1sum, int32_t N, int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride, int32_t dtype,
+                                   void* stream);
+size_t fc_trans_field_backward_generic_workspace_bytes(int32_t N, int32_t Cin, int32_t O, int32_t R, int32_t dtype);
+int fc_trans_field_backward_generic(const void* lift_sten, const fc_csr* by_source, const int64_t* slot_to_edge_s, const void* zonal_ang,
+                                    const void* zonal_mag, const void* phase, const void* ang, const void* mag, const void* s1sum,
+                                    const void* gy, void* gx, void* g_zonal_ang, void* g_zonal_mag, void* g_phase, void* workspace,
+                                    size_t workspace_bytes, int32_t N, int32_t E, int32_t Cin, int32_t O, int32_t R, int32_t sten_stride,
+                                    int32_t ftype, int32_t dtype, void* stream);
+int fc_echo_hist_dim_generic(int32_t n_bins);
+size_t fc_echo_generic_workspace_bytes(int32_t n_bins);
+int fc_echo_forward_generic(const void* x, const void* ln_t, const void* wxp_t, const fc_csr* by_target, void* hist, void* desc,
+                            void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t C, int32_t n_bins, int32_t dtype,
+                            void* stream);
+int fc_echo_backward_generic(const void* x, const void* ln_s, const void* wxp_s, const fc_csr* by_source, const void* hist,
+                             const void* g_desc, void* gx, void* hist_grad_workspace, void* workspace, size_t workspace_bytes, int32_t N,
+                             int32_t E, int32_t C, int32_t n_bins, int32_t dtype, void* stream);
 
 /* ---- support-graph build (what every FieldConv needs before its first launch on a mesh) ---------------------------- *
  * From the operator's own inputs (reference nn/field_conv.py:104-121): supp_edges (E,2) int64, col 0 = source, col 1 =

@@ -234,6 +234,30 @@ def echo_lift_cases(out):
             rec['g_' + name] = np_(gval)
         out[f'lift_block_t{ftype}'] = rec
 
+    # LiftBlock / TransField in double precision: the reference's module runs under .double() (its ECHO and FCPrecomp do not -- both
+    # raise "Index put requires the source and destination dtypes match" -- so the stencil is FCPrecomp's float32 one, cast).  More scalar
+    # inputs and output channels than the float32 cases; a generator of its own, so the cases above keep their values.
+    g64 = torch.Generator().manual_seed(901)
+    torch.manual_seed(901)
+    for ftype in (0, 1):
+        Cin, Cout = 5, 7
+        xs = torch.randn(N, Cin, generator=g64, dtype=torch.float64).requires_grad_(True)
+        lift = refnn.LiftBlock(Cin, Cout, n_rings=R, ftype=ftype).double()
+        with torch.no_grad():
+            lift.nonlin.bias.copy_(torch.randn(lift.nonlin.bias.shape, generator=g64, dtype=torch.float64) * 0.05)
+        lsten = sten[..., B:B + 2].to(torch.cdouble)
+        y = lift(xs, edges, lsten)
+        gy = rand_c(g64, N, Cout, dtype=torch.cdouble)
+        params = dict(lift.named_parameters())
+        grads = torch.autograd.grad(y, [xs] + list(params.values()), grad_outputs=gy)
+        rec = dict(x=np_(xs), edges=np_(edges), lift_sten=np_(lsten), y=np_(y), gy=np_(gy), gx=np_(grads[0]),
+                   Cin=Cin, Cout=Cout, R=R, ftype=ftype)
+        for name, t in lift.state_dict().items():
+            rec['p_' + name] = np_(t)
+        for (name, _), gval in zip(params.items(), grads[1:]):
+            rec['g_' + name] = np_(gval)
+        out[f'lift_block_t{ftype}_f64'] = rec
+
 
 def net_cases(out):
     """The segmentation network's topology (reference segmentation.ipynb:165-236): LiftBlock(3 -> nf),

@@ -202,7 +202,10 @@ def test_echo_block_and_lift_block_golden(dev):
 @pytest.mark.parametrize('N,k,Cin,O,R,ftype', [(700, 9, 3, 32, 6, 1), (257, 5, 4, 64, 8, 1), (130, 12, 1, 5, 2, 0), (64, 0, 3, 16, 6, 1),
                                              (100, 80, 3, 48, 6, 1), (90, 40, 2, 16, 4, 1),      # 4 / 2 wavefronts per vertex
                                              (120, 7, 3, 150, 6, 1),                              # output channels in blocks of 64
-                                             (150, 9, 7, 20, 5, 1), (90, 6, 10, 70, 6, 0)])       # more than four scalar inputs: blocks of 4
+                                             (150, 9, 7, 20, 5, 1), (90, 6, 10, 70, 6, 0),        # more than four scalar inputs
+                                             (80, 8, 3, 16, 10, 1)])                              # more than eight rings
+# (shapes outside the lane-mapped kernels' range -- > 4 inputs, > 64 outputs, > 8 rings -- take the run-time kernels of
+#  csrc/fc_lift_echo_generic.hip from ONE native call per pass)
 def test_trans_field_kernels_vs_host_composite(dev, N, k, Cin, O, R, ftype):
     """The TransField kernels against the oracle's torch restatement run on the CPU in float64 (pinned to the reference
     fixtures by the CPU suite): ragged in-degrees, isolated vertices, a strided stencil view."""
@@ -937,7 +940,8 @@ def test_native_graph_build_hub_vertex(dev):
 
 
 @pytest.mark.parametrize('N,k,C,n_bins', [(100, 80, 48, 3), (90, 40, 17, 2), (300, 9, 64, 1), (70, 66, 5, 4), (60, 10, 130, 2),
-                                          (80, 30, 48, 6), (50, 24, 30, 8), (64, 20, 64, 5)])   # n_bins > 4: channel blocks by LDS
+                                          (80, 30, 48, 6), (50, 24, 30, 8), (64, 20, 64, 5),    # n_bins > 4: channel blocks by LDS
+                                          (40, 12, 9, 10)])                                     # n_bins > 8: the run-time kernels
 def test_echo_kernels_vs_host_composite(dev, N, k, C, n_bins):
     """ECHO descriptor kernels against the oracle's torch restatement run on the CPU in float64 (pinned to the reference
     fixtures by the CPU suite), on supports wide enough that 2 or 4 wavefronts share a vertex, with ragged degrees and
@@ -1181,6 +1185,85 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize('N,k,B,R', [(300, 20, 2, 6), (1024, 128, 2, 6), (90, 9, 1, 3), (150, 12, 3, 8)])
+def test_lift_block_reads_the_factor_table(dev, N, k, B, R):
+    """`supp_sten[..., B:B+2]` of FCPrecomp's stencil stand-in (what the notebooks hand to LiftBlock, reference segmentation.ipynb:204) is a
+    stand-in too: the TransField kernels form the two columns w_r c, w_r c e^{i theta} from the (E,8) factor table (sten_stride 0) and
+    no (E,R,2) array is built.  Same output and gradients as with the materialised columns; nothing gets materialised."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.graph import LiftColumns
+    from fieldconv_amd.nn import LiftBlock
+    from fieldconv_amd.transforms import FCPrecomp
+    data = sphere_support(N, k, seed=N).to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    lift_sten = sten[..., B:B + 2]
+    assert isinstance(lift_sten, LiftColumns) and tuple(lift_sten.shape) == (edges.shape[0], R, 2) and lift_sten.dtype == torch.complex64
+    torch.manual_seed(N)
+    mod = LiftBlock(3, 24, n_rings=R, ftype=1).to(dev)
+    with torch.no_grad():
+        mod.nonlin.bias.uniform_(-0.3, 0.1)
+    g = torch.Generator().manual_seed(N)
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    gy = torch.complex(torch.randn(N, 24, generator=g), torch.randn(N, 24, generator=g)).to(dev)
+    params = list(mod.parameters())
+    out = []
+    for use_table in (True, False):
+        x = pos.clone().requires_grad_(True)
+        arg = lift_sten if use_table else sten.columns(0, 2)          # the dense (E,R,2) tensor the stand-in stands for
+        y = mod(x, edges, arg)
+        out.append((y.detach(),) + torch.autograd.grad(y, [x] + params, grad_outputs=gy))
+    assert lift_sten._dense is None and sten._dense is None             # nothing was materialised on the way
+    for a, b in zip(*out):
+        assert rel_err(H(a), H(b)) < 2e-6
+    # and the stand-in still behaves like the tensor when something else asks
+    assert torch.equal(lift_sten[:5], sten.columns(0, 2)[:5]) and lift_sten.abs().shape == (edges.shape[0], R, 2)
+
+
+@pytest.mark.parametrize('ftype', [0, 1])
+def test_lift_block_golden_f64(ftype, dev):
+    """LiftBlock(...).double() -- the reference's TransField / LiftBlock run in double precision (nn/trans_field.py:78-113,
+    nn/lift_block.py:53-55) -- against the reference's own float64 run (fixtures lift_block_t*_f64: 5 scalar inputs, 7 output channels):
+    output, input gradient and every parameter gradient to 1e-12 (csrc/fc_lift_echo_generic.hip + fc_tangent_nonlin_*_f64)."""
+    from fieldconv_amd.nn import LiftBlock
+    c = load_golden('echo_lift.npz')[f'lift_block_t{ftype}_f64']
+    m = load_params(LiftBlock(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ftype).double(), c).to(dev)
+    xs = D(c['x'], dev).requires_grad_(True)
+    y = m(xs, D(c['edges'], dev), D(c['lift_sten'], dev))
+    assert y.dtype == torch.complex128 and rel_err(H(y), c['y']) < 1e-12
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(y, [xs] + list(params.values()), grad_outputs=D(c['gy'], dev))
+    assert grads[0].dtype == torch.float64 and rel_err(H(grads[0]), c['gx']) < 1e-12
+    for (name, _), gval in zip(params.items(), grads[1:]):
+        assert rel_err(H(gval), c['g_' + name]) < 1e-12, name
+
+
+def test_echo_descriptors_in_double_precision(dev):
+    """ECHO descriptors of complex128 features (run-time kernels, csrc/fc_lift_echo_generic.hip) against the oracle's torch restatement in
+    float64 -- the reference's own ECHO raises for double inputs, so there is no reference run to capture; the restatement is pinned to the
+    reference's float32 fixtures by the CPU suite.  In double precision no vote flips a raster cell: 1e-12 on every entry."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import ECHO
+    from oracle.torch_composites import FCPrecomp, echo_descriptors as echo_ref
+    N, k, C = 70, 14, 6
+    data = sphere_support(N, k, seed=7)
+    edges, _, ln, wxp = FCPrecomp(1, 3, float(data.logMag.max()) * 1.0001)(data)
+    g = torch.Generator().manual_seed(7)
+    ln = torch.where(ln.abs() < 1e-6, torch.zeros_like(ln), ln).to(torch.complex128) * 0.999
+    wxp = wxp.to(torch.complex128)
+    x = torch.complex(torch.randn(N, C, generator=g, dtype=torch.float64), torch.randn(N, C, generator=g, dtype=torch.float64))
+    x[torch.rand(N, C, generator=g) < 0.05] = 0
+    for n_bins in (2, 11):
+        xr = x.clone().requires_grad_(True)
+        dr = echo_ref(xr, edges, ln, wxp, n_bins)
+        gd = torch.randn(dr.shape, generator=g, dtype=torch.float64)
+        gr, = torch.autograd.grad(dr, [xr], grad_outputs=gd)
+        xd = x.to(dev).requires_grad_(True)
+        dd = ECHO(C, n_bins).to(dev)(xd, edges.to(dev), ln.to(dev), wxp.to(dev))
+        gg, = torch.autograd.grad(dd, [xd], grad_outputs=gd.to(dev))
+        assert dd.dtype == torch.float64 and dd.shape == dr.shape
+        assert rel_err(H(dd), dr.detach().numpy()) < 1e-12 and rel_err(H(gg), gr.numpy()) < 1e-11
 
 
 # ------------------------------------------------------------------ double precision (the reference's modules run under .double())

@@ -255,6 +255,19 @@ def test_trans_field_matches_reference(ftype):
     # LiftBlock output = modReLU(TransField); check through the oracle's modReLU
     out = orc.tangent_nonlin_forward(y.detach().numpy(), c['p_nonlin.bias'])
     assert rel_err(out, c['y']) < 5e-6
+    # the reference's LiftBlock under .double() (5 scalar inputs, 7 output channels): output and every gradient at double precision
+    c = load_golden('echo_lift.npz')[f'lift_block_t{ftype}_f64']
+    m = TransField(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ftype).double()
+    m.load_state_dict({k[len('p_field.'):]: T(v) for k, v in c.items() if k.startswith('p_field.')})
+    bias = T(c['p_nonlin.bias']).requires_grad_(True)
+    x = T(c['x']).requires_grad_(True)
+    y = tc.tangent_nonlin(tc.trans_field(x, T(c['edges']), T(c['lift_sten']), m.zonalAng, m.zonalMag, m.phase, ftype), bias)
+    assert y.dtype == torch.complex128 and rel_err(y.detach().numpy(), c['y']) < 1e-13
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(y, [x, bias] + list(params.values()), grad_outputs=T(c['gy']))
+    assert rel_err(grads[0].numpy(), c['gx']) < 1e-12 and rel_err(grads[1].numpy(), c['g_nonlin.bias']) < 1e-12
+    for (name, _), gval in zip(params.items(), grads[2:]):
+        assert rel_err(gval.numpy(), c['g_field.' + name]) < 1e-12, name
 
 
 def test_factored_and_geometric_records_reconstruct_the_stencil():
