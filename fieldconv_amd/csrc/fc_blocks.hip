@@ -84,10 +84,13 @@ static bool filter_params_ok(const fc_filter_params& f, bool backward) {
     return true;
 }
 
+// packed = true: the images were written by an earlier launch of this pass (pack_filter_params_pair_impl)
 static int conv_forward(const float* x, const fc_mesh* m, const fc_dims* d, const fc_filter_params& f, float* wpk_f, float* wpk_b, float* y,
-                        const fc_epilogue* epi, void* ws, size_t ws_bytes, int records, hipStream_t st) {
-    int rc = pack_filter_params_impl(f.zonal, f.spherical, f.phase, f.ftype, wpk_f, wpk_b, d, records, st);
-    if (rc != FC_OK) return rc;
+                        const fc_epilogue* epi, void* ws, size_t ws_bytes, int records, hipStream_t st, bool packed = false) {
+    if (!packed) {
+        const int rc = pack_filter_params_impl(f.zonal, f.spherical, f.phase, f.ftype, wpk_f, wpk_b, d, records, st);
+        if (rc != FC_OK) return rc;
+    }
     const size_t need = records ? forward_workspace_bytes(d, m->kind) : 0;
     const bool give = need != 0 && need <= ws_bytes;
     return forward_impl(x, m->fwd, m->by_target, wpk_f, y, d, m->kind, give ? ws : nullptr, give ? need : 0, epi, st);
@@ -127,16 +130,19 @@ int fc_resnet_block_forward(const float* x, const fc_mesh* mesh, const fc_resnet
     float* wpk_f2 = ws.take(pl.wpk_f2);
     float* res_out = ws.take(pl.res_out);
     void* fws = ws.take(pl.fwd_ws);
+    // both convolutions' filter images (forward and backward) from one launch: the parameters are all known now
+    int rc = fc::pack_filter_params_pair_impl(p->conv1, wpk_f1, wpk_b1, &pl.d1, p->conv2, wpk_f2, wpk_b2, &pl.d2, pl.records, st);
+    if (rc != FC_OK) return rc;
     // h = modReLU_1(conv1(x)): the modReLU in the convolution's epilogue (pre1 = the pre-activation its VJP needs)
     fc_epilogue e1 = {nullptr, p->bias1, act1};
-    int rc = fc::conv_forward(x, mesh, &pl.d1, p->conv1, wpk_f1, wpk_b1, pre1, &e1, fws, pl.fwd_ws, pl.records, st);
+    rc = fc::conv_forward(x, mesh, &pl.d1, p->conv1, wpk_f1, wpk_b1, pre1, &e1, fws, pl.fwd_ws, pl.records, st, true);
     if (rc != FC_OK) return rc;
     // res(x)
     rc = fc_tangent_lin_forward(x, p->res_re, p->res_im, res_out, mesh->N, p->C_in, p->C_out, stream);
     if (rc != FC_OK) return rc;
     // out = modReLU_2(res(x) + conv2(h)): residual add and modReLU in conv2's epilogue
     fc_epilogue e2 = {res_out, p->bias2, out};
-    return fc::conv_forward(act1, mesh, &pl.d2, p->conv2, wpk_f2, wpk_b2, pre2, &e2, fws, pl.fwd_ws, pl.records, st);
+    return fc::conv_forward(act1, mesh, &pl.d2, p->conv2, wpk_f2, wpk_b2, pre2, &e2, fws, pl.fwd_ws, pl.records, st, true);
 }
 
 int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* mesh, const fc_resnet_block_params* p, const void* saved,

@@ -73,15 +73,26 @@ int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const f
     a.dbg = dbg;
     a.stamps = debug_stamp_buffer();
     const int nvt = a.ntiles << a.parts_log2;
-    const int grid = nvt < 2 * num_cus() ? nvt : 2 * num_cus();      // persistent: two workgroups per CU
+    int grid = nvt < 2 * num_cus() ? nvt : 2 * num_cus();            // persistent: two workgroups per CU
     // the last, partly filled round: as half tiles when those still fit one round
     const int rem = nvt % grid;
     a.nv_full = nvt;
     a.nv_total = nvt;
+    a.spread_cus = 0;
     static const bool halves = !(dev_env("FC_RING_HALVES") && atoi(dev_env("FC_RING_HALVES")) == 0);
     if (halves && a.parts_log2 == 0 && rem > 0 && 2 * rem <= grid) {
         a.nv_full = nvt - rem;
         a.nv_total = a.nv_full + 2 * rem;
+    }
+    // Between one and two workgroups per CU (a FAUST-sized mesh: 313 tiles on 256 CUs) whole tiles would leave some CUs with two of
+    // them and the rest with one: as many half tiles as fill every slot instead -- W whole + 2 (nvt - W) half tiles = 2 cus items, one per
+    // workgroup, a CU holding at most a whole and a half tile (RingArgs::spread_cus)
+    const int cus = num_cus();
+    if (halves && a.parts_log2 == 0 && nvt > cus && nvt < 2 * cus) {
+        a.nv_full = 2 * nvt - 2 * cus;
+        a.nv_total = 2 * cus;
+        a.spread_cus = cus;
+        grid = 2 * cus;
     }
     int rc = FC_ERR_UNSUPPORTED;
     const float2* x2 = reinterpret_cast<const float2*>(x);

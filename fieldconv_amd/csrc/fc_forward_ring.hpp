@@ -44,6 +44,10 @@ struct RingArgs {
                             // wavefront): the last, partly filled round of a persistent grid is cut in two so that every
                             // workgroup gets a share of it (1250 tiles on 512 workgroups: 2.6 tile times instead of 3)
     int nv_total;           // work items in all
+    int spread_cus;         // > 0: ONE item per workgroup on a grid of 2 * spread_cus workgroups (a mesh between one and two rounds of
+                            // whole tiles, e.g. a FAUST-sized one: 313 tiles on 256 CUs) -- the nv_full whole tiles are dealt evenly to
+                            // the first spread_cus workgroups, every other workgroup takes a half tile, so that a CU holds a whole and a
+                            // half tile or two half tiles instead of two whole tiles on some CUs and one on the others (ring_item)
     uint32_t wpk_bytes;
     uint32_t slab_bytes_w;  // bytes of one ring's planes in the packed image: 2 * halves * MP * KP * 2
     int dbg;                // development only (FC_DEBUG): bit0 skip gather, bit1 skip MFMA
@@ -59,6 +63,15 @@ __host__ __device__ inline MmaGeom ring_geom(int M, int F, int channels, int hal
     if (g.NKP > g.KST) g.NKP = g.KST;
     if (g.NKP < 1) g.NKP = 1;
     return g;
+}
+
+// Work item of workgroup `b`'s first (with spread_cus: only) pass.
+__device__ __forceinline__ int ring_item(const RingArgs& a) {
+    if (a.spread_cus == 0) return first_tile_of_block();
+    const int b = blockIdx.x, C = a.spread_cus, W = a.nv_full;
+    if (b >= C) return a.nv_full + (C - W) + (b - C);          // the second workgroup of a CU: always a half tile
+    const int w0 = (b * W) / C, w1 = ((b + 1) * W) / C;        // whole tiles before / up to this workgroup, evenly spaced
+    return w1 > w0 ? w0 : a.nv_full + (b - w0);
 }
 
 struct RingLds {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
     int beg[2], end[2], par = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        slot_range(first_tile_of_block(), j, 0, beg[j], end[j]);
+        slot_range(ring_item(a), j, 0, beg[j], end[j]);
         const int nch = (end[j] - beg[j] + CR - 1) >> LOG_CR;
         for (int ch = 0; ch < min(nch, nr); ++ch) dma_chunk(j, beg[j], ch);
     }
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(kDuoThreads, 4) void fc_forward_ring_kernel(
 
     stamp.realtime(29);
     stamp(28);
-    for (int vt = first_tile_of_block(); vt < a.nv_total; vt += gridDim.x) {
+    for (int vt = ring_item(a); vt < a.nv_total; vt += gridDim.x) {
         int nbeg[2], nend[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) slot_range(vt + gridDim.x, j, par ^ 1, nbeg[j], nend[j]);

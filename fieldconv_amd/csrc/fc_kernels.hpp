@@ -46,6 +46,9 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
 int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream);
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
                             float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream);
+// the filter images of TWO layers from one launch (an FCResNetBlock's two convolutions)
+int pack_filter_params_pair_impl(const fc_filter_params& f0, float* fwd0, float* bwd0, const fc_dims* d0, const fc_filter_params& f1,
+                                 float* fwd1, float* bwd1, const fc_dims* d1, int records, hipStream_t stream);
 size_t packed_filter_floats_fwd(const fc_dims* d, int records);
 size_t packed_filter_floats_bwd(const fc_dims* d, int records);
 

