@@ -627,6 +627,23 @@ def run_net(args, world, rank, dev, use_dist, backend):
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
+        # (0) what the HOST needs to enqueue a step: a few steps issued behind a synchronisation, timed until the last call returns
+        #     (the launch queue is far from full after five steps, so nothing here waits for the GPU)
+        def host_enqueue_ms(fn, n=5, reps=5):
+            best = None
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                dt = (time.perf_counter() - t0) / n * 1e3
+                best = dt if best is None else min(best, dt)
+            torch.cuda.synchronize()
+            return best
+        out['host_enqueue_ms_per_step'] = {'block_level_calls': host_enqueue_ms(step),
+                                           'note': 'host time to enqueue one step (Python, autograd, ctypes, allocator): five steps issued '
+                                                   'behind a synchronisation, timed until the last call returns, best of five; the step is '
+                                                   'GPU-bound while this stays below the replayed time'}
         # (1) the same step replayed as one HIP graph: the GPU-side floor of this schedule
         try:
             from fieldconv_amd.utils import StepGraph
@@ -640,6 +657,7 @@ def run_net(args, world, rank, dev, use_dist, backend):
         # (2) the per-operator host path (FIELDCONV_BLOCK_CALLS=0: ~80 foreign calls per step instead of 12)
         os.environ['FIELDCONV_BLOCK_CALLS'] = '0'
         try:
+            out['host_enqueue_ms_per_step']['per_operator_calls'] = host_enqueue_ms(step)
             out['per_operator_calls'] = {'ms_per_step': timeit(step), 'note': 'the same step with every block composed of per-operator autograd '
                                                                               'nodes and foreign calls (FIELDCONV_BLOCK_CALLS=0)'}
         finally:
@@ -887,7 +905,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
                     'note': 'HIP events on every 4th launch in the instrumented pass straight behind the literal timed region (the timed '
                             'region itself carries no events).  Not HBM-bound: the walks of the gathers pay for their vector arithmetic, '
                             'their row fetches (one per ~28 cycles and CU whatever the cache level) and their record reads one after '
-                            'the other (tools/ubench/walk.hip, DESIGN 3.11), with the matrix pipe and HBM mostly idle; achieved = '
+                            'the other (tools/ubench/walk.hip, DESIGN 5), with the matrix pipe and HBM mostly idle; achieved = '
                             'algorithmic bytes / launch time as SURVEY 8(d) prescribes'}
         # the bound the kernels live under: of all vector instructions the dominant kernel issues, how many are the gather's
         # own arithmetic (2 + 2B complex products and 2F ring updates per edge, packed: 2 instructions per complex product)

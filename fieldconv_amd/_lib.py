@@ -122,6 +122,8 @@ SIGNATURES = {
     'fc_tangent_lin_forward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int32, _c_int32, _c_int32, _vp]),
     'fc_tangent_lin_backward_workspace_bytes': (_sz, [_c_int32, _c_int32, _c_int32]),
     'fc_tangent_lin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _c_int32, _vp]),
+    'fc_soft_abs_forward': (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    'fc_soft_abs_backward': (ctypes.c_int, [_vp, _vp, _vp, _sz, _vp]),
     'fc_tangent_nonlin_forward': (ctypes.c_int, [_vp, _vp, _vp, _c_int32, _c_int32, _vp]),
     'fc_tangent_nonlin_backward_workspace_bytes': (_sz, [_c_int32, _c_int32]),
     'fc_tangent_nonlin_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _c_int32, _c_int32, _vp]),

@@ -67,30 +67,27 @@ def _filter_params(conv_tensors, ftype, grads=None):
                           grads[2].data_ptr() if grads[2] is not None else None)
 
 
-def _carve(flat, shapes):
-    """views of one flat float32 buffer, one per shape (None entries stay None and take no room)"""
-    out, off = [], 0
-    for shp in shapes:
-        if shp is None:
-            out.append(None)
-            continue
-        n = 1
-        for d in shp:
-            n *= d
-        out.append(flat[off:off + n].view(shp))
-        off += (n + 3) // 4 * 4             # 16-byte aligned pieces
-    return out
-
-
-def _carve_size(shapes):
-    total = 0
+def _carve_alloc(shapes, dev, zero=False):
+    """one flat float32 buffer and a view of it per shape (None entries stay None and take no room); pieces 16-byte aligned"""
+    sizes = []
     for shp in shapes:
         if shp is not None:
             n = 1
             for d in shp:
                 n *= d
-            total += (n + 3) // 4 * 4
-    return total
+            sizes.append((n + 3) // 4 * 4)
+    flat = (torch.zeros if zero else torch.empty)(sum(sizes), dtype=torch.float32, device=dev)
+    parts = iter(flat.split(sizes))
+    out = []
+    for shp in shapes:
+        if shp is None:
+            out.append(None)
+        else:
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(next(parts)[:n].view(shp) if n % 4 else next(parts).view(shp))
+    return out
 
 
 def _u8(nbytes, dev):
@@ -142,8 +139,7 @@ class _ResnetBlockFn(torch.autograd.Function):
                   b2.shape, re_w.shape, im_w.shape]
         with Fn._on(dev):
             gx = torch.empty_like(x)
-            flat = torch.empty(_carve_size(shapes), dtype=torch.float32, device=dev)
-            g_z1, g_s1, g_p1, g_b1, g_z2, g_s2, g_p2, g_b2, g_re, g_im = _carve(flat, shapes)
+            g_z1, g_s1, g_p1, g_b1, g_z2, g_s2, g_p2, g_b2, g_re, g_im = _carve_alloc(shapes, dev)
             ws = _u8(sizes[2], dev)
             bp = FcResnetBlockParams(C_in, C_mid, C_out, _filter_params((z1, s1, p1), ftype, (g_z1, g_s1, g_p1)),
                                      _filter_params((z2, s2, p2), ftype, (g_z2, g_s2, g_p2)), b1.data_ptr(), b2.data_ptr(),
@@ -169,17 +165,28 @@ def _conv_ok(conv, graph, x, channels=None):
     return ok
 
 
+def _conv_tensors(conv):
+    """(zonal, spherical, phase) of a FieldConv without nn.Module.__getattr__'s fallback chain (phase is a parameter for ftype 1, else a buffer)"""
+    p = conv._parameters
+    ph = p.get('phase')
+    return p['zonal'], p['spherical'], ph if ph is not None else conv._buffers['phase']
+
+
 def resnet_block(block, x, graph):
     """FCResNetBlock.forward through the block-level entry points, or None when they do not apply"""
     if not (enabled() and Fn.on_device(x) and _plain_graph(graph)):
         return None
-    c1, c2 = block.conv1, block.conv2
+    mods = block._modules
+    c1, c2, res = mods['conv1'], mods['conv2'], mods['res']
     if c1.ftype != c2.ftype or c1.B != c2.B or not _conv_ok(c1, graph, x) or not _conv_ok(c2, graph, x, c1.out_channels):
         return None
-    if max(block.res.Re.shape) > Fn.MAX_CHANNELS:
+    if res.in_channels > Fn.MAX_CHANNELS or res.out_channels > Fn.MAX_CHANNELS:
         return None
-    return _ResnetBlockFn.apply(x, c1.zonal, c1.spherical, c1.phase, block.nonlin1.bias, c2.zonal, c2.spherical, c2.phase,
-                                block.nonlin2.bias, block.res.Re, block.res.Im, int(c1.ftype), int(c1.B), graph)
+    z1, s1, p1 = _conv_tensors(c1)
+    z2, s2, p2 = _conv_tensors(c2)
+    rp = res._parameters
+    return _ResnetBlockFn.apply(x, z1, s1, p1, mods['nonlin1']._parameters['bias'], z2, s2, p2, mods['nonlin2']._parameters['bias'],
+                                rp['Re'], rp['Im'], int(c1.ftype), int(c1.B), graph)
 
 
 # --------------------------------------------------------------------------------------------------------------------- ECHOBlock
@@ -222,10 +229,8 @@ class _EchoBlockFn(torch.autograd.Function):
         shapes = [zonal.shape, spherical.shape, phase.shape if ftype == 1 else None, bias.shape]
         with Fn._on(dev):
             gx = torch.empty_like(x)
-            n_flat = _carve_size(shapes)
             # the module's bias has in_channels entries of which the first n_des act (reference nn/echo_block.py:57,93): the rest get zero
-            flat = (torch.zeros if bias.numel() > ctx.n_des else torch.empty)(n_flat, dtype=torch.float32, device=dev)
-            g_z, g_s, g_p, g_b = _carve(flat, shapes)
+            g_z, g_s, g_p, g_b = _carve_alloc(shapes, dev, zero=bias.numel() > ctx.n_des)
             ws = _u8(sizes[2], dev)
             bp = FcEchoBlockParams(zonal.shape[1], ctx.n_des, ctx.n_bins, _filter_params((zonal, spherical, phase), ftype, (g_z, g_s, g_p)),
                                    bias.data_ptr(), g_b.data_ptr())
@@ -287,7 +292,7 @@ class _LiftBlockFn(torch.autograd.Function):
         shapes = [zonal_ang.shape, zonal_mag.shape, phase.shape if ftype != 0 else None, bias.shape]
         with Fn._on(dev):
             gx = torch.empty((N, C_in), dtype=torch.float32, device=dev)
-            g_za, g_zm, g_ph, g_b = _carve(torch.empty(_carve_size(shapes), dtype=torch.float32, device=dev), shapes)
+            g_za, g_zm, g_ph, g_b = _carve_alloc(shapes, dev)
             bp = FcLiftBlockParams(C_in, C_out, ftype, zonal_ang.data_ptr(), zonal_mag.data_ptr(), phase.data_ptr(), bias.data_ptr(),
                                    g_za.data_ptr(), g_zm.data_ptr(), g_ph.data_ptr() if g_ph is not None else None, g_b.data_ptr())
             nws = lib.fc_lift_block_workspace_bytes(ctypes.byref(mesh), ctypes.byref(bp), 1)

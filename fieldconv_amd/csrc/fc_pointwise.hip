@@ -303,6 +303,26 @@ __global__ __launch_bounds__(64) void tangent_nonlin_gb_reduce_kernel(const floa
     if (lane == 0) gbias[c] = s;
 }
 
+// softAbs (reference utils/field.py:29-37: |z| outside the origin box, 0 inside; ECHOBlock's residual branch, nn/echo_block.py:103) and its
+// VJP g z/|z| -- one launch each instead of a dozen elementwise torch kernels and their autograd nodes
+__global__ void soft_abs_fwd_kernel(const float2* __restrict__ x, float* __restrict__ y, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float2 v = x[idx];
+    y[idx] = is_origin(v) ? 0.f : sqrtf(v.x * v.x + v.y * v.y);
+}
+__global__ void soft_abs_bwd_kernel(const float2* __restrict__ x, const float* __restrict__ gy, float2* __restrict__ gx, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float2 v = x[idx];
+    float2 o = make_float2(0.f, 0.f);
+    if (!is_origin(v)) {
+        const float s = gy[idx] / sqrtf(v.x * v.x + v.y * v.y);
+        o = make_float2(v.x * s, v.y * s);
+    }
+    gx[idx] = o;
+}
+
 }  // namespace fc
 
 namespace fc {
@@ -368,6 +388,22 @@ int fc_tangent_lin_backward(const float* x, const float* gy, const float* re_w, 
                             int32_t O, void* stream) {
     return fc::tangent_lin_backward_impl(x, gy, re_w, im_w, gx, nullptr, g_re, g_im, workspace, workspace_bytes, N, I, O,
                                          static_cast<hipStream_t>(stream));
+}
+
+int fc_soft_abs_forward(const float* x, float* y, size_t count, void* stream) {
+    if (!x || !y) return FC_ERR_BAD_ARGUMENT;
+    if (count == 0) return FC_OK;
+    hipLaunchKernelGGL(fc::soft_abs_fwd_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(x), y, count);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+int fc_soft_abs_backward(const float* x, const float* gy, float* gx, size_t count, void* stream) {
+    if (!x || !gy || !gx) return FC_ERR_BAD_ARGUMENT;
+    if (count == 0) return FC_OK;
+    hipLaunchKernelGGL(fc::soft_abs_bwd_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(x), gy, reinterpret_cast<float2*>(gx), count);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
 int fc_tangent_nonlin_forward(const float* x, const float* bias, float* y, int32_t N, int32_t C, void* stream) {

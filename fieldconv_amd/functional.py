@@ -854,6 +854,39 @@ def tangent_nonlin(x, bias):
     return _TangentNonLinFn.apply(x, bias)
 
 
+class _SoftAbsFn(torch.autograd.Function):
+    """reference utils/field.py:29-37 as one kernel per pass (fc_soft_abs_forward / _backward)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        with _on(x.device):
+            y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            check(lib.fc_soft_abs_forward(_p(x), _p(y), x.numel(), _stream()), 'fc_soft_abs_forward')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, = ctx.saved_tensors
+        gy = gy.contiguous()
+        with _on(x.device):
+            gx = torch.empty_like(x)
+            check(lib.fc_soft_abs_backward(_p(x), _p(gy), _p(gx), x.numel(), _stream()), 'fc_soft_abs_backward')
+        return gx
+
+
+def soft_abs(x):
+    """|x| outside the origin box, 0 inside (reference utils/field.py:29-37): one kernel per pass for complex64 device tensors, the
+    branch-free torch formulation (utils/field.py) otherwise (double precision)."""
+    if on_device(x) and x.dtype == torch.complex64:
+        return _SoftAbsFn.apply(x)
+    from .utils.field import softAbs
+    return softAbs(x)
+
+
 def _tkey(t):
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.dtype)
 

@@ -2,7 +2,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as _fn
-from ..utils.field import softAbs
 from .echo import ECHO
 from .field_conv import FieldConv
 from .tangent_nonlin import TangentNonLin
@@ -53,4 +52,4 @@ class ECHOBlock(nn.Module):
         d = d.reshape(d.shape[0], -1)
         d = F.relu(self.lin1(d))
         d = F.relu(self.lin2(d))
-        return self.lin3(d) + self.res(softAbs(x))
+        return self.lin3(d) + self.res(_fn.soft_abs(x))

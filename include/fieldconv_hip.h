@@ -297,6 +297,11 @@ int32_t fc_tangent_nonlin_backward_groups(int32_t N);
 int fc_tangent_nonlin_backward_partial(const float* x, const float* bias, const float* gy, float* gx, void* workspace,
                                        size_t workspace_bytes, int32_t N, int32_t C, void* stream);
 
+/* softAbs, reference utils/field.py:29-37 (what ECHOBlock feeds its linear residual, nn/echo_block.py:103): y = |x| outside the origin
+ * box, 0 inside; its VJP gx = gy x/|x| (0 inside).  x: count complex64 values, y / gy: count floats. */
+int fc_soft_abs_forward(const float* x, float* y, size_t count, void* stream);
+int fc_soft_abs_backward(const float* x, const float* gy, float* gx, size_t count, void* stream);
+
 /* The same in double precision (complex128 features, float64 bias): the reference's modules run under .double().
  * TangentLin in double precision is fc_cgemm with Wc = Re + i Im built by the caller. */
 int fc_tangent_nonlin_forward_f64(const double* x, const double* bias, double* y, int32_t N, int32_t C, void* stream);
