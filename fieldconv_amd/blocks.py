@@ -253,6 +253,64 @@ def echo_block_descriptors(block, x, graph, ln, wxp):
                               graph, slots)
 
 
+class _EchoTailFn(torch.autograd.Function):
+    """ECHOBlock behind its descriptors (reference nn/echo_block.py:95-103): lin3(relu(lin2(relu(lin1(d))))) + res(softAbs(x)) as ONE autograd
+    node.  The arithmetic is the reference's -- four dense layers on hipBLASLt through torch.addmm / torch.mm, softAbs through
+    fc_soft_abs_* -- with the backward pass written out (linear and ReLU VJPs), so that the host pays one node instead of fourteen:
+    on the reference's ~1k-vertex meshes the step is bound by what the host spends per autograd node."""
+
+    @staticmethod
+    def forward(ctx, d, x, w1, b1, w2, b2, w3, b3, wr, br):
+        lib = _lib.load()
+        x = x.contiguous()
+        with Fn._on(x.device):
+            a = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            check(lib.fc_soft_abs_forward(Fn._p(x), Fn._p(a), x.numel(), Fn._stream()), 'fc_soft_abs_forward')
+            h1 = torch.addmm(b1, d, w1.t()).relu_()
+            h2 = torch.addmm(b2, h1, w2.t()).relu_()
+            y = torch.addmm(b3, h2, w3.t()).add_(torch.addmm(br, a, wr.t()))       # lin3(h2) + res(a), in the reference's order
+        ctx.save_for_backward(d, x, a, h1, h2, w1, w2, w3, wr)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        d, x, a, h1, h2, w1, w2, w3, wr = ctx.saved_tensors
+        g = g.contiguous()
+        with Fn._on(x.device):
+            gb = g.sum(0)                                   # lin3.bias and res.bias see the same cotangent
+            g_w3 = g.t().mm(h2)
+            g_h2 = g.mm(w3).mul_(h2 > 0)
+            g_b2 = g_h2.sum(0)
+            g_w2 = g_h2.t().mm(h1)
+            g_h1 = g_h2.mm(w2).mul_(h1 > 0)
+            g_b1 = g_h1.sum(0)
+            g_w1 = g_h1.t().mm(d)
+            g_d = g_h1.mm(w1)
+            g_wr = g.t().mm(a)
+            g_a = g.mm(wr)
+            gx = torch.empty_like(x)
+            check(lib.fc_soft_abs_backward(Fn._p(x), Fn._p(g_a), Fn._p(gx), x.numel(), Fn._stream()), 'fc_soft_abs_backward')
+        return g_d, gx, g_w1, g_b1, g_w2, g_b2, g_w3, gb, g_wr, gb.clone()
+
+
+def echo_block_tail(block, d, x):
+    """ECHOBlock's MLP + residual behind the (N, n_des * dS) descriptors as one autograd node, or None when that does not apply"""
+    if not (enabled() and Fn.on_device(x)) or x.dtype != torch.complex64 or d.dtype != torch.float32:
+        return None
+    if os.environ.get('FIELDCONV_ECHO_TAIL', '1') == '0':          # development: torch's own Linear / ReLU nodes
+        return None
+    mods = block._modules
+    layers = [mods[name] for name in ('lin1', 'lin2', 'lin3', 'res')]
+    tens = []
+    for lin in layers:
+        w, b = lin._parameters.get('weight'), lin._parameters.get('bias')
+        if type(lin) is not torch.nn.Linear or w is None or b is None or w.dtype != torch.float32 or not w.is_contiguous():
+            return None
+        tens += [w, b]
+    return _EchoTailFn.apply(d, x, *tens)
+
+
 # --------------------------------------------------------------------------------------------------------------------- LiftBlock
 class _LiftBlockFn(torch.autograd.Function):
     """reference nn/lift_block.py:53-55: modReLU(TransField(x)) as fc_lift_block_forward / fc_lift_block_backward"""

@@ -1183,8 +1183,28 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
             out[native] = (y.detach(),) + torch.autograd.grad(y, [args[0]] + params, grad_outputs=gy.to(dev), allow_unused=True)
         for a, b in zip(out[True], out[False]):
             assert (a is None) == (b is None)
-            if a is not None:
+            if a is None:
+                continue
+            if name == 'echo':
+                # ECHOBlock's dense tail (three Linear layers + the residual on |x|) is one node with a written-out backward pass on the
+                # block-level path and torch's own Linear / ReLU nodes otherwise: the same GEMM calls, not necessarily the same bits
+                assert rel_err(H(a), H(b)) < 2e-6, name
+            else:
                 assert torch.equal(a, b), name
+    # ... while its native half -- convolution + modReLU + descriptor splat -- is bit-identical to the per-operator composition
+    from fieldconv_amd.blocks import echo_block_descriptors
+    from fieldconv_amd.graph import get_graph
+    em = mods['echo']
+    monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '1')
+    xa = x.to(dev).requires_grad_(True)
+    da = echo_block_descriptors(em, xa, get_graph(edges, sten, N), ln, wxp)
+    xb = x.to(dev).requires_grad_(True)
+    db = em.echo(em.conv.forward_act(xb, edges, sten, em.nonlin.bias[:, : em.n_des]), edges, ln, wxp)
+    gd = torch.randn(da.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    conv_params = [em.conv.zonal, em.conv.spherical, em.conv.phase, em.nonlin.bias]
+    ga = torch.autograd.grad(da, [xa] + conv_params, grad_outputs=gd)
+    gb = torch.autograd.grad(db, [xb] + conv_params, grad_outputs=gd)
+    assert torch.equal(da, db) and all(torch.equal(p_, q_) for p_, q_ in zip(ga, gb))
 
 
 def test_soft_abs_kernel_matches_the_torch_formulation(dev):
