@@ -33,6 +33,7 @@ SWITCHES = {
     'FIELDCONV_EAGER_STENCIL': '1: FCPrecomp returns the dense (E,R,F) tensor',
     'FIELDCONV_NO_FUSED_EPILOGUE': '1: residual add and modReLU as separate operators',
     'FIELDCONV_SEPARATE_CALLS': '1: one foreign call per kernel instead of fc_forward_params / fc_backward_all',
+    'FIELDCONV_CPP_NODES': '0: the block-level autograd nodes in Python (fieldconv_amd/blocks.py) instead of the C++ ones (fc_torch_nodes.so)',
     'FIELDCONV_ECHO_TAIL': "0: ECHOBlock's dense tail as torch's own Linear / ReLU autograd nodes instead of one node",
     'FIELDCONV_BLOCK_CALLS': '0: FCResNetBlock / ECHOBlock / LiftBlock composed of per-operator autograd nodes instead of the block-level entry points',
     # ---- read by bench.py only

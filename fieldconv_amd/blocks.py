@@ -20,6 +20,68 @@ from . import _lib
 from ._lib import FcEchoBlockParams, FcFilterParams, FcLiftBlockParams, FcMesh, FcResnetBlockParams, check
 from . import functional as Fn
 
+_NODES = None
+
+
+def cpp_nodes():
+    """The block-level autograd nodes in C++ (fieldconv_amd/csrc_torch/fc_torch_nodes.cpp -> _native/fc_torch_nodes.so), bound to the
+    library instance this process loaded; None when the extension is not built for these sources / this torch, or switched off
+    (FIELDCONV_CPP_NODES=0): the Python nodes below are then used -- same calls, same results, more host time per node."""
+    global _NODES
+    if os.environ.get('FIELDCONV_CPP_NODES', '1') == '0':
+        return None
+    if _NODES is None:
+        _NODES = False
+        lib = _lib.load()
+        if isinstance(lib, ctypes.CDLL):
+            from .build import TORCH_NODES_PATH, torch_nodes_needs_build
+            if os.path.exists(TORCH_NODES_PATH) and not torch_nodes_needs_build():
+                import importlib.util
+                spec = importlib.util.spec_from_file_location('fc_torch_nodes', TORCH_NODES_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                names = ('fc_resnet_block_forward', 'fc_resnet_block_backward', 'fc_echo_block_forward', 'fc_echo_block_backward',
+                         'fc_lift_block_forward', 'fc_lift_block_backward', 'fc_lift_block_workspace_bytes', 'fc_lift_block_saved_bytes',
+                         'fc_soft_abs_forward', 'fc_soft_abs_backward', 'fc_status_string')
+                mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in names})
+                _NODES = mod
+            else:
+                import warnings
+                warnings.warn('fieldconv_amd: fc_torch_nodes.so is not built for these sources (python -m fieldconv_amd.build --nodes); '
+                              'using the Python autograd nodes (more host time per block)')
+    return _NODES or None
+
+
+def _graph_ref(nodes, graph, B):
+    """the mesh as the C++ nodes take it (built once per graph and band limit; holds the grouping arrays and records)"""
+    key = ('graph_ref', int(B))
+    ref = graph._plans.get(key)
+    if ref is None:
+        empty = torch.empty(0, dtype=torch.int32, device=graph.rowptr_t.device)
+        if graph.geo_t is not None:
+            kind, fwd, bwd = 2, graph.geo_t, graph.rec_s
+        elif graph.factored:
+            kind, fwd, bwd = 1, graph.rec_t, graph.rec_s
+        else:
+            kind, fwd, bwd = 0, graph.sten_t, graph.sten_s
+        opt = lambda t: t if t is not None else empty
+        ref = graph._plans[key] = nodes.GraphRef([graph.rowptr_t, opt(graph.nbr_t), opt(graph.runs_t), graph.rowptr_s, opt(graph.nbr_s),
+                                                  opt(graph.runs_s), opt(fwd), opt(bwd)], graph.N, graph.E, graph.R, int(B), kind)
+    return ref
+
+
+def _resnet_sizes(lib, graph, mesh, C_in, C_mid, C_out, B):
+    """(saved bytes, forward workspace bytes, backward workspace bytes) of an FCResNetBlock on this mesh, cached with the graph"""
+    key = ('resnet', C_in, C_mid, C_out, int(B))
+    sizes = graph._plans.get(key)
+    if sizes is None:
+        bp = FcResnetBlockParams(C_in, C_mid, C_out)
+        bref = ctypes.byref(bp)
+        sizes = graph._plans[key] = (lib.fc_resnet_block_saved_bytes(mesh.ref, bref), lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 0),
+                                     lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 1))
+    return sizes
+
+
 def enabled():
     """False under the development switches that ask for separate operators / calls / no edge split (read per call: tests flip them),
     and while the benchmark brackets single kernels with events"""
@@ -108,12 +170,7 @@ class _ResnetBlockFn(torch.autograd.Function):
         mesh = _mesh(graph, B)
         bp = FcResnetBlockParams(C_in, C_mid, C_out, _filter_params((z1, s1, p1), ftype), _filter_params((z2, s2, p2), ftype),
                                  b1.data_ptr(), b2.data_ptr(), re_w.data_ptr(), im_w.data_ptr(), None, None, None, None)
-        key = ('resnet', C_in, C_mid, C_out, int(B))
-        sizes = graph._plans.get(key)
-        if sizes is None:
-            bref = ctypes.byref(bp)
-            sizes = graph._plans[key] = (lib.fc_resnet_block_saved_bytes(mesh.ref, bref), lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 0),
-                                         lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 1))
+        sizes = _resnet_sizes(lib, graph, mesh, C_in, C_mid, C_out, B)
         dev = x.device
         with Fn._on(dev):
             out = torch.empty((graph.N, C_out), dtype=torch.complex64, device=dev)
@@ -185,6 +242,14 @@ def resnet_block(block, x, graph):
     z1, s1, p1 = _conv_tensors(c1)
     z2, s2, p2 = _conv_tensors(c2)
     rp = res._parameters
+    nodes = cpp_nodes()
+    if nodes is not None:                      # the same node in C++ (csrc_torch/fc_torch_nodes.cpp): no interpreter in either pass
+        B = int(c1.B)
+        sizes = graph._plans.get(('resnet', c1.in_channels, c1.out_channels, c2.out_channels, B))
+        if sizes is None:
+            sizes = _resnet_sizes(_lib.load(), graph, _mesh(graph, B), c1.in_channels, c1.out_channels, c2.out_channels, B)
+        return nodes.resnet_block(x, z1, s1, p1, mods['nonlin1']._parameters['bias'], z2, s2, p2, mods['nonlin2']._parameters['bias'],
+                                  rp['Re'], rp['Im'], _graph_ref(nodes, graph, B), int(c1.ftype), sizes[0], sizes[1], sizes[2])
     return _ResnetBlockFn.apply(x, z1, s1, p1, mods['nonlin1']._parameters['bias'], z2, s2, p2, mods['nonlin2']._parameters['bias'],
                                 rp['Re'], rp['Im'], int(c1.ftype), int(c1.B), graph)
 
@@ -249,6 +314,19 @@ def echo_block_descriptors(block, x, graph, ln, wxp):
     if not 1 <= n_bins <= 8 or n_des != conv.out_channels:          # (more bins: the run-time ECHO kernels, composed path)
         return None
     slots = Fn.echo_slot_order(graph, ln, wxp)
+    nodes = cpp_nodes()
+    if nodes is not None:
+        lib, B = _lib.load(), int(conv.B)
+        key = ('echo_block', conv.in_channels, int(n_des), n_bins, B)
+        sizes = graph._plans.get(key)
+        if sizes is None:
+            bref = ctypes.byref(FcEchoBlockParams(conv.in_channels, int(n_des), n_bins))
+            mesh = _mesh(graph, B)
+            sizes = graph._plans[key] = (lib.fc_echo_block_saved_bytes(mesh.ref, bref), lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 0),
+                                         lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 1), lib.fc_echo_hist_dim(n_bins))
+        z, sp, ph = _conv_tensors(conv)
+        return nodes.echo_block(x, z, sp, ph, block._modules['nonlin']._parameters['bias'], _graph_ref(nodes, graph, B), list(slots[:4]),
+                                int(conv.ftype), int(n_des), n_bins, sizes[3], sizes[0], sizes[1], sizes[2])
     return _EchoBlockFn.apply(x, conv.zonal, conv.spherical, conv.phase, block.nonlin.bias, int(conv.ftype), int(conv.B), int(n_des), n_bins,
                               graph, slots)
 
@@ -308,6 +386,9 @@ def echo_block_tail(block, d, x):
         if type(lin) is not torch.nn.Linear or w is None or b is None or w.dtype != torch.float32 or not w.is_contiguous():
             return None
         tens += [w, b]
+    nodes = cpp_nodes()
+    if nodes is not None:
+        return nodes.echo_tail(d, x, *tens)
     return _EchoTailFn.apply(d, x, *tens)
 
 
@@ -373,4 +454,13 @@ def lift_block(block, x, supp_edges, lift_sten):
     from .graph import get_edge_csr
     csr = get_edge_csr(supp_edges, x.shape[0])
     sten, stride = Fn._TransFieldFn._stencil(lift_sten)         # (FCPrecomp's stand-in: the factor table, stride 0)
+    nodes = cpp_nodes()
+    if nodes is not None:
+        arrays = csr._plans.get('lift_arrays')
+        if arrays is None:
+            arrays = csr._plans['lift_arrays'] = [csr.rowptr_t, csr.nbr_t, csr.perm_t, csr.rowptr_s, csr.nbr_s, csr.perm_s]
+        fp, bias = field._parameters, block._modules['nonlin']._parameters['bias']
+        phase = fp.get('phase')
+        return nodes.lift_block(x, sten, fp['zonalAng'], fp['zonalMag'], phase if phase is not None else field._buffers['phase'], bias,
+                                arrays, int(stride), int(field.ftype), int(csr.E))
     return _LiftBlockFn.apply(x, sten, stride, field.zonalAng, field.zonalMag, field.phase, block.nonlin.bias, int(field.ftype), csr)

@@ -73,6 +73,64 @@ def build_dev(force=False, verbose=False):
     return path
 
 
+# ---- C++ autograd nodes (a torch extension: host-side plumbing above the C ABI, csrc_torch/fc_torch_nodes.cpp) ----------------------------
+TORCH_NODES_SRC = os.path.join(PKG, 'csrc_torch', 'fc_torch_nodes.cpp')
+TORCH_NODES_PATH = os.path.join(OUT_DIR, 'fc_torch_nodes.so')
+TORCH_NODES_DIGEST = TORCH_NODES_PATH + '.src.sha256'
+
+
+def _torch_nodes_digest():
+    import hashlib
+    import torch
+    h = hashlib.sha256()
+    for d in (TORCH_NODES_SRC, os.path.join(PKG, '..', 'include', 'fieldconv_hip.h')):
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())            # the extension is built against this torch's headers and ABI
+    return h.hexdigest()
+
+
+def torch_nodes_needs_build():
+    if not os.path.exists(TORCH_NODES_PATH) or not os.path.exists(TORCH_NODES_DIGEST):
+        return True
+    with open(TORCH_NODES_DIGEST) as f:
+        return f.read().strip() != _torch_nodes_digest()
+
+
+def build_torch_nodes(force=False, verbose=False):
+    """g++ against the installed torch's headers -> _native/fc_torch_nodes.so (module `fc_torch_nodes`).  No GPU code: the nodes call
+    libfieldconv_hip.so through function pointers the binding hands them."""
+    if not force and not torch_nodes_needs_build():
+        return TORCH_NODES_PATH
+    if under_profiler():
+        raise RuntimeError('fc_torch_nodes.so is missing or stale and this process runs under a profiler: build first')
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(OUT_DIR, exist_ok=True)
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    tmp = TORCH_NODES_PATH + '.tmp.%d' % os.getpid()
+    cmd = (['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-DTORCH_EXTENSION_NAME=fc_torch_nodes', '-DTORCH_API_INCLUDE_EXTENSION_H',
+            '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1', '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+            '-I' + os.path.join(rocm, 'include')]
+           + ['-isystem' + p for p in cpp_extension.include_paths()] + ['-isystem' + sysconfig.get_paths()['include'],
+           TORCH_NODES_SRC, '-o', tmp, '-L' + tlib, '-Wl,-rpath,' + tlib, '-lc10', '-lc10_hip', '-ltorch_cpu', '-ltorch', '-ltorch_python',
+           '-L' + os.path.join(rocm, 'lib'), '-lamdhip64'])
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError('building fc_torch_nodes.so failed:\n' + res.stdout)
+    os.replace(tmp, TORCH_NODES_PATH)
+    with open(TORCH_NODES_DIGEST + '.tmp.%d' % os.getpid(), 'w') as f:
+        f.write(_torch_nodes_digest())
+    os.replace(TORCH_NODES_DIGEST + '.tmp.%d' % os.getpid(), TORCH_NODES_DIGEST)
+    return TORCH_NODES_PATH
+
+
 def under_profiler():
     """rocprofv3's preloaded tool library has initialised the GPU before python starts; compiling from such a process
     means hipcc children that exec clang -- the exec hop the GPU pool forbids (it takes the machine down)."""
@@ -136,3 +194,5 @@ if __name__ == '__main__':
     print(build_native(force='--force' in sys.argv, verbose=True))
     if '--dev' in sys.argv:
         print(build_dev(force='--force' in sys.argv, verbose=True))
+    if '--nodes' in sys.argv:
+        print(build_torch_nodes(force='--force' in sys.argv, verbose=True))

@@ -1159,29 +1159,36 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
     inputs = {'resnet': lambda: (x.to(dev).requires_grad_(True), edges, sten),
               'echo': lambda: (x.to(dev).requires_grad_(True), edges, sten, ln, wxp),
               'lift': lambda: (pos.to(dev).requires_grad_(True), edges, sten[..., B:B + 2])}
-    node = {'resnet': '_ResnetBlockFn', 'echo': '_EchoBlockFn', 'lift': '_LiftBlockFn'}
+    node = {'resnet': 'ResnetBlockFn', 'echo': 'EchoBlockFn', 'lift': 'LiftBlockFn'}
+    from fieldconv_amd.blocks import cpp_nodes
+    assert cpp_nodes() is not None, 'fc_torch_nodes.so (the C++ autograd nodes) is not built'
     for name, mod in mods.items():
         params = list(mod.parameters())
         out = {}
-        for native in (True, False):
+        # the block-level node in C++ (fc_torch_nodes.so), the same node in Python (fieldconv_amd/blocks.py), per-operator composition
+        for native in ('cpp', 'python', False):
             monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '1' if native else '0')
+            monkeypatch.setenv('FIELDCONV_CPP_NODES', '1' if native == 'cpp' else '0')
             args = inputs[name]()
             y = mod(*args)
-            seen, todo, found = set(), [y.grad_fn], False
+            seen, todo, found = set(), [y.grad_fn], None
             while todo:                         # the block-level node is (not) in the autograd graph
                 fn = todo.pop()
                 if fn is None or fn in seen:
                     continue
                 seen.add(fn)
-                found = found or node[name] in type(fn).__name__
+                if node[name] in fn.name():
+                    found = 'cpp' if 'CppNode' in fn.name() else 'python'
                 todo += [nf for nf, _ in fn.next_functions]
-            assert found == native, (name, native)
+            assert found == (native or None), (name, native, found)
             gen = torch.Generator().manual_seed(1)
             gy = torch.randn(y.shape, generator=gen)
             if y.is_complex():
                 gy = torch.complex(gy, torch.randn(y.shape, generator=gen))
             out[native] = (y.detach(),) + torch.autograd.grad(y, [args[0]] + params, grad_outputs=gy.to(dev), allow_unused=True)
-        for a, b in zip(out[True], out[False]):
+        for a, b in zip(out['cpp'], out['python']):                 # the two bindings of the same node: the same calls, the same bits
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), name
+        for a, b in zip(out['cpp'], out[False]):
             assert (a is None) == (b is None)
             if a is None:
                 continue
@@ -1196,6 +1203,7 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
     from fieldconv_amd.graph import get_graph
     em = mods['echo']
     monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '1')
+    monkeypatch.setenv('FIELDCONV_CPP_NODES', '1')
     xa = x.to(dev).requires_grad_(True)
     da = echo_block_descriptors(em, xa, get_graph(edges, sten, N), ln, wxp)
     xb = x.to(dev).requires_grad_(True)

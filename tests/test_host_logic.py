@@ -55,6 +55,25 @@ def test_product_library_reads_no_environment_switch():
     assert ctypes.CDLL(build_dev()).fc_dev_switches() == 1
 
 
+def test_cpp_autograd_nodes_build_and_bind():
+    """fc_torch_nodes.so -- the block-level autograd nodes in C++ (csrc_torch/fc_torch_nodes.cpp; host-side plumbing, no GPU code) -- builds
+    against the installed torch, loads, and binds to the library's entry points through function pointers (no compute without a GPU)."""
+    from fieldconv_amd import blocks
+    from fieldconv_amd.build import build_native, build_torch_nodes, torch_nodes_needs_build
+    build_native()
+    path = build_torch_nodes()
+    assert os.path.exists(path) and not torch_nodes_needs_build()
+    nodes = blocks.cpp_nodes()
+    assert nodes is not None
+    for name in ('bind', 'GraphRef', 'resnet_block', 'echo_block', 'lift_block', 'echo_tail'):
+        assert hasattr(nodes, name), name
+    empty = torch.empty(0, dtype=torch.int32)
+    ref = nodes.GraphRef([empty] * 8, 10, 0, 6, 2, 1)
+    assert ref is not None
+    with pytest.raises(Exception):
+        nodes.GraphRef([empty] * 3, 10, 0, 6, 2, 1)
+
+
 def test_supported_query_and_sizes_need_no_gpu():
     lib = _lib.load()
     d = _lib.FcDims(20000, 640000, 48, 48, 6, 2)
@@ -479,6 +498,8 @@ def test_config3_step_takes_at_most_40_foreign_calls(monkeypatch):
     monkeypatch.setattr(functional, '_stream', lambda: ctypes.c_void_p(0))
     for name in ('FIELDCONV_BLOCK_CALLS', 'FIELDCONV_NO_FUSED_EPILOGUE', 'FIELDCONV_NO_EDGE_SPLIT'):
         monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv('FIELDCONV_CPP_NODES', '0')      # the Python binding of the block-level nodes: its calls can be counted (the C++ nodes
+                                                        # reach the library through function pointers: the same calls, one per block and pass)
 
     from fieldconv_amd.data import sphere_support
     N, k, nf, B, R, n_cls = 300, 24, 48, 2, 6, 8
