@@ -51,7 +51,7 @@ __device__ __forceinline__ void lin_load_fragments(float4 (&a)[kLinChunk], const
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* __restrict__ in, const float* __restrict__ wre,
                                                                   const float* __restrict__ wim, float2* out,
-                                                                  const float2* addend, int N, int K, int M, int ldw) {
+                                                                  const float2* addend, int N, int K, int M, int ldw, int split) {
     extern __shared__ float lds[];
     const int KR = round_up(2 * K, 16), KS = slab_stride(KR), MP = round_up(M, 16);
     float* Wr = lds;
@@ -62,8 +62,13 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
     const float* in_f = reinterpret_cast<const float*>(in);
     const bool vec = (K & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;       // 16-byte aligned rows
 
+    // split (meshes whose 16-vertex blocks cannot occupy the chip with four of them per workgroup): a workgroup takes ONE block at a time
+    // and its four wavefronts share the block's output tiles -- a wavefront's serial chain of fp32 MFMAs (32 cycles each) is a quarter as
+    // long, the input rows are read by all four (L1 hits).  Same sums in the same order: bit-identical to the unsplit walk.
+    const int bstep = split ? gridDim.x : gridDim.x * kLinWaves;
+    const int tcount = split ? 1 : kLinTiles, mstart = split ? wave : 0, mstride = split ? kLinWaves : kLinTiles;
     // first input fragments of this wavefront: in flight while the filter is staged
-    const int blk0 = blockIdx.x * kLinWaves + wave;
+    const int blk0 = split ? blockIdx.x : blockIdx.x * kLinWaves + wave;
     float4 a[kLinChunk];
     {
         const int n = min(blk0, nblocks - 1) * 16 + fr;
@@ -96,11 +101,11 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
     __syncthreads();
 
     bool loaded = true;
-    for (int blk = blk0; blk < nblocks; blk += gridDim.x * kLinWaves) {
+    for (int blk = blk0; blk < nblocks; blk += bstep) {
         const int n = blk * 16 + fr;
         const float* row = in_f + (size_t)min(n, N - 1) * 2 * K;
         const float keep = n < N ? 1.f : 0.f;
-        for (int mg = 0; mg < MT; mg += kLinTiles) {
+        for (int mg = mstart; mg < MT; mg += mstride) {
             f32x4 acc_re[kLinTiles], acc_im[kLinTiles];
 #pragma unroll
             for (int t = 0; t < kLinTiles; ++t) { acc_re[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_im[t] = acc_re[t]; }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
                 loaded = false;
 #pragma unroll
                 for (int t = 0; t < kLinTiles; ++t) {
-                    if (mg + t < MT) {
+                    if (t < tcount && mg + t < MT) {
                         const float* pr = Wr + ((mg + t) * 16 + fr) * KS + 4 * fq;
                         const float* pi = Wi + ((mg + t) * 16 + fr) * KS + 4 * fq;
 #pragma unroll
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int no = blk * 16 + 4 * fq + j;
-                    if (no < N && mo < M) {
+                    if (t < tcount && no < N && mo < M) {
                         float2 v = make_float2(acc_re[t][j], acc_im[t][j]);
                         if (addend) {           // (may be `out` itself: each entry is read and written by this thread only)
                             const float2 s = addend[(size_t)no * M + mo];
@@ -339,6 +344,13 @@ static int lin_grid(int N) {
     const int groups = ((N + 15) / 16 + kLinWaves - 1) / kLinWaves;
     return groups < 4 * num_cus() ? groups : 4 * num_cus();
 }
+// one 16-vertex block per workgroup at a time, its output tiles dealt to the four wavefronts (tangent_lin_kernel: split), when there is
+// more than one tile and the blocks alone cannot give every SIMD of the chip work
+static bool lin_split(int N, int M) { return M > 16 && (N + 15) / 16 <= 8 * num_cus(); }
+static int lin_grid_split(int N) {
+    const int nblocks = (N + 15) / 16;
+    return nblocks < 4 * num_cus() ? nblocks : 4 * num_cus();
+}
 static int lin_gw_groups(int N) {
     const int nblocks = (N + 15) / 16;
     return nblocks < kLinGwGroups ? nblocks : kLinGwGroups;
@@ -350,9 +362,10 @@ int tangent_lin_backward_impl(const float* x, const float* gy, const float* re_w
     if (!workspace || workspace_bytes < fc_tangent_lin_backward_workspace_bytes(N, I, O)) return FC_ERR_WORKSPACE;
     const size_t lds = 2 * (size_t)lin_plane_floats(I, O) * sizeof(float);
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(tangent_lin_kernel<true>, dim3(lin_grid(N)), dim3(kLinThreads), lds, s,
+    const bool split = lin_split(N, I);
+    hipLaunchKernelGGL(tangent_lin_kernel<true>, dim3(split ? lin_grid_split(N) : lin_grid(N)), dim3(kLinThreads), lds, s,
                        reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx),
-                       reinterpret_cast<const float2*>(gx_addend), N, O, I, I);
+                       reinterpret_cast<const float2*>(gx_addend), N, O, I, I, split ? 1 : 0);
     float2* part = reinterpret_cast<float2*>(workspace);
     const int ng = lin_gw_groups(N);
     const int pairs = ((O + 15) / 16) * ((I + 15) / 16);
@@ -372,9 +385,10 @@ int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w,
     if (!x || !re_w || !im_w || !y || N <= 0 || I <= 0 || O <= 0) return FC_ERR_BAD_ARGUMENT;
     const size_t lds = 2 * (size_t)fc::lin_plane_floats(O, I) * sizeof(float);
     if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(fc::lin_grid(N)), dim3(fc::kLinThreads), lds,
+    const bool split = fc::lin_split(N, O);
+    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(split ? fc::lin_grid_split(N) : fc::lin_grid(N)), dim3(fc::kLinThreads), lds,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w,
-                       reinterpret_cast<float2*>(y), (const float2*)nullptr, N, I, O, I);
+                       reinterpret_cast<float2*>(y), (const float2*)nullptr, N, I, O, I, split ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
