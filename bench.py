@@ -507,9 +507,11 @@ def run_net(args, world, rank, dev, use_dist, backend):
     vertex (what sample_n = 1024 / epsilon = 0.2 give, :89,120), launched EAGERLY -- the reference trains with batch size 1 on a different
     mesh every step (:137), so a captured HIP graph does not cover a training run; the replayed figure is an extra.  With N > 1 ranks every
     rank holds its own mesh and a replica (one bucketed all-reduce of the gradients per step), as in --mode dp."""
+    from fieldconv_amd.blocks import cpp_nodes
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.dist import GradientBuckets
     from fieldconv_amd.functional import kernel_timer
+    from fieldconv_amd.graph import get_graph
     from fieldconv_amd.nn import ECHOBlock, FCResNetBlock, LiftBlock
     from fieldconv_amd.transforms import FCPrecomp
     N, k, nf, B, R, n_cls = args.net_verts, args.net_k, args.channels, args.band_limit, args.n_rings, 8
@@ -614,6 +616,8 @@ def run_net(args, world, rank, dev, use_dist, backend):
                    'parallelism': 'single GPU' if world == 1 and not use_dist else f'data-parallel x{world}: one mesh per GPU, one bucketed '
                                   f'all-reduce of {4 * buckets.flat.numel()} gradient bytes per step over RCCL',
                    'step_launch': 'eager (a training run sees a different mesh every step: reference segmentation.ipynb:137)',
+                   'kernels': describe_kernels(get_graph(*pre(data)[:2], N), nf, nf, B),
+                   'autograd_nodes': 'C++ (fc_torch_nodes.so)' if cpp_nodes() is not None else 'Python (fieldconv_amd/blocks.py)',
                    'env': env_report()},
         'ranks': identity, 'roofline': roofline, 'kernels': per_kernel, 'settled': settled, 'protocol': PROTOCOL_NOTE,
     }

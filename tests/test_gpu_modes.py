@@ -37,6 +37,9 @@ MODES = {
     'no_half_tiles': {'FC_HALF_TILES': '0'},
     'half_tiles_in_the_backward_pass_too': {'FC_HALF_TILES': '2'},
     'one_call_per_kernel': {'FIELDCONV_SEPARATE_CALLS': '1'},   # the per-kernel entry points instead of fc_forward_params / fc_backward_all
+    'blocks_from_per_operator_nodes': {'FIELDCONV_BLOCK_CALLS': '0'},   # FCResNetBlock / ECHOBlock / LiftBlock composed of per-operator autograd nodes
+    'block_nodes_in_python': {'FIELDCONV_CPP_NODES': '0'},      # the block-level nodes of fieldconv_amd/blocks.py instead of fc_torch_nodes.so
+    'echo_tail_from_torch_nodes': {'FIELDCONV_ECHO_TAIL': '0'},   # ECHOBlock's dense tail as torch's own Linear / ReLU nodes
 }
 
 
@@ -88,7 +91,7 @@ def test_bench_single_rank_over_rccl():
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['steps'] == 3
 
 
-@pytest.mark.parametrize('fwd_overlap,mode', [('0', 'layer'), ('1', 'layer'), ('0', 'dp')])
+@pytest.mark.parametrize('fwd_overlap,mode', [('0', 'layer'), ('1', 'layer'), ('0', 'dp'), ('0', 'net')])
 def test_bench_two_ranks_on_one_gpu(fwd_overlap, mode):
     """The driver's multi-GPU command line (torch.distributed.run, --gpus 2) with both ranks on this box's one GPU: gloo
     instead of RCCL (which refuses two ranks per device), otherwise the code bench.py runs with N > 1 -- partition, halo
@@ -98,7 +101,7 @@ def test_bench_two_ranks_on_one_gpu(fwd_overlap, mode):
     from conftest import free_port
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--verts', '3000', '--dp-verts', '1500', '--mode', mode, '--no-cpu-baseline', '--no-extras']
+           '--verts', '3000', '--dp-verts', '1500', '--net-verts', '512', '--net-k', '40', '--mode', mode, '--no-cpu-baseline', '--no-extras']
     env = _clean_env({'BENCH_BACKEND': 'gloo', 'BENCH_FORWARD_OVERLAP': fwd_overlap, 'OMP_NUM_THREADS': '4'})
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
@@ -152,3 +155,19 @@ def test_bench_data_parallel_mode_single_rank():
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and 'data-parallel' in line['config']['parallelism']
     assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1 and line['roofline']['kernel'].startswith('fc_')
+
+
+def test_bench_segmentation_net_mode():
+    """bench.py --mode net (BASELINE configs[2]: the segmentation network's topology on a 1 024-vertex mesh, launched eagerly through the
+    block-level entry points): the line carries roofline, the replayed-graph figure, the host's enqueue time and the per-operator
+    comparison, and the eager step is not host-bound by more than a third."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'net', '--steps', '10', '--warmup', '5', '--no-cpu-baseline']
+    res = subprocess.run(cmd, cwd=ROOT, env=_clean_env({}), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['config']['convs_per_step'] == 9 and 'eager' in line['config']['step_launch']
+    assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1 and line['roofline']['kernel'].startswith('fc_')
+    assert line['graph_replay']['ms_per_step'] > 0 and line['new_mesh_every_step']['ms_per_step'] > 0
+    assert line['settled']['ms_per_step'] < 1.35 * line['graph_replay']['ms_per_step'], line['settled']
+    assert line['host_enqueue_ms_per_step']['block_level_calls'] < line['host_enqueue_ms_per_step']['per_operator_calls']
+    assert 'product build' in line['config']['library']
