@@ -155,9 +155,21 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
             }
         }
     };
+    // Item of this workgroup's round k (nitems: none).  Rounds deal the items in order; with the frequency groups as work items (gsplit:
+    // the items of group 0 -- one frequency heavier -- come first) the LAST, partly filled round is dealt from the TOP of the grid: those
+    // workgroups took the lighter group-1 items in the round before, so the heaviest workgroup carries (group 0 + group 1 + group 1)
+    // instead of (group 0 + group 0 + group 1) -- a FAUST-sized mesh (313 tiles, band limit 3): 10 frequency-walks instead of 11.
+    const int grid = gridDim.x, first = first_tile_of_block();
+    const int full = nitems / grid * grid, rem = nitems - full;
+    auto item_of = [&](const int k) {
+        const int vt = first + k * grid;
+        if (!a.gsplit || vt < full) return vt < nitems ? vt : nitems;
+        const int pos = first - (grid - rem);
+        return (k == full / grid && pos >= 0) ? full + pos : nitems;
+    };
     int beg = 0, end = 0, ro[R];      // ro: ring-run offsets of my source (factored), see fc_forward.hip
     {
-        slot_range(first_tile_of_block(), beg, end, ro);
+        slot_range(item_of(0), beg, end, ro);
         if (FACTORED) {
             const int nch = (end - beg + CR - 1) >> LOG_CR;
             for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
@@ -167,12 +179,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
     Stamper stamp{(a.stamps && a.stamp_who == 1 && blockIdx.x == 0) ? a.stamps + wave * 256 : nullptr, 0};       // development: in-kernel timeline
     stamp.realtime(29);
     stamp(28);
-    for (int vt = first_tile_of_block(); vt < nitems; vt += gridDim.x) {
+    for (int rk = 0, vt = item_of(0); vt < nitems; vt = item_of(++rk)) {
         stamp(10);
         const int tile = tile_of(vt);
         const int gsel = (a.gsplit && vt >= a.ntiles) ? 1 : 0;      // gsplit: the one frequency group this item runs
         int nbeg = 0, nend = 0, nro[R];      // my source in the next item
-        slot_range(vt + gridDim.x, nbeg, nend, nro);
+        slot_range(item_of(rk + 1), nbeg, nend, nro);
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
         // my (vertex, channel) entry of x for the gx epilogue: issued now, consumed after the first slab

@@ -8,6 +8,7 @@
 //   fc_generic_gather   contrib[n,i,r,f] = sum_{e: dst_e = n} x[src_e,i] e^{-i (f-B) phi[src_e,i]} S[e,r,f]     (:128-134)
 //   fc_generic_scatter  gxt[j,i,f] = sum_{e: src_e = j} sum_r gC[dst_e,i,r,f] conj(S[e,r,f]),  then the chain rule through
 //                       the rotation: gx = sum_f gxt_f conj(u_f) + [x != 0] (i x/|x|^2) sum_f m_f Im(conj(gxt_f) xt_f)
+#include <algorithm>
 #include "fc_common.hpp"
 #include "fc_kernels.hpp"
 
@@ -32,14 +33,17 @@ template <typename T> __device__ __forceinline__ Cx<T> g_unit_power(Cx<T> u, int
     return p;
 }
 
-// one workgroup per target vertex; thread-owned accumulators in LDS (entry (i, r, f) belongs to the thread of (i, f))
+// one workgroup per (target vertex, block of Ib input channels: blockIdx.y); thread-owned accumulators in LDS (entry (i, r, f) belongs
+// to the thread of (i, f)).  The channels are independent, so any I runs as ceil(I / Ib) blocks whose accumulators fit the CU's LDS.
 template <typename T>
 __global__ __launch_bounds__(kGenThreads) void fc_generic_gather_kernel(
     const Cx<T>* __restrict__ x, const Cx<T>* __restrict__ sten_t, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr,
-    Cx<T>* __restrict__ contrib, const int I, const int R, const int F, const int B) {
+    Cx<T>* __restrict__ contrib, const int Ifull, const int Ib, const int R, const int F, const int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<T>* const acc = reinterpret_cast<Cx<T>*>(smem);          // [I][R][F]
     const int n = blockIdx.x;
+    const int i0 = blockIdx.y * Ib;
+    const int I = min(Ib, Ifull - i0);
     const int nif = I * F, RF = R * F;
     for (int idx = threadIdx.x; idx < I * RF; idx += kGenThreads) acc[idx] = Cx<T>{(T)0, (T)0};
     __syncthreads();
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(kGenThreads) void fc_generic_gather_kernel(
         const int i = idx / F, f = idx - i * F;
         Cx<T>* const mine = acc + (size_t)i * RF + f;
         for (int s = b; s < e; ++s) {
-            const Cx<T> xv = x[(size_t)nbr[s] * I + i];
+            const Cx<T> xv = x[(size_t)nbr[s] * Ifull + i0 + i];
             const Cx<T> xt = gmul(xv, g_unit_power(g_unit_conj(xv), f - B));
             const Cx<T>* S = sten_t + (size_t)s * RF + f;
             for (int r = 0; r < R; ++r) {
@@ -59,25 +63,27 @@ __global__ __launch_bounds__(kGenThreads) void fc_generic_gather_kernel(
         }
     }
     __syncthreads();
-    Cx<T>* out = contrib + (size_t)n * I * RF;
+    Cx<T>* out = contrib + ((size_t)n * Ifull + i0) * RF;
     for (int idx = threadIdx.x; idx < I * RF; idx += kGenThreads) out[idx] = acc[idx];
 }
 
-// one workgroup per source vertex
+// one workgroup per (source vertex, block of Ib input channels)
 template <typename T>
 __global__ __launch_bounds__(kGenThreads) void fc_generic_scatter_kernel(
     const Cx<T>* __restrict__ x, const Cx<T>* __restrict__ gc, const Cx<T>* __restrict__ sten_s, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ nbr, Cx<T>* __restrict__ gx, const int I, const int R, const int F, const int B) {
+    const int32_t* __restrict__ nbr, Cx<T>* __restrict__ gx, const int Ifull, const int Ib, const int R, const int F, const int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<T>* const gxt = reinterpret_cast<Cx<T>*>(smem);          // [I][F]
     const int j = blockIdx.x;
+    const int i0 = blockIdx.y * Ib;
+    const int I = min(Ib, Ifull - i0);
     const int nif = I * F, RF = R * F;
     const int b = rowptr[j], e = rowptr[j + 1];
     for (int idx = threadIdx.x; idx < nif; idx += kGenThreads) {
         const int i = idx / F, f = idx - i * F;
         Cx<T> a{(T)0, (T)0};
         for (int s = b; s < e; ++s) {
-            const Cx<T>* g = gc + ((size_t)nbr[s] * I + i) * RF + f;
+            const Cx<T>* g = gc + ((size_t)nbr[s] * Ifull + i0 + i) * RF + f;
             const Cx<T>* S = sten_s + (size_t)s * RF + f;
             for (int r = 0; r < R; ++r) {
                 const Cx<T> v = gmul_conj(g[r * F], S[r * F]);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(kGenThreads) void fc_generic_scatter_kernel(
     }
     __syncthreads();
     for (int i = threadIdx.x; i < I; i += kGenThreads) {
-        const Cx<T> xv = x[(size_t)j * I + i];
+        const Cx<T> xv = x[(size_t)j * Ifull + i0 + i];
         const Cx<T> u = g_unit_conj(xv);
         const T inv2 = g_is_origin(xv) ? (T)0 : (T)1 / (xv.x * xv.x + xv.y * xv.y);
         Cx<T> acc{(T)0, (T)0};
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(kGenThreads) void fc_generic_scatter_kernel(
         const T q = eq * inv2;
         acc.x += -xv.y * q;
         acc.y += xv.x * q;
-        gx[(size_t)j * I + i] = acc;
+        gx[(size_t)j * Ifull + i0 + i] = acc;
     }
 }
 
@@ -115,12 +121,16 @@ template <typename T>
 static int launch_gather(const void* x, const void* sten_t, const fc_csr* by_target, void* contrib, int n_targets, int I, int R, int B,
                          hipStream_t stream) {
     const int F = 2 * B + 1;
-    const size_t lds = (size_t)I * R * F * sizeof(Cx<T>);
-    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
+    const size_t per_channel = (size_t)R * F * sizeof(Cx<T>);
+    if (per_channel > kMaxLds) return FC_ERR_UNSUPPORTED;                      // (more than 20 480 float / 10 240 double (ring, frequency) pairs)
+    const int Ib = (int)std::min<size_t>((size_t)I, kMaxLds / per_channel);    // input channels per workgroup: its accumulators in LDS
+    const size_t lds = (size_t)Ib * per_channel;
+    const int nblk = (I + Ib - 1) / Ib;
+    if (nblk > 65535) return FC_ERR_UNSUPPORTED;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(fc_generic_gather_kernel<T>), lds, lds_ok)) return FC_ERR_LAUNCH;
-    hipLaunchKernelGGL(fc_generic_gather_kernel<T>, dim3(n_targets), dim3(kGenThreads), lds, stream, static_cast<const Cx<T>*>(x),
-                       static_cast<const Cx<T>*>(sten_t), by_target->rowptr, by_target->nbr, static_cast<Cx<T>*>(contrib), I, R, F, B);
+    hipLaunchKernelGGL(fc_generic_gather_kernel<T>, dim3(n_targets, nblk), dim3(kGenThreads), lds, stream, static_cast<const Cx<T>*>(x),
+                       static_cast<const Cx<T>*>(sten_t), by_target->rowptr, by_target->nbr, static_cast<Cx<T>*>(contrib), I, Ib, R, F, B);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -128,13 +138,17 @@ template <typename T>
 static int launch_scatter(const void* x, const void* g_contrib, const void* sten_s, const fc_csr* by_source, void* gx, int N, int I, int R,
                           int B, hipStream_t stream) {
     const int F = 2 * B + 1;
-    const size_t lds = (size_t)I * F * sizeof(Cx<T>);
-    if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
+    const size_t per_channel = (size_t)F * sizeof(Cx<T>);
+    if (per_channel > kMaxLds) return FC_ERR_UNSUPPORTED;
+    const int Ib = (int)std::min<size_t>((size_t)I, kMaxLds / per_channel);
+    const size_t lds = (size_t)Ib * per_channel;
+    const int nblk = (I + Ib - 1) / Ib;
+    if (nblk > 65535) return FC_ERR_UNSUPPORTED;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(fc_generic_scatter_kernel<T>), lds, lds_ok)) return FC_ERR_LAUNCH;
-    hipLaunchKernelGGL(fc_generic_scatter_kernel<T>, dim3(N), dim3(kGenThreads), lds, stream, static_cast<const Cx<T>*>(x),
+    hipLaunchKernelGGL(fc_generic_scatter_kernel<T>, dim3(N, nblk), dim3(kGenThreads), lds, stream, static_cast<const Cx<T>*>(x),
                        static_cast<const Cx<T>*>(g_contrib), static_cast<const Cx<T>*>(sten_s), by_source->rowptr, by_source->nbr,
-                       static_cast<Cx<T>*>(gx), I, R, F, B);
+                       static_cast<Cx<T>*>(gx), I, Ib, R, F, B);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

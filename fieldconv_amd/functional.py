@@ -541,10 +541,6 @@ def _generic_field_conv(x, w_eff, graph):
         raise ValueError(f'x has shape {tuple(x.shape)}, expected ({graph.N}, {w_eff.shape[1]})')
     if w_eff.shape[2] != graph.R or w_eff.shape[3] != graph.F:
         raise ValueError(f'stencil is (E,{graph.R},{graph.F}) but the filter is {tuple(w_eff.shape)}')
-    itemsize = 16 if x.dtype == torch.complex128 else 8
-    if w_eff.shape[1] * graph.R * graph.F * itemsize > 160 * 1024:
-        raise _lib.FieldConvNativeError(f'in_channels * n_rings * (2 band_limit + 1) = {w_eff.shape[1] * graph.R * graph.F} exceeds the '
-                                        f'run-time path\'s LDS budget ({160 * 1024 // itemsize})')
     return _GenericFieldConvFn.apply(x, w_eff.contiguous(), graph)
 
 

@@ -250,7 +250,7 @@ int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s
  *                       products with fc_cgemm (below);
  *   fc_generic_scatter  gx (N, I) c64 from g_contrib (n_targets, I, R, F) over the out-edges (by_source CSR with nbr = targets,
  *                       sten_s in its slot order), including the chain rule through the rotation e^{-i m angle(x)}.
- * I * R * F complex numbers (gather) must fit the CU's 160 KB of LDS; any channel count otherwise. */
+ * Any channel count: a workgroup takes as many input channels as its R * F accumulators per channel fit in the CU's 160 KB of LDS. */
 typedef enum fc_dtype { FC_F32 = 0, FC_F64 = 1 } fc_dtype;       /* real scalar type of a complex tensor: complex64 / complex128 */
 int fc_shape_compiled(int32_t n_rings, int32_t band_limit);
 int fc_generic_gather(const void* x, const void* sten_t, const fc_csr* by_target, void* contrib, int32_t n_targets, int32_t I,

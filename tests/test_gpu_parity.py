@@ -582,6 +582,7 @@ def test_empty_graph_and_isolated_vertices(dev):
     (90, 6, 7, 5, 4, 2),           # (band limit 0 cannot be constructed in the reference either: xavier on an empty tensor)
     (60, 5, 70, 66, 2, 12),        # wide and many rings: no channel blocks on this path
     (40, 4, 6, 6, 5, 11),
+    (30, 4, 180, 9, 5, 12),        # 180 channels x 12 rings x 11 frequencies: the response of a target exceeds a CU's LDS -> channel blocks
 ], ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d' % s)
 def test_any_rings_and_band_limit_run_time_path(shape, dev):
     """(n_rings, band_limit) pairs without specialised kernels -- n_rings > 8 or band_limit > 3 -- take the run-time path
