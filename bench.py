@@ -229,7 +229,7 @@ PROTOCOL_NOTE = ('value / ms_per_step: literally the command line -- `warmup` un
                  'run lives at; reported beside it, never as value (--cold skips it)')
 
 
-def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, after_timed=None, settle=True):
+def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, after_timed=None, settle=True, head_start_cycles=0):
     """-> (seconds for `steps` steps under the LITERAL protocol, max over ranks; info).
 
     The literal protocol -- `warmup` steps, fence, `steps` steps, fence, as the first GPU work of the process -- is the value
@@ -260,6 +260,14 @@ def timed_loop(step, steps, warmup, use_dist, dev, backend, before_timed=None, a
         elapsed = time.perf_counter() - t0
         if before_timed is not None:            # the instrumented pass: same steps, event pairs on a sample of the launches, untimed
             before_timed()
+            if head_start_cycles:
+                for _ in range(2):              # the per-operator path's own first steps (allocator growth, caches) are not sampled
+                    step()
+                before_timed()
+                # network modes (the instrumented steps run the per-operator host path): the host gets a head start behind a spinning
+                # kernel -- an event pair brackets a launch on the GPU's time line only while the launch queue is not empty (a
+                # bracket the host is late for also counts the wait for its kernel)
+                torch.cuda._sleep(head_start_cycles)
             for _ in range(steps):
                 step()
             fence()
@@ -322,6 +330,56 @@ def sum_over_ranks(value, use_dist, dev, backend):
     return int(t.item())
 
 
+def _timeit_ms(fn, n_warm=10, n=50):
+    for _ in range(n_warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def _host_enqueue_ms(fn, n=5, reps=5):
+    """what the HOST needs to enqueue a step: a few steps issued behind a synchronisation, timed until the last call returns (the
+    launch queue is far from full after five steps, so nothing here waits for the GPU)"""
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        best = dt if best is None else min(best, dt)
+    torch.cuda.synchronize()
+    return best
+
+
+def host_and_replay_extras(out, step):
+    """host enqueue time, the step replayed as one HIP graph, and the per-operator host path of the same step (single GPU only)"""
+    out['host_enqueue_ms_per_step'] = {'block_level_calls': _host_enqueue_ms(step),
+                                       'note': 'host time to enqueue one step (Python, autograd, ctypes, allocator): five steps issued '
+                                               'behind a synchronisation, timed until the last call returns, best of five; the step is '
+                                               'GPU-bound while this stays below the replayed time'}
+    try:
+        from fieldconv_amd.utils import StepGraph
+        sg = StepGraph(lambda: step())
+        out['graph_replay'] = {'ms_per_step': _timeit_ms(sg.replay, 20, 100),
+                               'note': 'the same forward + loss + backward captured once and replayed (fieldconv_amd.utils.StepGraph): one '
+                                       'mesh only -- not what a training run over a dataset can use'}
+        out['eager_over_replay'] = out['ms_per_step'] / out['graph_replay']['ms_per_step']
+    except Exception as exc:                      # noqa: BLE001
+        out['graph_replay'] = {'error': repr(exc)[:200]}
+    os.environ['FIELDCONV_BLOCK_CALLS'] = '0'
+    try:
+        out['host_enqueue_ms_per_step']['per_operator_calls'] = _host_enqueue_ms(step)
+        out['per_operator_calls'] = {'ms_per_step': _timeit_ms(step), 'note': 'the same step with every block composed of per-operator autograd '
+                                                                            'nodes and foreign calls (FIELDCONV_BLOCK_CALLS=0)'}
+    finally:
+        del os.environ['FIELDCONV_BLOCK_CALLS']
+
+
 # ------------------------------------------------------------------------------------------------ mode dp (config 5)
 def run_dp(args, world, rank, dev, use_dist, backend):
     from fieldconv_amd.data import sphere_support
@@ -374,8 +432,8 @@ def run_dp(args, world, rank, dev, use_dist, backend):
     harvested = {}
 
     def arm_timer():
-        # 17 convolutions per step, every 4th launch of each kernel family bracketed: 4 and 17 are coprime, so over the timed
-        # region every layer of the network is sampled equally often
+        # 17 convolutions per step, every 4th launch of each kernel family bracketed: 4 and 17 are coprime, so over the instrumented
+        # pass every layer of the network is sampled equally often (the blocks run as per-operator calls while the timer is armed)
         kernel_timer.reset(pairs=3 * (args.steps * n_convs // 4 + 2))
         kernel_timer.stride = 4
         kernel_timer.enabled = True
@@ -384,8 +442,8 @@ def run_dp(args, world, rank, dev, use_dist, backend):
         kernel_timer.enabled = False
         harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
 
-    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
-                               settle=not args.cold)
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=None if args.no_kernel_events else arm_timer, after_timed=harvest,
+                               settle=not args.cold, head_start_cycles=4_000_000)
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     identity = run_identity(use_dist, dev, backend, dev.index, {'vertices': N, 'edges': E})
     if rank != 0:
@@ -425,7 +483,7 @@ def run_dp(args, world, rank, dev, use_dist, backend):
                     'frac': per_kernel[dom]['hbm_frac'], 'traffic': None, 'avg_launch_ms': per_kernel[dom]['avg_ms'],
                     'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes_avg_per_launch'],
                     'note': f'mean over the {len(layers)} FieldConv layers of the network (HIP events around every 4th launch of each '
-                            'kernel family inside the timed region; algorithmic bytes of SURVEY 8(d) summed over the layers / their '
+                            'kernel family in the instrumented pass behind the timed region; algorithmic bytes of SURVEY 8(d) summed over the layers / their '
                             'number); traffic: no counter pass is committed for this mode'}
     settled = None
     if info['settled'] is not None:
@@ -444,7 +502,7 @@ def run_dp(args, world, rank, dev, use_dist, backend):
             cpu['sample'] = 'ONE FieldConv layer of the network (C=%d, band_limit=%d), not the whole network: ' % (nf, B) + cpu['sample']
         except Exception as exc:
             cpu = {'value': None, 'unit': 'Medges/s', 'cores': threads, 'kind': 'port', 'sample': f'failed: {type(exc).__name__}: {exc}'}
-    return {
+    out = {
         'metric': 'FieldConv fwd+bwd Medges/s (config 5: correspondence-net replicas, one mesh per GPU, C=64, M=3)',
         'value': E_total * n_convs / (elapsed / args.steps) / 1e6, 'unit': 'Medges/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -461,6 +519,9 @@ def run_dp(args, world, rank, dev, use_dist, backend):
         'ranks': identity,
         'roofline': roofline, 'kernels': per_kernel, 'cpu_baseline': cpu, 'settled': settled, 'protocol': PROTOCOL_NOTE,
     }
+    if world == 1 and not use_dist and not args.no_extras:
+        host_and_replay_extras(out, step)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ mode net (config 3)
@@ -562,8 +623,8 @@ def run_net(args, world, rank, dev, use_dist, backend):
         kernel_timer.enabled = False
         harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
 
-    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
-                               settle=not args.cold)
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=None if args.no_kernel_events else arm_timer, after_timed=harvest,
+                               settle=not args.cold, head_start_cycles=4_000_000)
     E_total = sum_over_ranks(E, use_dist, dev, backend)
     identity = run_identity(use_dist, dev, backend, dev.index, {'vertices': N, 'edges': E})
     if rank != 0:
@@ -622,50 +683,8 @@ def run_net(args, world, rank, dev, use_dist, backend):
         'ranks': identity, 'roofline': roofline, 'kernels': per_kernel, 'settled': settled, 'protocol': PROTOCOL_NOTE,
     }
     if world == 1 and not use_dist and not args.no_extras:
-        def timeit(fn, n_warm=10, n=50):
-            for _ in range(n_warm):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
-        # (0) what the HOST needs to enqueue a step: a few steps issued behind a synchronisation, timed until the last call returns
-        #     (the launch queue is far from full after five steps, so nothing here waits for the GPU)
-        def host_enqueue_ms(fn, n=5, reps=5):
-            best = None
-            for _ in range(reps):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                dt = (time.perf_counter() - t0) / n * 1e3
-                best = dt if best is None else min(best, dt)
-            torch.cuda.synchronize()
-            return best
-        out['host_enqueue_ms_per_step'] = {'block_level_calls': host_enqueue_ms(step),
-                                           'note': 'host time to enqueue one step (Python, autograd, ctypes, allocator): five steps issued '
-                                                   'behind a synchronisation, timed until the last call returns, best of five; the step is '
-                                                   'GPU-bound while this stays below the replayed time'}
-        # (1) the same step replayed as one HIP graph: the GPU-side floor of this schedule
-        try:
-            from fieldconv_amd.utils import StepGraph
-            sg = StepGraph(lambda: step())
-            out['graph_replay'] = {'ms_per_step': timeit(sg.replay, 20, 100),
-                                   'note': 'the same forward + loss + backward captured once and replayed (fieldconv_amd.utils.StepGraph): one '
-                                           'mesh only -- not what a training run over a dataset can use'}
-            out['eager_over_replay'] = out['ms_per_step'] / out['graph_replay']['ms_per_step']
-        except Exception as exc:                      # noqa: BLE001
-            out['graph_replay'] = {'error': repr(exc)[:200]}
-        # (2) the per-operator host path (FIELDCONV_BLOCK_CALLS=0: ~80 foreign calls per step instead of 12)
-        os.environ['FIELDCONV_BLOCK_CALLS'] = '0'
-        try:
-            out['host_enqueue_ms_per_step']['per_operator_calls'] = host_enqueue_ms(step)
-            out['per_operator_calls'] = {'ms_per_step': timeit(step), 'note': 'the same step with every block composed of per-operator autograd '
-                                                                              'nodes and foreign calls (FIELDCONV_BLOCK_CALLS=0)'}
-        finally:
-            del os.environ['FIELDCONV_BLOCK_CALLS']
+        host_and_replay_extras(out, step)
+        timeit = _timeit_ms
         # (3) a DIFFERENT mesh every step, preprocessing included: what the reference's training loop does (segmentation.ipynb:276-317)
         meshes = []
         for i in range(8):
@@ -804,7 +823,7 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         if not graph_step:
             harvested[tag] = {k_: sum(v) / len(v) for k_, v in kernel_timer.elapsed_ms().items() if v}
 
-    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=arm_timer, after_timed=harvest,
+    elapsed, info = timed_loop(step, args.steps, args.warmup, use_dist, dev, backend, before_timed=None if args.no_kernel_events else arm_timer, after_timed=harvest,
                                settle=not args.cold)
     if graph_step:                          # per-kernel times from a few eager steps behind the timed regions
         kernel_timer.reset(pairs=64)
@@ -1044,6 +1063,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cold', action='store_true', help='no clock-settling steps before the measurement (see timed_loop)')
     ap.add_argument('--no-extras', action='store_true', help='only the metric of record (used by the child runs)')
+    ap.add_argument('--no-kernel-events', action='store_true', help='no instrumented pass behind the timed region (roofline: null) -- for runs under a profiler')
     ap.add_argument('--dump', default=None, help='write y and gx of one step to this file (child runs)')
     args = ap.parse_args()
 

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__; __graft_entry__.build()" || exit 1   # never build under the profiler
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/dp_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dp_prof -o dp -- python3 "$ROOT/bench.py" --mode dp --steps 20 --warmup 5 --cold --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dp_prof -o dp -- python3 "$ROOT/bench.py" --mode dp --steps 20 --warmup 5 --cold --no-cpu-baseline --no-extras --no-kernel-events 2>&1 | tail -1 | cut -c1-300
 mkdir -p "$ROOT/gpurun_out/dp_prof"
 cp /tmp/dp_prof/*kernel_stats.csv "$ROOT/gpurun_out/dp_prof/"
 python3 - "$ROOT/gpurun_out/dp_prof/dp_kernel_stats.csv" "${1:-70}" <<'PY'

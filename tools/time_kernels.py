@@ -15,7 +15,44 @@ from fieldconv_amd.transforms import FCPrecomp
 kind = sys.argv[1] if len(sys.argv) > 1 else 'geo'
 N, k, C, B, R = int(os.environ.get('N', 20000)), int(os.environ.get('K', 32)), int(os.environ.get('C', 48)), int(os.environ.get('B', 2)), int(os.environ.get('R', 6))
 dev = torch.device('cuda:0')
-data = (sphere_support(N, k) if kind == 'geo' else random_support(N, k)).to(dev)
+data = sphere_support(N, k) if kind == 'geo' else random_support(N, k)
+
+
+def renumber(data, order):
+    """The same mesh with vertex order[j] renamed j (edges regrouped by source, per-edge fields carried along)."""
+    import numpy as np
+    inv = np.empty(order.size, dtype=np.int64)
+    inv[order] = np.arange(order.size)
+    e = inv[data.supp_edges.numpy()]
+    o = torch.from_numpy(np.argsort(e[:, 0], kind='stable'))
+    data.supp_edges = torch.from_numpy(e)[o]
+    data.logMag, data.logAng, data.xp = data.logMag[o], data.logAng[o], data.xp[o]
+    data.w = data.w[torch.from_numpy(order)]
+    return data
+
+
+def distinct_per_tile(edges, N, by):
+    """Mean number of distinct vertices at the other end of the edges of 16 consecutive vertices (by = 1: tiles of targets)."""
+    import numpy as np
+    e = edges.cpu().numpy()
+    key = (e[:, by] // 16) * np.int64(N) + e[:, 1 - by]
+    return np.unique(key).size / ((N + 15) // 16)
+
+
+# ORDER=rcb16: compact 16-vertex tiles (recursive coordinate bisection of the point set); ORDER=random: a random numbering;
+# default: the generator's (a Fibonacci lattice: consecutive vertices lie a golden angle apart on a latitude band)
+ORDER = os.environ.get('ORDER', '')
+if ORDER and kind == 'geo':
+    import numpy as np
+    from fieldconv_amd.data.synthetic import _fibonacci_sphere, _rcb_order
+    if ORDER.startswith('rcb'):
+        order, _ = _rcb_order(_fibonacci_sphere(N, 0, N, 0), max(1, N // int(ORDER[3:])))
+    else:
+        order = np.random.default_rng(0).permutation(N)
+    data = renumber(data, order)
+print('order %s: distinct sources per tile of 16 targets %.1f, distinct targets per tile of 16 sources %.1f' % (
+    ORDER or 'generator', distinct_per_tile(data.supp_edges, N, 1), distinct_per_tile(data.supp_edges, N, 0)))
+data = data.to(dev)
 edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
 graph = SupportGraph(edges, sten, N, allow_factored=os.environ.get('FACT', '1') == '1')
 lib = _lib.load()
