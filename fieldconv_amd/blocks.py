@@ -87,7 +87,8 @@ def enabled():
     and while the benchmark brackets single kernels with events"""
     env = os.environ
     return (env.get('FIELDCONV_BLOCK_CALLS', '1') != '0' and Fn._ONE_CALL and env.get('FIELDCONV_NO_FUSED_EPILOGUE', '0') != '1'
-            and env.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1' and not Fn.kernel_timer.enabled)
+            and env.get('FIELDCONV_NO_EDGE_SPLIT', '0') != '1' and env.get('FC_SPLIT_FINISH', '0') in ('', '0')
+            and not Fn.kernel_timer.enabled)
 
 
 def _plain_graph(graph):

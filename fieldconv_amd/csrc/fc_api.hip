@@ -200,8 +200,8 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
     return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
 }
 
-static int check_finish_params(const float* gw_eff, const fc_filter_params* params, const fc_dims* dims) {
-    if (!gw_eff || !params || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+static int check_finish_params(const fc_filter_params* params, const fc_dims* dims) {
+    if (!params || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
     if (params->ftype < 0 || params->ftype > 2 || !params->zonal || !params->spherical || !params->g_zonal || !params->g_spherical ||
         (params->ftype == 1 && (!params->phase || !params->g_phase)))
@@ -213,12 +213,13 @@ static int check_finish_params(const float* gw_eff, const fc_filter_params* para
 int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,
                               const fc_filter_params* params, void* stream) {
     {
-        const int rc = check_finish_params(gw_eff, params, dims);
+        const int rc = check_finish_params(params, dims);
         if (rc != FC_OK) return rc;
     }
     // the partials' fixed-order sum and the parameter-gradient chain in ONE launch (FC_SPLIT_FINISH=1: the two kernels)
     static const bool split_finish = [] { const char* e = fc::dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     if (split_finish) {
+        if (!gw_eff) return FC_ERR_BAD_ARGUMENT;        // (the two-kernel development variant passes gW_eff from one to the other)
         int rc = fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
         if (rc != FC_OK) return rc;
         rc = fc_filter_param_grads(gw_eff, params->zonal, params->spherical, params->phase, params->ftype, params->g_zonal,
@@ -232,7 +233,7 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream) {
-    if (!gw_eff) return FC_ERR_BAD_ARGUMENT;
+    if (!gw_eff && !params) return FC_ERR_BAD_ARGUMENT;         // with parameters gW_eff is optional: nullptr = not wanted
     // With parameters the pass ends in ONE launch (fc_backward_finish_params' kernel): when tiles are shared, the sum of the data kernel's
     // partial gx arrays rides there too instead of a launch of its own between the kernels (nobody reads gx before this call returns)
     static const bool split_finish = [] { const char* e = fc::dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
@@ -240,7 +241,7 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     int rc = check_bwd(x, gy, sten_or_rec_s, by_source, wpk_bwd, gx, dims);
     if (rc != FC_OK) return rc;
     if (params) {           // before anything is enqueued: a bad params struct must not leave gx half-finished in the workspace
-        rc = check_finish_params(gw_eff, params, dims);
+        rc = check_finish_params(params, dims);
         if (rc != FC_OK) return rc;
     }
     if (records) {

@@ -68,9 +68,7 @@ static bool resnet_plan(const fc_mesh* m, const fc_resnet_block_params* p, Resne
     pl.g_pre1 = pl.g_h;
     pl.part1 = blk_align(fc_tangent_nonlin_backward_workspace_bytes(m->N, p->C_mid));
     pl.part2 = blk_align(fc_tangent_nonlin_backward_workspace_bytes(m->N, p->C_out));
-    const size_t rf = (size_t)m->R * (2 * m->B + 1) * 8;
-    const size_t gw1 = (size_t)p->C_mid * p->C_in * rf, gw2 = (size_t)p->C_out * p->C_mid * rf;
-    pl.gw = blk_align(gw1 > gw2 ? gw1 : gw2);
+    pl.gw = 0;           // (the convolutions' gW_eff tensors are not wanted: fc_backward_all pulls the partial sums back to the parameters)
     pl.lin_ws = blk_align(fc_tangent_lin_backward_workspace_bytes(m->N, p->C_in, p->C_out));
     const size_t b1 = backward_workspace_bytes(&pl.d1), b2 = backward_workspace_bytes(&pl.d2);
     pl.conv_ws = blk_align(b1 > b2 ? b1 : b2);
@@ -166,7 +164,6 @@ int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* 
     float* g_pre1 = ws.take(pl.g_pre1);
     float* part1 = ws.take(pl.part1);
     float* part2 = ws.take(pl.part2);
-    float* gw = ws.take(pl.gw);
     void* lin_ws = ws.take(pl.lin_ws);
     void* cws = ws.take(pl.conv_ws);
     const int N = mesh->N;
@@ -177,7 +174,7 @@ int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* 
     f2.bias_partials = part2;
     f2.bias_nparts = fc_tangent_nonlin_backward_groups(N);
     f2.g_bias = p->g_bias2;
-    rc = fc_backward_all(act1, g_pre2, mesh->bwd, mesh->by_source, pl.records, wpk_b2, g_h, gw, &f2, cws, pl.conv_ws, &pl.d2, stream);
+    rc = fc_backward_all(act1, g_pre2, mesh->bwd, mesh->by_source, pl.records, wpk_b2, g_h, nullptr, &f2, cws, pl.conv_ws, &pl.d2, stream);
     if (rc != FC_OK) return rc;
     // modReLU_1 and conv1: gx = conv1's input gradient ...
     rc = fc_tangent_nonlin_backward_partial(pre1, p->bias1, g_h, g_pre1, part1, pl.part1, N, p->C_mid, stream);
@@ -186,7 +183,7 @@ int fc_resnet_block_backward(const float* x, const float* g_out, const fc_mesh* 
     f1.bias_partials = part1;
     f1.bias_nparts = fc_tangent_nonlin_backward_groups(N);
     f1.g_bias = p->g_bias1;
-    rc = fc_backward_all(x, g_pre1, mesh->bwd, mesh->by_source, pl.records, wpk_b1, gx, gw, &f1, cws, pl.conv_ws, &pl.d1, stream);
+    rc = fc_backward_all(x, g_pre1, mesh->bwd, mesh->by_source, pl.records, wpk_b1, gx, nullptr, &f1, cws, pl.conv_ws, &pl.d1, stream);
     if (rc != FC_OK) return rc;
     // ... plus the residual branch's (res sees the same cotangent as conv2: g_pre2), added by the TangentLin kernel itself
     return fc::tangent_lin_backward_impl(x, g_pre2, p->res_re, p->res_im, gx, gx, p->g_res_re, p->g_res_im, lin_ws, pl.lin_ws, N, p->C_in,
@@ -225,7 +222,7 @@ static bool echo_plan(const fc_mesh* m, const fc_echo_block_params* p, EchoPlan&
     pl.g_act = pl.pre;
     pl.g_pre = pl.pre;
     pl.part = blk_align(fc_tangent_nonlin_backward_workspace_bytes(m->N, p->n_des));
-    pl.gw = blk_align((size_t)p->n_des * p->C_in * m->R * (2 * m->B + 1) * 8);
+    pl.gw = 0;
     pl.gh = pl.hist;
     pl.conv_ws = blk_align(backward_workspace_bytes(&pl.d));
     pl.ws_bwd = pl.g_act + pl.g_pre + pl.part + pl.gw + pl.gh + pl.conv_ws;
@@ -285,7 +282,6 @@ int fc_echo_block_backward(const float* x, const float* g_desc, const fc_mesh* m
     float* g_act = ws.take(pl.g_act);
     float* g_pre = ws.take(pl.g_pre);
     float* part = ws.take(pl.part);
-    float* gw = ws.take(pl.gw);
     float* gh = ws.take(pl.gh);
     void* cws = ws.take(pl.conv_ws);
     const int N = mesh->N;
@@ -297,7 +293,7 @@ int fc_echo_block_backward(const float* x, const float* g_desc, const fc_mesh* m
     f.bias_partials = part;
     f.bias_nparts = fc_tangent_nonlin_backward_groups(N);
     f.g_bias = p->g_bias;
-    return fc_backward_all(x, g_pre, mesh->bwd, mesh->by_source, pl.records, wpk_b, gx, gw, &f, cws, pl.conv_ws, &pl.d, stream);
+    return fc_backward_all(x, g_pre, mesh->bwd, mesh->by_source, pl.records, wpk_b, gx, nullptr, &f, cws, pl.conv_ws, &pl.d, stream);
 }
 
 }  // extern "C"

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B, const int po0,
     const int pi0, const int Ifull, const float* __restrict__ bias_partials, const int bias_nparts, float* __restrict__ g_bias,
     const int bias_block0, const f32x4* __restrict__ gx_parts, f32x4* __restrict__ gx, const size_t gx_count4, const size_t gx_stride4,
-    const int gx_nparts, const size_t gx_tail_floats, const int gx_block0) {
+    const int gx_nparts, const size_t gx_tail_floats, const int gx_block0, const int dbg) {
     // (po0, pi0, Ifull: the filter is the block [po0, po0 + O) x [pi0, pi0 + I) of parameter tensors with Ifull input channels)
     __shared__ float2 part[kRpGroups][kRpPairs * 8 * 7];     // [group][(r*F + f)*16 + pair]
     __shared__ float2 gws[kRpPairs * 8 * 7];                 // [pair][r][f]
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         if (lane == 0) g_bias[c] = s;
         return;
     }
+    if (dbg & 8) return;
     const int F = 2 * B + 1;
     const int nit = (I + kRpPairs - 1) / kRpPairs;
     const int o = blockIdx.x / nit, i0 = (blockIdx.x - o * nit) * kRpPairs;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         const int f = rf % F, r = rf / F;
         const int i = i0 + pi;
         float2 s = make_float2(0.f, 0.f);
-        if (i < I) {
+        if (i < I && !(dbg & 1)) {
             const size_t ro = st.pairs ? (size_t)dump_k(r, o, R, O, true) * st.so : (size_t)r * st.sr + (size_t)o * st.so;
             const float2* src = gwp + ro + (size_t)f * st.sf + i;
             const int pend = min((grp + 1) * per, P);
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         part[grp][e] = s;
     }
     __syncthreads();
+    if (dbg & 4) { if (threadIdx.x == 0 && g_zonal) g_zonal[blockIdx.x] = part[0][0].x; return; }
     const float sc = 1.f / (float)F;
     for (int e = threadIdx.x; e < nent; e += kRpThreads) {
         const int pi = e % kRpPairs, rf = e / kRpPairs;
@@ -418,13 +420,24 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         for (int grp = 1; grp < kRpGroups; ++grp) { s.x += part[grp][e].x; s.y += part[grp][e].y; }      // fixed order
         s.x *= sc;
         s.y *= sc;
-        if (gw_out && i0 + pi < I) gw_out[(((size_t)o * I + i0 + pi) * R + r) * F + f] = s;
         gws[(pi * 8 + r) * 7 + f] = s;
     }
     __syncthreads();
+    if (gw_out) {
+        // gW_eff[o][i0 .. i0+15][r][f] is ONE contiguous block of the output: written in its own order from LDS (entry by entry from the
+        // loop above the 8-byte stores lie R*F*8 bytes apart -- 11 of this launch's 16.7 us at 64 channels, band limit 3)
+        const int RF = R * F;
+        const int npi = min(kRpPairs, I - i0);
+        float2* const dst = gw_out + ((size_t)o * I + i0) * RF;
+        for (int j = threadIdx.x; j < npi * RF; j += kRpThreads) {
+            const int pi = j / RF, rem = j - pi * RF;
+            const int r = rem / F, f = rem - r * F;
+            dst[j] = gws[(pi * 8 + r) * 7 + f];
+        }
+    }
     const int pair = threadIdx.x / R, r = threadIdx.x - pair * R;
     const bool valid = pair < kRpPairs && i0 + pair < I;
-    if (valid)
+    if (valid && !(dbg & 2))
         param_grads_entry(gws + (pair * 8 + r) * 7, zonal, sph, phase, ftype, g_zonal, g_sph, gph + (pair * 8 + r) * (kMaxB + 1), Ifull, R, B,
                           po0 + o, pi0 + i0 + pair, r);
     __syncthreads();
@@ -446,6 +459,7 @@ int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, s
     const int nit = (d->I + kRpPairs - 1) / kRpPairs;
     const RpStrides st{sp, sr, sf, so, ring_pairs ? 1 : 0};
     const int main_blocks = d->O * nit;
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG_RP"); return e ? atoi(e) : 0; }();      // development: 1 no partial loads, 2 no parameter chain
     const int bias_blocks = (bias_partials && bias_nparts > 0 && g_bias) ? (d->O + kRpThreads / 64 - 1) / (kRpThreads / 64) : 0;
     const bool sum_gx = gx_parts && gx && gx_nparts > 1;
     const size_t gx_floats = gx_count * 2, gx_count4 = sum_gx ? (gx_floats + 3) / 4 : 0;
@@ -454,7 +468,7 @@ int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, s
                        reinterpret_cast<const float2*>(gwp), st, P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph,
                        g_phase, d->O, d->I, d->R, d->B, o0, i0, Ifull > 0 ? Ifull : d->I, bias_partials, bias_nparts, g_bias, main_blocks,
                        reinterpret_cast<const f32x4*>(gx_parts), reinterpret_cast<f32x4*>(gx), gx_count4, gx_stride / 2, gx_nparts,
-                       gx_floats % 4, main_blocks + bias_blocks);
+                       gx_floats % 4, main_blocks + bias_blocks, dbg);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

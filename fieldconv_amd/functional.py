@@ -306,7 +306,10 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
     this pass (fc_filter_params' rider; needs params)."""
     O, I, R, F = wshape
     gx = torch.empty_like(x)
-    gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device)
+    # with module parameters only their gradients are wanted: the (O,I,R,F) tensor is never written (gw_eff = NULL)
+    # (the development library's two-kernel finish, FC_SPLIT_FINISH=1, hands gW_eff from one kernel to the other)
+    want_gw = params is None or os.environ.get('FC_SPLIT_FINISH', '0') not in ('', '0')
+    gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device) if want_gw else None
     nbytes = plan.ws_bwd
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     sten = graph.rec_s if graph.factored else graph.sten_s
@@ -322,8 +325,9 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
                             g_p.data_ptr() if g_p is not None else None)
         if bias_sum is not None:
             fp.bias_partials, fp.bias_nparts, fp.g_bias = bias_sum[0].data_ptr(), bias_sum[1], bias_sum[2].data_ptr()
+    gwp = _p(gw) if gw is not None else None
     if graph.on_gx is None and _ONE_CALL and not kernel_timer.enabled:
-        check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, plan.records, _p(wpk_b), _p(gx), _p(gw),
+        check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, plan.records, _p(wpk_b), _p(gx), gwp,
                                   ctypes.byref(fp) if fp is not None else None, wsp, nbytes, plan.dref, st), 'fc_backward_all')
         return gx, gw, pgrads
     with _timed('fc_backward_data'):
@@ -338,7 +342,7 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
     with _timed('fc_backward_filter'):
         check(lib.fc_backward_filter(_p(x), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_filter')
     if fp is not None:      # partial sums + parameter gradients in one launch
-        check(lib.fc_backward_finish_params(_p(gw), wsp, nbytes, plan.dref, plan.records, ctypes.byref(fp), st), 'fc_backward_finish_params')
+        check(lib.fc_backward_finish_params(gwp, wsp, nbytes, plan.dref, plan.records, ctypes.byref(fp), st), 'fc_backward_finish_params')
     else:
         check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_finish')
     return gx, gw, pgrads

@@ -191,9 +191,11 @@ int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, c
  * fc_forward_params = fc_pack_filter_params (wpk_bwd may be NULL; `records` as above) + fc_forward (kind 0) / fc_forward_factored (1) /
  *                     fc_forward_geometric (2), same arguments;
  * fc_backward_all   = fc_backward_data (records 0) or fc_backward_data_factored (1) + fc_backward_filter +
- *                     fc_backward_finish into gw_eff (required) + fc_filter_param_grads when params is not NULL (then the pass
+ *                     fc_backward_finish into gw_eff + fc_filter_param_grads when params is not NULL (then the pass
  *                     ends in fc_backward_finish_params' single launch, which also adds the data kernel's partial gx arrays when
- *                     tiles were shared: gx is complete when the call's work is, not between its kernels). */
+ *                     tiles were shared: gx is complete when the call's work is, not between its kernels).  gw_eff is required
+ *                     without params and OPTIONAL with them: NULL = only the parameter gradients are wanted (a module's backward
+ *                     pass; the (O,I,R,F) tensor is then never written). */
 typedef struct fc_filter_params {
     const float* zonal;
     const float* spherical;
@@ -216,7 +218,7 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
                     const float* wpk_bwd, float* gx, float* gw_eff, const fc_filter_params* params, void* workspace,
                     size_t workspace_bytes, const fc_dims* dims, void* stream);
 /* fc_backward_finish + fc_filter_param_grads in ONE launch: every workgroup sums the partials of its
- * (output channel, 16 input channels) block in the fixed order, writes gw_eff and pulls the block back to the parameters.
+ * (output channel, 16 input channels) block in the fixed order, writes gw_eff (unless NULL) and pulls the block back to the parameters.
  * The partials are summed in four consecutive groups whose sums are then added in order: deterministic, but rounded
  * differently from fc_backward_finish's single chain.  fc_backward_all uses it when it is given params. */
 int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records,

@@ -106,6 +106,18 @@ def timeit(fn, reps=20):
     return ts[len(ts) // 2], ts[0]
 
 
+# the finishing launch (partial sums + parameter-gradient chain, ftype 1)
+zon = torch.randn(C, C, R, generator=g).to(dev)
+sphp = torch.randn(C, C, R, B, 2, generator=g).to(dev)
+php = torch.randn(C, C, B + 1, generator=g).to(dev)
+gz, gs, gp = torch.empty_like(zon), torch.empty_like(sphp), torch.empty_like(php)
+fp = _lib.FcFilterParams(zon.data_ptr(), sphp.data_ptr(), php.data_ptr(), 1, gz.data_ptr(), gs.data_ptr(), gp.data_ptr(), None, 0, None)
+
+
+def finish():
+    lib.fc_backward_finish_params(None if os.environ.get('NO_GW') else _p(gw), _p(ws), nb, ctypes.byref(dims), REC, ctypes.byref(fp), _stream())
+
+
 which = os.environ.get('WHICH', 'fb')
 tag = os.environ.get('FC_DEBUG', '0') + '/' + os.environ.get('FC_DEBUG_BWD', '0') + (' factored' if FACT else ' dense')
 if 'f' in which:
@@ -113,4 +125,5 @@ if 'f' in which:
 if 'b' in which:
     print(f'FC_DEBUG={tag} {kind} bwd_data median/min us: %.1f %.1f' % timeit(bwd_data))
     print(f'FC_DEBUG={tag} {kind} bwd_filter median/min us: %.1f %.1f' % timeit(bwd_filter))
+    print(f'FC_DEBUG={tag} {kind} finish median/min us: %.1f %.1f' % timeit(finish))
     print('gx checksum: %.9e %.9e' % (gx.abs().double().sum().item(), gx[::97].real.double().sum().item()))
