@@ -35,7 +35,8 @@ SWITCHES = {
     'FIELDCONV_NO_FUSED_EPILOGUE': '1: residual add and modReLU as separate operators',
     'FIELDCONV_SEPARATE_CALLS': '1: one foreign call per kernel instead of fc_forward_params / fc_backward_all',
     'FIELDCONV_CPP_NODES': '0: the block-level autograd nodes in Python (fieldconv_amd/blocks.py) instead of the C++ ones (fc_torch_nodes.so)',
-    'FIELDCONV_ECHO_TAIL': "0: ECHOBlock's dense tail as torch's own Linear / ReLU autograd nodes instead of one node",
+    'FIELDCONV_ECHO_TAIL': "0: ECHOBlock's dense tail as torch's own Linear / ReLU autograd nodes instead of one node; aten: one node composed "
+                           "of ATen GEMMs instead of the native head (fc_echo_head_*)",
     'FIELDCONV_BLOCK_CALLS': '0: FCResNetBlock / ECHOBlock / LiftBlock composed of per-operator autograd nodes instead of the block-level entry points',
     # ---- read by bench.py only
     'BENCH_BACKEND': 'gloo: several ranks share a device (test rigs); default nccl (= RCCL)',

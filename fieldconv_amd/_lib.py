@@ -49,6 +49,12 @@ class FcEchoBlockParams(ctypes.Structure):
     _fields_ = [('C_in', _c_int32), ('n_des', _c_int32), ('n_bins', _c_int32), ('conv', FcFilterParams), ('bias', _vp), ('g_bias', _vp)]
 
 
+class FcEchoHeadParams(ctypes.Structure):
+    """fc_echo_head_params: ECHOBlock's dense tail (lin1, lin2, lin3, res) and where its gradients go"""
+    _fields_ = [('D', _c_int32), ('H1', _c_int32), ('H2', _c_int32), ('C_in', _c_int32), ('C_out', _c_int32)] + \
+               [(n, _vp) for n in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3', 'wr', 'br', 'g_w1', 'g_b1', 'g_w2', 'g_b2', 'g_w3', 'g_b3', 'g_wr', 'g_br')]
+
+
 class FcLiftBlockParams(ctypes.Structure):
     _fields_ = [('C_in', _c_int32), ('C_out', _c_int32), ('ftype', _c_int32), ('zonal_ang', _vp), ('zonal_mag', _vp), ('phase', _vp),
                 ('bias', _vp), ('g_zonal_ang', _vp), ('g_zonal_mag', _vp), ('g_phase', _vp), ('g_bias', _vp)]
@@ -58,6 +64,7 @@ _DP = ctypes.POINTER(FcDims)
 _MP = ctypes.POINTER(FcMesh)
 _RBP = ctypes.POINTER(FcResnetBlockParams)
 _EBP = ctypes.POINTER(FcEchoBlockParams)
+_EHP = ctypes.POINTER(FcEchoHeadParams)
 _LBP = ctypes.POINTER(FcLiftBlockParams)
 _CP = ctypes.POINTER(FcCsr)
 _EP = ctypes.POINTER(FcEpilogue)
@@ -144,6 +151,10 @@ SIGNATURES = {
     'fc_echo_block_workspace_bytes': (_sz, [_MP, _EBP, _c_int32]),
     'fc_echo_block_forward': (ctypes.c_int, [_vp, _MP, _vp, _vp, _EBP, _vp, _vp, _sz, _vp, _sz, _vp]),
     'fc_echo_block_backward': (ctypes.c_int, [_vp, _vp, _MP, _vp, _vp, _EBP, _vp, _sz, _vp, _vp, _sz, _vp]),
+    'fc_echo_head_forward_workspace_bytes': (_sz, [_c_int32, _EHP]),
+    'fc_echo_head_forward': (ctypes.c_int, [_vp, _vp, _EHP, _vp, _vp, _vp, _vp, _sz, _c_int32, _vp]),
+    'fc_echo_head_backward_workspace_bytes': (_sz, [_c_int32, _EHP]),
+    'fc_echo_head_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _EHP, _vp, _vp, _vp, _vp, _sz, _c_int32, _vp]),
     'fc_lift_block_saved_bytes': (_sz, [_MP, _LBP]),
     'fc_lift_block_workspace_bytes': (_sz, [_MP, _LBP, _c_int32]),
     'fc_lift_block_forward': (ctypes.c_int, [_vp, _vp, _c_int32, _MP, _vp, _LBP, _vp, _vp, _sz, _vp]),

@@ -42,7 +42,8 @@ def cpp_nodes():
                 spec.loader.exec_module(mod)
                 names = ('fc_resnet_block_forward', 'fc_resnet_block_backward', 'fc_echo_block_forward', 'fc_echo_block_backward',
                          'fc_lift_block_forward', 'fc_lift_block_backward', 'fc_lift_block_workspace_bytes', 'fc_lift_block_saved_bytes',
-                         'fc_soft_abs_forward', 'fc_soft_abs_backward', 'fc_status_string')
+                         'fc_soft_abs_forward', 'fc_soft_abs_backward', 'fc_echo_head_forward', 'fc_echo_head_backward',
+                         'fc_echo_head_forward_workspace_bytes', 'fc_echo_head_backward_workspace_bytes', 'fc_status_string')
                 mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in names})
                 _NODES = mod
             else:
@@ -373,6 +374,66 @@ class _EchoTailFn(torch.autograd.Function):
         return g_d, gx, g_w1, g_b1, g_w2, g_b2, g_w3, gb, g_wr, gb.clone()
 
 
+def _head_params(d, x, w1, w2, w3, wr):
+    return int(d.shape[1]), int(w1.shape[0]), int(w2.shape[0]), int(x.shape[1]), int(w3.shape[0])
+
+
+def head_supported(d, x, w1, w2, w3, wr):
+    """the native head's limits (fc_echo_head_params): the reference's 128 / 64 hidden units, at most 64 channels either side"""
+    D, H1, H2, C, Q = _head_params(d, x, w1, w2, w3, wr)
+    return H1 <= 128 and H2 <= 64 and C <= 64 and Q <= 64 and w1.shape[1] == D and w2.shape[1] == H1 and w3.shape[1] == H2 and \
+        wr.shape == (Q, C)
+
+
+class _EchoHeadFn(torch.autograd.Function):
+    """The same tail as fc_echo_head_forward / fc_echo_head_backward (csrc/fc_head.hip): three launches per pass on the fp32 matrix pipe
+    instead of ~30 (twelve ATen GEMMs -- the weight gradients contract over the vertices into a handful of tiles -- bias sums, masks, adds)."""
+
+    @staticmethod
+    def forward(ctx, d, x, w1, b1, w2, b2, w3, b3, wr, br):
+        lib = _lib.load()
+        d, x = d.contiguous(), x.contiguous()
+        N = int(d.shape[0])
+        D, H1, H2, C, Q = _head_params(d, x, w1, w2, w3, wr)
+        hp = _lib.FcEchoHeadParams(D, H1, H2, C, Q, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                   wr.data_ptr(), br.data_ptr(), None, None, None, None, None, None, None, None)
+        with Fn._on(x.device):
+            nws = lib.fc_echo_head_forward_workspace_bytes(N, ctypes.byref(hp))
+            buf = torch.empty(N * (H1 + H2) + (nws + 3) // 4, dtype=torch.float32, device=x.device)
+            h1, h2, ws = buf[:N * H1].view(N, H1), buf[N * H1:N * (H1 + H2)].view(N, H2), buf[N * (H1 + H2):]
+            y = torch.empty(N, Q, dtype=torch.float32, device=x.device)        # (its own storage: the caller may write into it)
+            check(lib.fc_echo_head_forward(Fn._p(d), Fn._p(x), ctypes.byref(hp), Fn._p(h1), Fn._p(h2), Fn._p(y),
+                                           Fn._p(ws) if nws else None, nws, N, Fn._stream()), 'fc_echo_head_forward')
+        ctx.save_for_backward(d, x, h1, h2, w1, w2, w3, wr)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        d, x, h1, h2, w1, w2, w3, wr = ctx.saved_tensors
+        g = g.contiguous()
+        N = int(d.shape[0])
+        D, H1, H2, C, Q = _head_params(d, x, w1, w2, w3, wr)
+        with Fn._on(x.device):
+            sizes = [N * D, 2 * N * C, H1 * D, H1, H2 * H1, H2, Q * H2, Q, Q * C, Q, N * H1]
+            hp = _lib.FcEchoHeadParams(D, H1, H2, C, Q, w1.data_ptr(), None, w2.data_ptr(), None, w3.data_ptr(), None, wr.data_ptr(), None,
+                                       None, None, None, None, None, None, None, None)
+            nws = lib.fc_echo_head_backward_workspace_bytes(N, ctypes.byref(hp))
+            buf = torch.empty(sum(-(-s // 4) * 4 for s in sizes) + (nws + 3) // 4, dtype=torch.float32, device=x.device)
+            parts, off = [], 0
+            for s in sizes:
+                parts.append(buf[off:off + s])
+                off += -(-s // 4) * 4
+            g_d, gx, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wr, g_br, g_h1 = parts
+            ws = buf[off:]
+            hp.g_w1, hp.g_b1, hp.g_w2, hp.g_b2 = g_w1.data_ptr(), g_b1.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr()
+            hp.g_w3, hp.g_b3, hp.g_wr, hp.g_br = g_w3.data_ptr(), g_b3.data_ptr(), g_wr.data_ptr(), g_br.data_ptr()
+            check(lib.fc_echo_head_backward(Fn._p(d), Fn._p(x), Fn._p(h1), Fn._p(h2), Fn._p(g), ctypes.byref(hp), Fn._p(g_d), Fn._p(gx),
+                                            Fn._p(g_h1), Fn._p(ws), nws, N, Fn._stream()), 'fc_echo_head_backward')
+        return (g_d.view(N, D), torch.view_as_complex(gx.view(N, C, 2)), g_w1.view(H1, D), g_b1, g_w2.view(H2, H1), g_b2, g_w3.view(Q, H2), g_b3,
+                g_wr.view(Q, C), g_br)
+
+
 def echo_block_tail(block, d, x):
     """ECHOBlock's MLP + residual behind the (N, n_des * dS) descriptors as one autograd node, or None when that does not apply"""
     if not (enabled() and Fn.on_device(x)) or x.dtype != torch.complex64 or d.dtype != torch.float32:
@@ -387,10 +448,12 @@ def echo_block_tail(block, d, x):
         if type(lin) is not torch.nn.Linear or w is None or b is None or w.dtype != torch.float32 or not w.is_contiguous():
             return None
         tens += [w, b]
+    # FIELDCONV_ECHO_TAIL=aten (development): the tail composed of ATen GEMMs inside one node, as before the native head
+    native = os.environ.get('FIELDCONV_ECHO_TAIL', '1') != 'aten' and head_supported(d, x, tens[0], tens[2], tens[4], tens[6])
     nodes = cpp_nodes()
     if nodes is not None:
-        return nodes.echo_tail(d, x, *tens)
-    return _EchoTailFn.apply(d, x, *tens)
+        return (nodes.echo_head if native and hasattr(nodes, 'echo_head') else nodes.echo_tail)(d, x, *tens)
+    return (_EchoHeadFn if native else _EchoTailFn).apply(d, x, *tens)
 
 
 # --------------------------------------------------------------------------------------------------------------------- LiftBlock

@@ -43,7 +43,7 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 9; }
+int fc_abi_version(void) { return 10; }
 
 int fc_dev_switches(void) { return fc::kDevSwitches ? 1 : 0; }
 

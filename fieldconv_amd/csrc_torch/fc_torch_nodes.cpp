@@ -28,6 +28,10 @@ struct Api {
     decltype(&fc_lift_block_saved_bytes) lift_saved = nullptr;
     decltype(&fc_soft_abs_forward) soft_abs_fwd = nullptr;
     decltype(&fc_soft_abs_backward) soft_abs_bwd = nullptr;
+    decltype(&fc_echo_head_forward) head_fwd = nullptr;
+    decltype(&fc_echo_head_backward) head_bwd = nullptr;
+    decltype(&fc_echo_head_forward_workspace_bytes) head_fwd_ws = nullptr;
+    decltype(&fc_echo_head_backward_workspace_bytes) head_bwd_ws = nullptr;
     decltype(&fc_status_string) status_string = nullptr;
 } api;
 
@@ -49,6 +53,10 @@ void bind(const std::map<std::string, int64_t>& addrs) {
     take(api.lift_saved, addrs, "fc_lift_block_saved_bytes");
     take(api.soft_abs_fwd, addrs, "fc_soft_abs_forward");
     take(api.soft_abs_bwd, addrs, "fc_soft_abs_backward");
+    take(api.head_fwd, addrs, "fc_echo_head_forward");
+    take(api.head_bwd, addrs, "fc_echo_head_backward");
+    take(api.head_fwd_ws, addrs, "fc_echo_head_forward_workspace_bytes");
+    take(api.head_bwd_ws, addrs, "fc_echo_head_backward_workspace_bytes");
     take(api.status_string, addrs, "fc_status_string");
 }
 
@@ -372,6 +380,64 @@ struct EchoTailFn : public torch::autograd::Function<EchoTailFn> {
     }
 };
 
+// The same tail through the library's own kernels (fc_echo_head_forward / fc_echo_head_backward, csrc/fc_head.hip): three launches per pass
+struct EchoHeadFn : public torch::autograd::Function<EchoHeadFn> {
+    static fc_echo_head_params params(const at::Tensor& d, const at::Tensor& x, const at::Tensor& w1, const at::Tensor& w2, const at::Tensor& w3,
+                                      const at::Tensor& wr) {
+        fc_echo_head_params p{};
+        p.D = (int32_t)d.size(1);
+        p.H1 = (int32_t)w1.size(0);
+        p.H2 = (int32_t)w2.size(0);
+        p.C_in = (int32_t)x.size(1);
+        p.C_out = (int32_t)w3.size(0);
+        p.w1 = fp(w1); p.w2 = fp(w2); p.w3 = fp(w3); p.wr = fp(wr);
+        return p;
+    }
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& d_, const at::Tensor& x_, const at::Tensor& w1, const at::Tensor& b1,
+                              const at::Tensor& w2, const at::Tensor& b2, const at::Tensor& w3, const at::Tensor& b3, const at::Tensor& wr,
+                              const at::Tensor& br) {
+        const at::Tensor d = d_.contiguous(), x = x_.contiguous();
+        c10::DeviceGuard guard(x.device());
+        fc_echo_head_params p = params(d, x, w1, w2, w3, wr);
+        p.b1 = fp(b1); p.b2 = fp(b2); p.b3 = fp(b3); p.br = fp(br);
+        const int64_t N = d.size(0);
+        const int64_t nws = (int64_t)api.head_fwd_ws((int32_t)N, &p);
+        const auto opts = d.options().dtype(at::kFloat);
+        at::Tensor buf = at::empty({N * (p.H1 + p.H2) + (nws + 3) / 4}, opts);
+        at::Tensor h1 = buf.narrow(0, 0, N * p.H1).view({N, p.H1}), h2 = buf.narrow(0, N * p.H1, N * p.H2).view({N, p.H2});
+        at::Tensor y = at::empty({N, p.C_out}, opts);                 // (its own storage: the caller may write into it)
+        check(api.head_fwd(fp(d), fp(x), &p, fpm(h1), fpm(h2), fpm(y), nws ? fpm(buf) + N * (p.H1 + p.H2) : nullptr, (size_t)nws, (int32_t)N,
+                           stream_of(x)), "fc_echo_head_forward");
+        ctx->save_for_backward({d, x, h1, h2, w1, w2, w3, wr});
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto sv = ctx->get_saved_variables();
+        const at::Tensor &d = sv[0], &x = sv[1], &h1 = sv[2], &h2 = sv[3], &w1 = sv[4], &w2 = sv[5], &w3 = sv[6], &wr = sv[7];
+        const at::Tensor g = grads[0].contiguous();
+        c10::DeviceGuard guard(x.device());
+        fc_echo_head_params p = params(d, x, w1, w2, w3, wr);
+        const int64_t N = d.size(0);
+        const auto opts = d.options().dtype(at::kFloat);
+        // one buffer: g_d, gx, the eight parameter gradients, g_h1 (scratch), the workspace
+        const int64_t sizes[11] = {N * p.D, 2 * N * p.C_in, (int64_t)p.H1 * p.D, p.H1, (int64_t)p.H2 * p.H1, p.H2, (int64_t)p.C_out * p.H2,
+                                   p.C_out, (int64_t)p.C_out * p.C_in, p.C_out, N * p.H1};
+        int64_t off[12];
+        off[0] = 0;
+        for (int i = 0; i < 11; ++i) off[i + 1] = off[i] + (sizes[i] + 3) / 4 * 4;
+        const int64_t nws = (int64_t)api.head_bwd_ws((int32_t)N, &p);
+        at::Tensor buf = at::empty({off[11] + (nws + 3) / 4}, opts);
+        auto piece = [&](int i) { return buf.narrow(0, off[i], sizes[i]); };
+        p.g_w1 = fpm(piece(2)); p.g_b1 = fpm(piece(3)); p.g_w2 = fpm(piece(4)); p.g_b2 = fpm(piece(5));
+        p.g_w3 = fpm(piece(6)); p.g_b3 = fpm(piece(7)); p.g_wr = fpm(piece(8)); p.g_br = fpm(piece(9));
+        check(api.head_bwd(fp(d), fp(x), fp(h1), fp(h2), fp(g), &p, fpm(piece(0)), fpm(piece(1)), fpm(piece(10)), fpm(buf) + off[11], (size_t)nws,
+                           (int32_t)N, stream_of(x)), "fc_echo_head_backward");
+        return {piece(0).view({N, p.D}), at::view_as_complex(piece(1).view({N, p.C_in, 2})), piece(2).view({p.H1, p.D}), piece(3),
+                piece(4).view({p.H2, p.H1}), piece(5), piece(6).view({p.C_out, p.H2}), piece(7), piece(8).view({p.C_out, p.C_in}), piece(9)};
+    }
+};
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -397,5 +463,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("echo_tail", [](const at::Tensor& d, const at::Tensor& x, const at::Tensor& w1, const at::Tensor& b1, const at::Tensor& w2,
                           const at::Tensor& b2, const at::Tensor& w3, const at::Tensor& b3, const at::Tensor& wr, const at::Tensor& br) {
         return EchoTailFn::apply(d, x, w1, b1, w2, b2, w3, b3, wr, br);
+    });
+    m.def("echo_head", [](const at::Tensor& d, const at::Tensor& x, const at::Tensor& w1, const at::Tensor& b1, const at::Tensor& w2,
+                          const at::Tensor& b2, const at::Tensor& w3, const at::Tensor& b3, const at::Tensor& wr, const at::Tensor& br) {
+        return EchoHeadFn::apply(d, x, w1, b1, w2, b2, w3, b3, wr, br);
     });
 }

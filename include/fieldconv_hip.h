@@ -411,6 +411,26 @@ int fc_echo_block_backward(const float* x, const float* g_desc, const fc_mesh* m
                            const fc_echo_block_params* p, const void* saved, size_t saved_bytes, float* gx, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* ECHOBlock behind its descriptors, reference nn/echo_block.py:95-103:  y = lin3(relu(lin2(relu(lin1(d))))) + res(softAbs(x)).
+ * d (N, D) f32 the flattened descriptors (D = n_des * fc_echo_hist_dim(n_bins)), x (N, C_in) c64 the block's input, y (N, C_out) f32;
+ * w1 (H1, D), w2 (H2, H1), w3 (C_out, H2), wr (C_out, C_in) and the biases as torch.nn.Linear holds them (the reference: H1 = 128,
+ * H2 = 64); H1 <= 128, H2 <= 64, C_in <= 64, C_out <= 64, else FC_ERR_UNSUPPORTED (the host then composes the tail of dense layers).
+ * forward: h1 (N, H1) and h2 (N, H2) receive the hidden activations (after their ReLUs) -- the caller keeps them, with d and x, for the
+ * backward pass.  backward: g (N, C_out) the cotangent of y; g_d (N, D), gx (N, C_in) c64, every g_* of the struct (weights and biases)
+ * and g_h1 (N, H1, scratch the caller provides) are written.  All products run on v_mfma_f32_16x16x4_f32 (fp32 operands and sums);
+ * three launches per pass (csrc/fc_head.hip). */
+typedef struct fc_echo_head_params {
+    int32_t D, H1, H2, C_in, C_out;
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *wr, *br;
+    float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_wr, *g_br;       /* backward only */
+} fc_echo_head_params;
+size_t fc_echo_head_forward_workspace_bytes(int32_t N, const fc_echo_head_params* p);
+int fc_echo_head_forward(const float* d, const float* x, const fc_echo_head_params* p, float* h1, float* h2, float* y, void* workspace,
+                         size_t workspace_bytes, int32_t N, void* stream);
+size_t fc_echo_head_backward_workspace_bytes(int32_t N, const fc_echo_head_params* p);
+int fc_echo_head_backward(const float* d, const float* x, const float* h1, const float* h2, const float* g, const fc_echo_head_params* p,
+                          float* g_d, float* gx, float* g_h1, void* workspace, size_t workspace_bytes, int32_t N, void* stream);
+
 /* LiftBlock: out = modReLU(TransField(x)), reference nn/lift_block.py:53-55.  x (N,C_in) f32, C_in <= 4, C_out <= 64; lift_sten /
  * sten_stride / slot_to_edge_* as for fc_trans_field_forward / _backward (mesh: N, E, R and the two groupings with nbr; kind, fwd, bwd
  * are not read); phase / g_phase for ftype != 0 only (phase: zeros otherwise). */

@@ -40,6 +40,7 @@ MODES = {
     'blocks_from_per_operator_nodes': {'FIELDCONV_BLOCK_CALLS': '0'},   # FCResNetBlock / ECHOBlock / LiftBlock composed of per-operator autograd nodes
     'block_nodes_in_python': {'FIELDCONV_CPP_NODES': '0'},      # the block-level nodes of fieldconv_amd/blocks.py instead of fc_torch_nodes.so
     'echo_tail_from_torch_nodes': {'FIELDCONV_ECHO_TAIL': '0'},   # ECHOBlock's dense tail as torch's own Linear / ReLU nodes
+    'echo_tail_from_aten_gemms': {'FIELDCONV_ECHO_TAIL': 'aten'},   # ... as one node composed of ATen GEMMs instead of fc_echo_head_*
 }
 
 

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
-    assert _lib.load(path).fc_abi_version() == 9
+    assert _lib.load(path).fc_abi_version() == 10
 
 
 def test_product_library_reads_no_environment_switch():
@@ -65,7 +65,7 @@ def test_cpp_autograd_nodes_build_and_bind():
     assert os.path.exists(path) and not torch_nodes_needs_build()
     nodes = blocks.cpp_nodes()
     assert nodes is not None
-    for name in ('bind', 'GraphRef', 'resnet_block', 'echo_block', 'lift_block', 'echo_tail'):
+    for name in ('bind', 'GraphRef', 'resnet_block', 'echo_block', 'lift_block', 'echo_tail', 'echo_head'):
         assert hasattr(nodes, name), name
     empty = torch.empty(0, dtype=torch.int32)
     ref = nodes.GraphRef([empty] * 8, 10, 0, 6, 2, 1)
@@ -485,7 +485,7 @@ class _CountingLibrary:
 def test_config3_step_takes_at_most_40_foreign_calls(monkeypatch):
     """BASELINE configs[2]'s network (LiftBlock, four FCResNetBlocks, ECHOBlock: nine convolutions; reference
     segmentation.ipynb:196-236) forward + loss + backward: how often does the binding cross into the library?  One call per block and
-    pass = 12 (+ 2 for ECHOBlock's softAbs), where the per-operator path took ~80 (16 per FCResNetBlock).  The reference trains with batch size 1 on a different
+    pass = 12 (+ 2 for ECHOBlock's dense tail, fc_echo_head_*), where the per-operator path took ~80 (16 per FCResNetBlock).  The reference trains with batch size 1 on a different
     ~1k-vertex mesh every step (segmentation.ipynb:120,137), so the host's per-step cost is what a training run sees."""
     from fieldconv_amd import blocks, functional
     header = open(os.path.join(ROOT, 'include', 'fieldconv_hip.h')).read()
@@ -530,7 +530,7 @@ def test_config3_step_takes_at_most_40_foreign_calls(monkeypatch):
     assert all(g is not None for g in grads)
     enq = [c for c in steady if c in counting.enqueue]
     assert sorted(enq) == sorted(['fc_lift_block_forward', 'fc_lift_block_backward', 'fc_echo_block_forward', 'fc_echo_block_backward',
-                                  'fc_soft_abs_forward', 'fc_soft_abs_backward']          # (softAbs: ECHOBlock's linear residual on |x|)
+                                  'fc_echo_head_forward', 'fc_echo_head_backward']        # (ECHOBlock's dense tail behind its descriptors)
                                  + ['fc_resnet_block_forward', 'fc_resnet_block_backward'] * 4), enq
     assert len(steady) <= 40, (len(steady), steady)
     assert len(first) <= 80, (len(first), first)
