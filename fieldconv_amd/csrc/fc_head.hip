@@ -35,6 +35,7 @@ constexpr int kRgStride = kRgTile + 16;      // LDS row stride: the four k rows 
 // contiguous direction is k is stored by 32 lanes along k -- without it they would share four banks
 __device__ __forceinline__ int rg_swz(int k) { return (k >> 2) & 7; }
 constexpr int kRgMaxProblems = 6;
+constexpr int kRgDepth = 2;             // chunks in flight per thread (registers; more would cost the occupancy that hides the rest)
 constexpr int kRgPer = kRgTile * kRgChunk / kRgThreads;      // elements per thread, operand and chunk
 
 struct RgProblem {
@@ -52,52 +53,101 @@ struct RgProblem {
 struct RgArgs {
     RgProblem p[kRgMaxProblems];
     int count;
+    int dbg;                // development (FC_DEBUG_RG): 1 no products, 2 no loads, 4 no staging
 };
 
 __device__ __forceinline__ float soft_abs_of(float2 v) { return is_origin(v) ? 0.f : sqrtf(v.x * v.x + v.y * v.y); }
 
-__global__ __launch_bounds__(kRgThreads) void fc_rgemm_kernel(const RgArgs args) {
-    __shared__ float As[2][kRgChunk][kRgStride], Bs[2][kRgChunk][kRgStride];
-    int pi = 0;
-#pragma unroll
-    for (int q = 1; q < kRgMaxProblems; ++q)
-        if (q < args.count && (int)blockIdx.x >= args.p[q].block0) pi = q;
-    const RgProblem& g = args.p[pi];
+// One 64 x 64 tile of one problem for one k slice.  AK / BN: the operand's contiguous direction is k (A) / n (B) -- the thread index runs
+// along it, so a wavefront's loads are whole segments.  A thread's eight elements per operand and chunk lie a constant step apart; rows
+// and k entries beyond the problem are read clamped (always valid memory) and multiplied by zero: no branch per element.
+template <bool AK, bool BN, bool BABS>
+__device__ __forceinline__ void rgemm_tile(const RgProblem& g, const int tm, const int tn, const int slice, float (&As)[2][kRgChunk][kRgStride],
+                                           float (&Bs)[2][kRgChunk][kRgStride], const int dbg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x - g.block0;
-    const int tm = b % g.tiles_m;
-    b /= g.tiles_m;
-    const int tn = b % g.tiles_n, slice = b / g.tiles_n;
     const int m0 = tm * kRgTile, n0 = tn * kRgTile;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int fr = lane & 15, fq = lane >> 4;
+    // the problem's fields, read once (scalar registers)
+    const float* const gA = g.A;
+    const float* const gB = g.B;
+    const int gM = g.M, gN = g.N;
+    const long sam = g.sam, sak = g.sak, sbk = g.sbk, sbn = g.sbn;
     const int kbeg = slice * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    // the thread index runs along each operand's contiguous direction
-    const bool a_k_fast = g.sak == 1, b_n_fast = g.sbn == 1;
-    float ra[kRgPer], rb[kRgPer];
-    auto fetch = [&](const int k0) {
+    // element j of this thread: A (am0 + AM_STEP j, ak0 + AK_STEP j), B (bk0 + BK_STEP j, bn0 + BN_STEP j)
+    constexpr int AM_STEP = AK ? kRgThreads / kRgChunk : 0, AK_STEP = AK ? 0 : kRgThreads / kRgTile;
+    constexpr int BN_STEP = BN ? 0 : kRgThreads / kRgChunk, BK_STEP = BN ? kRgThreads / kRgTile : 0;
+    const int am0 = AK ? tid / kRgChunk : tid % kRgTile, ak0 = AK ? tid % kRgChunk : tid / kRgTile;
+    const int bn0 = BN ? tid % kRgTile : tid / kRgChunk, bk0 = BN ? tid / kRgTile : tid % kRgChunk;
+    // A thread's loads walk eight pointers per operand, advanced by one chunk per round (rows / columns beyond the problem are clamped to
+    // the last valid one: every address is valid memory); the LDS slots are fixed per thread.  Raw loads only, all sixteen in flight -- a
+    // select on a loaded value would make the compiler wait for it there and then: entries outside the problem are zeroed when the chunk
+    // is staged, and only edge tiles and the last, partial chunk of a slice take that path at all.
+    typedef typename std::conditional<BABS, float2, float>::type BT;
+    const float* pa[kRgPer];
+    const BT* pb[kRgPer];
+    int sa[kRgPer], sb[kRgPer];
+    unsigned amask = 0, bmask = 0;
 #pragma unroll
-        for (int j = 0; j < kRgPer; ++j) {
-            const int idx = tid + j * kRgThreads;
-            const int am = a_k_fast ? idx / kRgChunk : idx % kRgTile, ak = a_k_fast ? idx % kRgChunk : idx / kRgTile;
-            ra[j] = (m0 + am < g.M && k0 + ak < kend) ? g.A[(long)(m0 + am) * g.sam + (long)(k0 + ak) * g.sak] : 0.f;
-            const int bn = b_n_fast ? idx % kRgTile : idx / kRgChunk, bk = b_n_fast ? idx / kRgTile : idx % kRgChunk;
-            float v = 0.f;
-            if (n0 + bn < g.N && k0 + bk < kend) {
-                const long at = (long)(k0 + bk) * g.sbk + (long)(n0 + bn) * g.sbn;
-                v = g.b_abs ? soft_abs_of(reinterpret_cast<const float2*>(g.B)[at]) : g.B[at];
+    for (int j = 0; j < kRgPer; ++j) {
+        const int am = am0 + AM_STEP * j, ak = ak0 + AK_STEP * j;
+        pa[j] = gA + (long)min(m0 + am, gM - 1) * sam + (long)(kbeg + ak) * sak;
+        sa[j] = ak * kRgStride + (am ^ rg_swz(ak));
+        amask |= (m0 + am < gM ? 1u : 0u) << j;
+        const int bn = bn0 + BN_STEP * j, bk = bk0 + BK_STEP * j;
+        pb[j] = reinterpret_cast<const BT*>(gB) + (long)(kbeg + bk) * sbk + (long)min(n0 + bn, gN - 1) * sbn;
+        sb[j] = bk * kRgStride + (bn ^ rg_swz(bk));
+        bmask |= (n0 + bn < gN ? 1u : 0u) << j;
+    }
+    const bool interior = m0 + kRgTile <= gM && n0 + kRgTile <= gN;
+    const long stepa = (long)kRgChunk * sak, stepb = (long)kRgChunk * sbk;
+    // kRgDepth chunks are in flight per thread (registers)
+    float ra[kRgDepth][kRgPer];
+    BT rb[kRgDepth][kRgPer];
+    auto fetch = [&](auto dc, const int k0) {                  // chunks are fetched in k order (the pointers walk)
+        constexpr int d = decltype(dc)::value;
+        if (dbg & 2) return;
+        if (k0 + kRgChunk <= kend) {
+#pragma unroll
+            for (int j = 0; j < kRgPer; ++j) {
+                ra[d][j] = *pa[j];
+                rb[d][j] = *pb[j];
+                pa[j] += stepa;
+                pb[j] += stepb;
             }
-            rb[j] = v;
+        } else {                // the slice's last, partial chunk: k clamped to its last entry
+#pragma unroll
+            for (int j = 0; j < kRgPer; ++j) {
+                const int ka = k0 + ak0 + AK_STEP * j, kb = k0 + bk0 + BK_STEP * j;
+                ra[d][j] = pa[j][(long)(min(ka, kend - 1) - ka) * sak];
+                rb[d][j] = pb[j][(long)(min(kb, kend - 1) - kb) * sbk];
+            }
         }
     };
-    auto stage = [&](const int buf) {
+    float* const Asf = &As[0][0][0];
+    float* const Bsf = &Bs[0][0][0];
+    auto bval = [](const BT& v) {
+        if constexpr (BABS) return soft_abs_of(v);
+        else return v;
+    };
+    auto stage = [&](auto dc, const int kf, const int buf) {     // chunk kf, held by register set d, into LDS buffer buf
+        constexpr int d = decltype(dc)::value;
+        if (dbg & 4) return;
+        float* const ad = Asf + buf * (kRgChunk * kRgStride);
+        float* const bd = Bsf + buf * (kRgChunk * kRgStride);
+        if (interior && kf + kRgChunk <= kend) {
 #pragma unroll
-        for (int j = 0; j < kRgPer; ++j) {
-            const int idx = tid + j * kRgThreads;
-            const int am = a_k_fast ? idx / kRgChunk : idx % kRgTile, ak = a_k_fast ? idx % kRgChunk : idx / kRgTile;
-            As[buf][ak][am ^ rg_swz(ak)] = ra[j];
-            const int bn = b_n_fast ? idx % kRgTile : idx / kRgChunk, bk = b_n_fast ? idx / kRgTile : idx % kRgChunk;
-            Bs[buf][bk][bn ^ rg_swz(bk)] = rb[j];
+            for (int j = 0; j < kRgPer; ++j) {
+                ad[sa[j]] = ra[d][j];
+                bd[sb[j]] = bval(rb[d][j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRgPer; ++j) {
+                const int ak = ak0 + AK_STEP * j, bk = bk0 + BK_STEP * j;
+                ad[sa[j]] = ((amask >> j) & 1u) && kf + ak < kend ? ra[d][j] : 0.f;
+                bd[sb[j]] = ((bmask >> j) & 1u) && kf + bk < kend ? bval(rb[d][j]) : 0.f;
+            }
         }
     };
     f32x4 acc[2][2];
@@ -106,44 +156,100 @@ __global__ __launch_bounds__(kRgThreads) void fc_rgemm_kernel(const RgArgs args)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (kbeg < kend) {
-        fetch(kbeg);
+        static_for<0, kRgDepth>([&](auto dc) {
+            const int k0 = kbeg + decltype(dc)::value * kRgChunk;
+            if (k0 < kend) fetch(dc, k0);
+        });
         int buf = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += kRgChunk, buf ^= 1) {
-            stage(buf);
-            __syncthreads();                                   // chunk k0 is in LDS; the products of chunk k0 - 32 (other buffer) are done
-            if (k0 + kRgChunk < kend) fetch(k0 + kRgChunk);    // in flight during the products below
+        for (int kg = kbeg; kg < kend; kg += kRgDepth * kRgChunk) {
+            static_for<0, kRgDepth>([&](auto dc) {
+                const int k0 = kg + decltype(dc)::value * kRgChunk;
+                if (k0 < kend) {                                           // (uniform)
+                    stage(dc, k0, buf);
+                    __syncthreads();                                       // chunk k0 is in LDS; the products of the chunk before it (other buffer) are done
+                    if (k0 + kRgDepth * kRgChunk < kend) fetch(dc, k0 + kRgDepth * kRgChunk);
+                    if (!(dbg & 1))
 #pragma unroll
-            for (int ks = 0; ks < kRgChunk; ks += 4) {
-                float a[2], bb[2];
+                    for (int ks = 0; ks < kRgChunk; ks += 4) {
+                        float a[2], bb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = As[buf][ks + fq][(wm + 16 * i + fr) ^ rg_swz(ks)];
-                    bb[i] = Bs[buf][ks + fq][(wn + 16 * i + fr) ^ rg_swz(ks)];
+                        for (int i = 0; i < 2; ++i) {
+                            a[i] = As[buf][ks + fq][(wm + 16 * i + fr) ^ rg_swz(ks)];
+                            bb[i] = Bs[buf][ks + fq][(wn + 16 * i + fr) ^ rg_swz(ks)];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], bb[j], acc[i][j]);
+                    }
+                    buf ^= 1;
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], bb[j], acc[i][j]);
-            }
+            });
         }
     }
-    // D layout of v_mfma_f32_16x16x4_f32: lane l holds column l & 15, register t row 4 (l >> 4) + t
-    float* C = g.C + (g.slices > 1 ? (size_t)slice * g.M * g.N : 0);
+    // The tile leaves through LDS: the matrix pipe's result layout (lane l: column l & 15, register t: row 4 (l >> 4) + t) would store
+    // 64-byte pieces; from LDS every row of the tile goes out as 256 contiguous bytes (11 MB of outputs and partials per backward pass).
+    float* C = g.C + (g.slices > 1 ? (size_t)slice * gM * gN : 0);
     const bool epi = g.slices == 1;
+    const float* const bias = epi ? g.bias : nullptr;
+    const bool relu = epi && g.relu;
+    __syncthreads();                                // everyone's products are done: the operand buffers are free
+    float* const tile = &As[0][0][0];               // [64][64 + 4] floats (17 KB of the 20 KB buffer pair)
+    constexpr int TS = kRgTile + 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int m = m0 + wm + 16 * i + 4 * fq + t, n = n0 + wn + 16 * j + fr;
-                if (m < g.M && n < g.N) {
-                    float v = acc[i][j][t];
-                    if (epi && g.bias) v += g.bias[n];
-                    if (epi && g.relu) v = fmaxf(v, 0.f);
-                    C[(size_t)m * g.N + n] = v;
-                }
+            for (int t = 0; t < 4; ++t) tile[(wm + 16 * i + 4 * fq + t) * TS + wn + 16 * j + fr] = acc[i][j][t];
+    __syncthreads();
+    if ((gN & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 16 + (tid >> 4), c = (tid & 15) * 4;
+            const int m = m0 + r, n = n0 + c;
+            if (m < gM && n < gN) {                 // (n < N and N a multiple of 4: the four columns exist)
+                float4 v = *reinterpret_cast<const float4*>(tile + r * TS + c);
+                if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(C + (size_t)m * gN + n) = v;
             }
+        }
+    } else {
+        for (int idx = tid; idx < kRgTile * kRgTile; idx += kRgThreads) {
+            const int r = idx / kRgTile, c = idx % kRgTile;
+            const int m = m0 + r, n = n0 + c;
+            if (m < gM && n < gN) {
+                float v = tile[r * TS + c];
+                if (bias) v += bias[n];
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)m * gN + n] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRgThreads) void fc_rgemm_kernel(const RgArgs args) {
+    __shared__ float As[2][kRgChunk][kRgStride], Bs[2][kRgChunk][kRgStride];
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kRgMaxProblems; ++q)
+        if (q < args.count && (int)blockIdx.x >= args.p[q].block0) pi = q;
+    pi = __builtin_amdgcn_readfirstlane(pi);           // (uniform: the problem's fields are scalar loads from the kernel arguments)
+    const RgProblem& g = args.p[pi];
+    int b = blockIdx.x - g.block0;
+    const int tm = b % g.tiles_m;
+    b /= g.tiles_m;
+    const int tn = b % g.tiles_n, slice = b / g.tiles_n;
+    const bool ak = g.sak == 1, bn = g.sbn == 1;
+    // (B as softAbs of complex numbers: with n as its contiguous direction only -- rg_launch checks)
+    if (g.b_abs) {
+        if (ak) rgemm_tile<true, true, true>(g, tm, tn, slice, As, Bs, args.dbg);
+        else rgemm_tile<false, true, true>(g, tm, tn, slice, As, Bs, args.dbg);
+    } else if (ak && bn) rgemm_tile<true, true, false>(g, tm, tn, slice, As, Bs, args.dbg);
+    else if (ak) rgemm_tile<true, false, false>(g, tm, tn, slice, As, Bs, args.dbg);
+    else if (bn) rgemm_tile<false, true, false>(g, tm, tn, slice, As, Bs, args.dbg);
+    else rgemm_tile<false, false, false>(g, tm, tn, slice, As, Bs, args.dbg);
 }
 
 // The second launch of a k-split product and of the bias gradients, grouped like the first: task t sums `parts` arrays of `count`
@@ -157,6 +263,7 @@ struct RfTask {
     long count, stride;
     int parts, N, relu;
     int block0;
+    int wave;               // one wavefront per output entry (few entries, many parts)
 };
 struct RfArgs {
     RfTask t[kRfMaxTasks];
@@ -170,6 +277,22 @@ __global__ __launch_bounds__(kRfThreads) void fc_rgemm_finish_kernel(const RfArg
     for (int q = 1; q < kRfMaxTasks; ++q)
         if (q < args.count && (int)blockIdx.x >= args.t[q].block0) ti = q;
     const RfTask& t = args.t[ti];
+    if (t.wave) {
+        // few sums of many parts (the bias gradients: one number per channel from every 16-row tile): a wavefront per sum -- lanes take
+        // every 64th part in order, then a fixed butterfly
+        const int lane = threadIdx.x & 63;
+        const long col = (long)((int)blockIdx.x - t.block0) * (kRfThreads / 64) + (threadIdx.x >> 6);
+        if (col >= t.count) return;
+        float s = 0.f;
+        for (int p = lane; p < t.parts; p += 64) s += t.part[(long)p * t.stride + col];
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
+        if (lane == 0) {
+            t.out[col] = s;
+            if (t.out2) t.out2[col] = s;
+        }
+        return;
+    }
     const long idx = (long)((int)blockIdx.x - t.block0) * kRfThreads + threadIdx.x;
     if (idx >= t.count) return;
     float s = 0.f;
@@ -195,9 +318,9 @@ static void rg_plan(RgProblem& g) {
     const long tiles = (long)g.tiles_m * g.tiles_n;
     const int cus = num_cus();
     int slices = 1;
-    if (tiles < cus && g.K >= 4 * kRgChunk) {
-        const long want = (2L * cus + tiles - 1) / tiles;                  // about two workgroups per CU
-        const long by_len = (g.K + 4 * kRgChunk - 1) / (4 * kRgChunk);     // at least 128 k entries per slice
+    if (tiles < 2 * cus && g.K >= 8 * kRgChunk) {
+        const long want = (3L * cus + tiles - 1) / tiles;                  // about three workgroups per CU: they hide each other's load latency
+        const long by_len = (g.K + 4 * kRgChunk - 1) / (4 * kRgChunk);     // at least 128 k entries per slice (requested whole: kRgDepth)
         slices = (int)(want < by_len ? want : by_len);
         if (slices < 1) slices = 1;
     }
@@ -219,10 +342,13 @@ static RgProblem rg_problem(const float* A, const float* B, int M, int N, int K,
 static int rg_launch(RgArgs& a, hipStream_t stream) {
     int blocks = 0;
     for (int q = 0; q < a.count; ++q) {
+        if (a.p[q].b_abs && a.p[q].sbn != 1) return FC_ERR_UNSUPPORTED;
         a.p[q].block0 = blocks;
         blocks += a.p[q].tiles_m * a.p[q].tiles_n * a.p[q].slices;
     }
     if (blocks == 0) return FC_OK;
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG_RG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     hipLaunchKernelGGL(fc_rgemm_kernel, dim3(blocks), dim3(kRgThreads), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
@@ -231,7 +357,8 @@ static int rf_launch(RfArgs& a, hipStream_t stream) {
     int blocks = 0;
     for (int q = 0; q < a.count; ++q) {
         a.t[q].block0 = blocks;
-        blocks += (int)((a.t[q].count + kRfThreads - 1) / kRfThreads);
+        const long per = a.t[q].wave ? kRfThreads / 64 : kRfThreads;
+        blocks += (int)((a.t[q].count + per - 1) / per);
     }
     if (blocks == 0) return FC_OK;
     hipLaunchKernelGGL(fc_rgemm_finish_kernel, dim3(blocks), dim3(kRfThreads), 0, stream, a);
@@ -250,6 +377,10 @@ constexpr int kHdMaxH1 = 128, kHdMaxH2 = 64, kHdMaxQ = 64, kHdMaxC = 64;
 
 struct HeadDims { int N, D, H1, H2, C, Q; };
 
+// A lane first requests a batch of its weight entries -- raw, clamped loads: every one valid memory, none behind a condition, so all are in
+// flight together (one round trip to L2 per 16 entries instead of one per entry) -- then runs the instruction chain, masking at the use.
+constexpr int kHdBatch = 16;
+
 // acc += A[16 rows][K] (LDS, row stride lda) . W^T, W (n, k) row-major with row stride ldw (a torch Linear weight): column tile n0
 __device__ __forceinline__ f32x4 tile_times_wt(const float* a_lds, int lda, const float* __restrict__ w, int ldw, int n0, int nmax, int K, f32x4 acc,
                                                int fr, int fq) {
@@ -257,23 +388,26 @@ __device__ __forceinline__ f32x4 tile_times_wt(const float* a_lds, int lda, cons
     const int n = n0 + fr;
     const float* wrow = w + (size_t)min(n, nmax - 1) * ldw;
     const float keep = n < nmax ? 1.f : 0.f;
-    if ((K & 15) == 0 && (ldw & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {      // four k entries per load
-        for (int j = 0; j < kq; j += 4) {
-            const int k = fq * kq + j;
-            const float4 a4 = *reinterpret_cast<const float4*>(a_lds + fr * lda + k);
-            const float4 b4 = *reinterpret_cast<const float4*>(wrow + k);
-            acc = mfma16(a4.x, b4.x * keep, acc);
-            acc = mfma16(a4.y, b4.y * keep, acc);
-            acc = mfma16(a4.z, b4.z * keep, acc);
-            acc = mfma16(a4.w, b4.w * keep, acc);
+    const bool vec = (K & 15) == 0 && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;      // four k entries per load
+    for (int j0 = 0; j0 < kq; j0 += kHdBatch) {
+        float bv[kHdBatch];
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < kHdBatch; j += 4) {
+                const float4 b4 = *reinterpret_cast<const float4*>(wrow + min(fq * kq + j0 + j, K - 4));
+                bv[j] = b4.x; bv[j + 1] = b4.y; bv[j + 2] = b4.z; bv[j + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kHdBatch; ++j) bv[j] = wrow[min(fq * kq + j0 + j, K - 1)];
         }
-        return acc;
-    }
-    for (int j = 0; j < kq; ++j) {
-        const int k = fq * kq + j;
-        const float av = k < K ? a_lds[fr * lda + k] : 0.f;
-        const float bv = k < K ? wrow[k] * keep : 0.f;
-        acc = mfma16(av, bv, acc);
+#pragma unroll
+        for (int j = 0; j < kHdBatch; ++j) {
+            const int k = fq * kq + j0 + j;
+            const float av = a_lds[fr * lda + min(k, K - 1)];
+            const float b = (j0 + j < kq && k < K) ? bv[j] * keep : 0.f;       // (entries past the contraction: a zero product)
+            acc = mfma16(av, b, acc);
+        }
     }
     return acc;
 }
@@ -284,11 +418,17 @@ __device__ __forceinline__ f32x4 tile_times_w(const float* a_lds, int lda, const
     const int n = n0 + fr;
     const float keep = n < nmax ? 1.f : 0.f;
     const int nc = min(n, nmax - 1);
-    for (int j = 0; j < kq; ++j) {
-        const int k = fq * kq + j;
-        const float av = k < K ? a_lds[fr * lda + k] : 0.f;
-        const float bv = k < K ? w[(size_t)k * ldw + nc] * keep : 0.f;
-        acc = mfma16(av, bv, acc);
+    for (int j0 = 0; j0 < kq; j0 += kHdBatch) {
+        float bv[kHdBatch];
+#pragma unroll
+        for (int j = 0; j < kHdBatch; ++j) bv[j] = w[(size_t)min(fq * kq + j0 + j, K - 1) * ldw + nc];
+#pragma unroll
+        for (int j = 0; j < kHdBatch; ++j) {
+            const int k = fq * kq + j0 + j;
+            const float av = a_lds[fr * lda + min(k, K - 1)];
+            const float b = (j0 + j < kq && k < K) ? bv[j] * keep : 0.f;
+            acc = mfma16(av, b, acc);
+        }
     }
     return acc;
 }
@@ -497,7 +637,7 @@ int fc_echo_head_forward(const float* d, const float* x, const fc_echo_head_para
     if (split) {
         fc::RfArgs fa{};
         fa.count = 1;
-        fa.t[0] = fc::RfTask{static_cast<const float*>(workspace), h1, nullptr, p->b1, (long)N * p->H1, (long)N * p->H1, ra.p[0].slices, p->H1, 1, 0};
+        fa.t[0] = fc::RfTask{static_cast<const float*>(workspace), h1, nullptr, p->b1, (long)N * p->H1, (long)N * p->H1, ra.p[0].slices, p->H1, 1, 0, 0};
         rc = fc::rf_launch(fa, s);
         if (rc != FC_OK) return rc;
     }
@@ -547,15 +687,15 @@ int fc_echo_head_backward(const float* d, const float* x, const float* h1, const
         ra.p[1 + q] = gp;
         if (split)
             fa.t[fa.count++] = fc::RfTask{reinterpret_cast<const float*>(ws + wg[q].off), wg[q].out, nullptr, nullptr, (long)gp.M * gp.N,
-                                          (long)gp.M * gp.N, gp.slices, gp.N, 0, 0};
+                                          (long)gp.M * gp.N, gp.slices, gp.N, 0, 0, 0};
     }
     int rc = fc::rg_launch(ra, s);
     if (rc != FC_OK) return rc;
     // the bias gradients: per-tile column sums in tile order (lin3.bias and res.bias see the same cotangent)
     const long bstride = H1 + H2 + Q;
-    fa.t[fa.count++] = fc::RfTask{bias_part, p->g_b1, nullptr, nullptr, H1, bstride, pl.tiles, H1, 0, 0};
-    fa.t[fa.count++] = fc::RfTask{bias_part + H1, p->g_b2, nullptr, nullptr, H2, bstride, pl.tiles, H2, 0, 0};
-    fa.t[fa.count++] = fc::RfTask{bias_part + H1 + H2, p->g_b3, p->g_br, nullptr, Q, bstride, pl.tiles, Q, 0, 0};
+    fa.t[fa.count++] = fc::RfTask{bias_part, p->g_b1, nullptr, nullptr, H1, bstride, pl.tiles, H1, 0, 0, 1};
+    fa.t[fa.count++] = fc::RfTask{bias_part + H1, p->g_b2, nullptr, nullptr, H2, bstride, pl.tiles, H2, 0, 0, 1};
+    fa.t[fa.count++] = fc::RfTask{bias_part + H1 + H2, p->g_b3, p->g_br, nullptr, Q, bstride, pl.tiles, Q, 0, 0, 1};
     (void)C; (void)D;
     return fc::rf_launch(fa, s);
 }
