@@ -25,27 +25,39 @@ constexpr int kLinThreads = 256;
 constexpr int kLinWaves = kLinThreads / kWave;
 constexpr int kLinChunk = 6;      // k blocks (8 complex inputs each) loaded ahead of their MFMAs
 constexpr int kLinTiles = 4;      // output tiles accumulated together
-constexpr int kLinStage = 8;      // filter entries in flight per thread while staging
+constexpr int kLinStage = 16;     // filter entries in flight per thread while staging
 
 __host__ __device__ inline int lin_plane_floats(int M, int K) { return round_up(M, 16) * slab_stride(round_up(2 * K, 16)); }
 
 __device__ __forceinline__ void lin_load_fragments(float4 (&a)[kLinChunk], const float* row, int kc, int fq, int K, bool vec,
                                                    float keep) {
+    // raw, clamped loads first -- all in flight together -- then the masks: a select right behind its load makes the compiler wait for
+    // that load before it issues the next one (six round trips to L2 / HBM per fragment set instead of one)
     const int last = 2 * K - 1;
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < kLinChunk; ++u) a[u] = *reinterpret_cast<const float4*>(row + min(16 * (kc + u) + 4 * fq, 2 * K - 4));
+        return;                 // (masked where they are used: lin_mask_fragments)
+    }
+    // odd channel counts / unaligned rows: element by element (a rare path: its loads stay behind their conditions)
 #pragma unroll
     for (int u = 0; u < kLinChunk; ++u) {
         const int kr0 = 16 * (kc + u) + 4 * fq;
-        if (vec) {
-            a[u] = *reinterpret_cast<const float4*>(row + min(kr0, 2 * K - 4));
-            if (kr0 > 2 * K - 4) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            a[u].x = kr0 <= last ? row[min(kr0, last)] : 0.f;
-            a[u].y = kr0 + 1 <= last ? row[min(kr0 + 1, last)] : 0.f;
-            a[u].z = kr0 + 2 <= last ? row[min(kr0 + 2, last)] : 0.f;
-            a[u].w = kr0 + 3 <= last ? row[min(kr0 + 3, last)] : 0.f;
-        }
+        a[u].x = kr0 <= last ? row[min(kr0, last)] : 0.f;
+        a[u].y = kr0 + 1 <= last ? row[min(kr0 + 1, last)] : 0.f;
+        a[u].z = kr0 + 2 <= last ? row[min(kr0 + 2, last)] : 0.f;
+        a[u].w = kr0 + 3 <= last ? row[min(kr0 + 3, last)] : 0.f;
         a[u].x *= keep; a[u].y *= keep; a[u].z *= keep; a[u].w *= keep;
     }
+}
+
+// the vector path's raw fragments: rows beyond the mesh and k entries beyond the row count as zero
+__device__ __forceinline__ void lin_mask_fragments(float4 (&a)[kLinChunk], int kc, int fq, int K, bool vec, float keep) {
+    if (!vec) return;
+    const bool on = keep != 0.f;
+#pragma unroll
+    for (int u = 0; u < kLinChunk; ++u)
+        if (!(on && 16 * (kc + u) + 4 * fq <= 2 * K - 4)) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <bool TRANSPOSED>
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
             for (int kc = 0; kc < KB; kc += kLinChunk) {
                 if (!loaded) lin_load_fragments(a, row, kc, fq, K, vec, keep);
                 loaded = false;
+                lin_mask_fragments(a, kc, fq, K, vec, keep);
 #pragma unroll
                 for (int t = 0; t < kLinTiles; ++t) {
                     if (t < tcount && mg + t < MT) {
@@ -131,21 +144,101 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
                     }
                 }
             }
+            // (the addend may be `out` itself: each entry is read and written by this thread only.  A tile's four entries are requested
+            // together, from clamped -- always valid -- addresses, before the first is used: one round trip per tile instead of four)
 #pragma unroll
             for (int t = 0; t < kLinTiles; ++t) {
-                const int mo = (mg + t) * 16 + fr;
+                if (t < tcount && mg + t < MT) {
+                    const int mo = (mg + t) * 16 + fr;
+                    float2 add[4];
+                    if (addend) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int no = blk * 16 + 4 * fq + j;
-                    if (t < tcount && no < N && mo < M) {
-                        float2 v = make_float2(acc_re[t][j], acc_im[t][j]);
-                        if (addend) {           // (may be `out` itself: each entry is read and written by this thread only)
-                            const float2 s = addend[(size_t)no * M + mo];
-                            v.x += s.x;
-                            v.y += s.y;
-                        }
-                        out[(size_t)no * M + mo] = v;
+                        for (int j = 0; j < 4; ++j) add[j] = addend[(size_t)min(blk * 16 + 4 * fq + j, N - 1) * M + min(mo, M - 1)];
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int no = blk * 16 + 4 * fq + j;
+                        if (no < N && mo < M) {
+                            float2 v = make_float2(acc_re[t][j], acc_im[t][j]);
+                            if (addend) {
+                                v.x += add[j].x;
+                                v.y += add[j].y;
+                            }
+                            out[(size_t)no * M + mo] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The same product for meshes whose 16-vertex blocks cannot occupy the chip (the split walk above: one block per workgroup, its output
+// tiles dealt to the wavefronts) WITHOUT the filter's way through LDS: a wavefront needs only its own 16 output channels of the filter --
+// requested, with the block's input rows, as one batch of loads straight into the matrix pipe's operand layout (lane l: output channel
+// l & 15, input channels 8 kb + 2 (l >> 4) and the next) -- so the kernel has no LDS, no barrier and one round trip to L2 before its
+// instruction chain, where the staged walk zeroes 67 KB, stages the filter and synchronises twice (10.6 -> us at 4 999 vertices and 64
+// channels).  The products and their order are the staged walk's: bit-identical.  K % 8 == 0, K <= 64, 16-byte aligned rows.
+constexpr int kLinDirectKB = 8;          // k blocks of 16 real entries: up to 64 complex input channels
+
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(kLinThreads) void tangent_lin_direct_kernel(const float2* __restrict__ in, const float* __restrict__ wre,
+                                                                         const float* __restrict__ wim, float2* out, const float2* addend, int N,
+                                                                         int K, int M, int ldw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nblocks = (N + 15) / 16, MT = (M + 15) / 16, KB = K / 8;
+    const float* in_f = reinterpret_cast<const float*>(in);
+    for (int mt = wave; mt < MT; mt += kLinWaves) {
+        const int m = mt * 16 + fr, mc = min(m, M - 1);
+        // my filter fragments: (re, -im | im, re) of two input channels per k block
+        float2 w_re[kLinDirectKB], w_im[kLinDirectKB];
+#pragma unroll
+        for (int kb = 0; kb < kLinDirectKB; ++kb) {
+            const int c0 = min(8 * kb + 2 * fq, K - 2);
+            if (TRANSPOSED) {
+                w_re[kb] = make_float2(wre[(size_t)c0 * ldw + mc], wre[(size_t)(c0 + 1) * ldw + mc]);
+                w_im[kb] = make_float2(-wim[(size_t)c0 * ldw + mc], -wim[(size_t)(c0 + 1) * ldw + mc]);
+            } else {
+                w_re[kb] = *reinterpret_cast<const float2*>(wre + (size_t)mc * ldw + c0);
+                w_im[kb] = *reinterpret_cast<const float2*>(wim + (size_t)mc * ldw + c0);
+            }
+        }
+        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+            const int n = blk * 16 + fr;
+            const float* row = in_f + (size_t)min(n, N - 1) * 2 * K;
+            float4 a[kLinDirectKB];
+#pragma unroll
+            for (int kb = 0; kb < kLinDirectKB; ++kb) a[kb] = *reinterpret_cast<const float4*>(row + min(16 * kb + 4 * fq, 2 * K - 4));
+            float2 add[4];
+            const int mo = mt * 16 + fr;
+            if (addend) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add[j] = addend[(size_t)min(blk * 16 + 4 * fq + j, N - 1) * M + min(mo, M - 1)];
+            }
+            f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = acc_re;
+            const bool row_on = n < N;
+#pragma unroll
+            for (int kb = 0; kb < kLinDirectKB; ++kb) {
+                if (kb < KB) {
+                    const float4 av = row_on ? a[kb] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float2 r2 = w_re[kb], i2 = w_im[kb];
+                    acc_re = mfma16(av.x, r2.x, acc_re);  acc_im = mfma16(av.x, i2.x, acc_im);
+                    acc_re = mfma16(av.y, -i2.x, acc_re); acc_im = mfma16(av.y, r2.x, acc_im);
+                    acc_re = mfma16(av.z, r2.y, acc_re);  acc_im = mfma16(av.z, i2.y, acc_im);
+                    acc_re = mfma16(av.w, -i2.y, acc_re); acc_im = mfma16(av.w, r2.y, acc_im);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int no = blk * 16 + 4 * fq + j;
+                if (no < N && mo < M) {
+                    float2 v = make_float2(acc_re[j], acc_im[j]);
+                    if (addend) {
+                        v.x += add[j].x;
+                        v.y += add[j].y;
+                    }
+                    out[(size_t)no * M + mo] = v;
                 }
             }
         }
@@ -347,6 +440,11 @@ static int lin_grid(int N) {
 // one 16-vertex block per workgroup at a time, its output tiles dealt to the four wavefronts (tangent_lin_kernel: split), when there is
 // more than one tile and the blocks alone cannot give every SIMD of the chip work
 static bool lin_split(int N, int M) { return M > 16 && (N + 15) / 16 <= 8 * num_cus(); }
+// the split walk without LDS (tangent_lin_direct_kernel): K input channels, rows and filter 16-byte / 8-byte aligned
+static bool lin_direct(const void* in, const float* wre, const float* wim, int K, int ldw, bool transposed) {
+    if (K % 8 != 0 || K > 8 * kLinDirectKB || (reinterpret_cast<uintptr_t>(in) & 15)) return false;
+    return transposed || ((ldw & 1) == 0 && (reinterpret_cast<uintptr_t>(wre) & 7) == 0 && (reinterpret_cast<uintptr_t>(wim) & 7) == 0);
+}
 static int lin_grid_split(int N) {
     const int nblocks = (N + 15) / 16;
     return nblocks < 4 * num_cus() ? nblocks : 4 * num_cus();
@@ -363,9 +461,13 @@ int tangent_lin_backward_impl(const float* x, const float* gy, const float* re_w
     const size_t lds = 2 * (size_t)lin_plane_floats(I, O) * sizeof(float);
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     const bool split = lin_split(N, I);
-    hipLaunchKernelGGL(tangent_lin_kernel<true>, dim3(split ? lin_grid_split(N) : lin_grid(N)), dim3(kLinThreads), lds, s,
-                       reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx),
-                       reinterpret_cast<const float2*>(gx_addend), N, O, I, I, split ? 1 : 0);
+    if (split && lin_direct(gy, re_w, im_w, O, I, true))
+        hipLaunchKernelGGL(tangent_lin_direct_kernel<true>, dim3(lin_grid_split(N)), dim3(kLinThreads), 0, s, reinterpret_cast<const float2*>(gy),
+                           re_w, im_w, reinterpret_cast<float2*>(gx), reinterpret_cast<const float2*>(gx_addend), N, O, I, I);
+    else
+        hipLaunchKernelGGL(tangent_lin_kernel<true>, dim3(split ? lin_grid_split(N) : lin_grid(N)), dim3(kLinThreads), lds, s,
+                           reinterpret_cast<const float2*>(gy), re_w, im_w, reinterpret_cast<float2*>(gx),
+                           reinterpret_cast<const float2*>(gx_addend), N, O, I, I, split ? 1 : 0);
     float2* part = reinterpret_cast<float2*>(workspace);
     const int ng = lin_gw_groups(N);
     const int pairs = ((O + 15) / 16) * ((I + 15) / 16);
@@ -386,9 +488,14 @@ int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w,
     const size_t lds = 2 * (size_t)fc::lin_plane_floats(O, I) * sizeof(float);
     if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
     const bool split = fc::lin_split(N, O);
-    hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(split ? fc::lin_grid_split(N) : fc::lin_grid(N)), dim3(fc::kLinThreads), lds,
-                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w,
-                       reinterpret_cast<float2*>(y), (const float2*)nullptr, N, I, O, I, split ? 1 : 0);
+    if (split && fc::lin_direct(x, re_w, im_w, I, I, false))
+        hipLaunchKernelGGL(fc::tangent_lin_direct_kernel<false>, dim3(fc::lin_grid_split(N)), dim3(fc::kLinThreads), 0,
+                           static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w, reinterpret_cast<float2*>(y),
+                           (const float2*)nullptr, N, I, O, I);
+    else
+        hipLaunchKernelGGL(fc::tangent_lin_kernel<false>, dim3(split ? fc::lin_grid_split(N) : fc::lin_grid(N)), dim3(fc::kLinThreads), lds,
+                           static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w,
+                           reinterpret_cast<float2*>(y), (const float2*)nullptr, N, I, O, I, split ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
