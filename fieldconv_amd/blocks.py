@@ -436,7 +436,8 @@ class _EchoHeadFn(torch.autograd.Function):
 
 def echo_block_tail(block, d, x):
     """ECHOBlock's MLP + residual behind the (N, n_des * dS) descriptors as one autograd node, or None when that does not apply"""
-    if not (enabled() and Fn.on_device(x)) or x.dtype != torch.complex64 or d.dtype != torch.float32:
+    # (an operator-level node like the convolutions': FIELDCONV_BLOCK_CALLS=0, which composes the BLOCKS of per-operator nodes, keeps it)
+    if not Fn.on_device(x) or x.dtype != torch.complex64 or d.dtype != torch.float32:
         return None
     if os.environ.get('FIELDCONV_ECHO_TAIL', '1') == '0':          # development: torch's own Linear / ReLU nodes
         return None

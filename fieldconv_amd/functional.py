@@ -39,6 +39,7 @@ class KernelTimer:
 
 
 kernel_timer = KernelTimer()
+KEEP_GW_EFF = False      # tests: also materialise gW_eff (O,I,R,F) when a module's backward pass only needs the parameter gradients
 _ONE_CALL = os.environ.get('FIELDCONV_SEPARATE_CALLS', '0') != '1'      # development: one foreign call per kernel instead of per pass
 
 
@@ -308,7 +309,7 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
     gx = torch.empty_like(x)
     # with module parameters only their gradients are wanted: the (O,I,R,F) tensor is never written (gw_eff = NULL)
     # (the development library's two-kernel finish, FC_SPLIT_FINISH=1, hands gW_eff from one kernel to the other)
-    want_gw = params is None or os.environ.get('FC_SPLIT_FINISH', '0') not in ('', '0')
+    want_gw = params is None or KEEP_GW_EFF or os.environ.get('FC_SPLIT_FINISH', '0') not in ('', '0')
     gw = torch.empty((O, I, R, F), dtype=torch.complex64, device=x.device) if want_gw else None
     nbytes = plan.ws_bwd
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
