@@ -42,6 +42,24 @@ __device__ __forceinline__ void tf_load_sten(const float2* __restrict__ lsten, i
     s1 = p[1];
 }
 
+template <bool FACTORS>
+__device__ __forceinline__ void tf_load_sten_t(const float2* __restrict__ lsten, int edge, int R, int r, int stride, float2& s0, float2& s1) {
+    tf_load_sten(lsten, edge, R, r, FACTORS ? 0 : (stride ? stride : 1), s0, s1);
+}
+
+// The per-edge chain of the two gathers (slot -> edge and neighbour -> stencil row and neighbour's value) is latency, not data: kTfAhead
+// edges go through each stage together -- straight-line code, no branch per edge: an edge past the end is the last edge again and its
+// contribution is dropped by a select -- so a group costs two round trips instead of two per edge.  Sums in edge order as before.
+constexpr int kTfAhead = 8;
+
+// the filters of the combination stages, staged once per workgroup: [o][i][r] as in memory
+__device__ __forceinline__ void tf_stage_filters(float* s_zA, float* s_zM, const float* __restrict__ zA, const float* __restrict__ zM, int count) {
+    for (int idx = threadIdx.x; idx < count; idx += kTfWaves * kWave) {
+        s_zA[idx] = zA[idx];
+        s_zM[idx] = zM[idx];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
     const float* __restrict__ x, const float2* __restrict__ lsten, const int32_t* __restrict__ rowptr,
@@ -52,6 +70,7 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
     __shared__ float s_mag[kTfWaves][kTfMaxIn * kTfMaxR];
     __shared__ float2 s_s1[kTfWaves][kTfMaxIn * kTfMaxR];
     __shared__ float2 s_cs[kWave * kTfMaxIn];              // (cos, sin) of phase[o][i]
+    __shared__ float s_zA[kWave * kTfMaxIn * kTfMaxR], s_zM[kWave * kTfMaxIn * kTfMaxR];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Cin = a.Cin, R = a.R, O = a.O, IR = Cin * R;
@@ -60,6 +79,7 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
         sincosf(phase[idx], &s, &c);
         s_cs[idx] = make_float2(c, s);
     }
+    tf_stage_filters(s_zA, s_zM, zA, zM, O * IR);
     __syncthreads();
     // `wpv` (1, 2 or 4) wavefronts share a vertex, each with every wpv-th in-edge (meshes with few vertices and wide
     // supports, see fc_echo.hip); their sums are added in wavefront order
@@ -72,19 +92,37 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
     float mag = 0.f;
     const float xd = active ? x[(size_t)n * Cin + li] : 0.f;
     const int beg = active ? rowptr[n] : 0, end = active ? rowptr[n + 1] : 0;
-    for (int e = beg + sub; e < end; e += wpv) {
-        const int src = nbr[e];
-        const int edge = (int)perm[e];
-        float2 s0, s1;
-        tf_load_sten(lsten, edge, R, lr, a.sten_stride, s0, s1);
-        const float xs = x[(size_t)src * Cin + li];
-        const float d = xs - xd;
-        ang.x += d * s1.x;
-        ang.y += d * s1.y;
-        mag += xs * soft_abs(s0);
-        s1sum.x += s1.x;
-        s1sum.y += s1.y;
-    }
+    auto gather = [&](auto factors) {
+        constexpr bool FACTORS = decltype(factors)::value;
+        for (int e0 = beg + sub; e0 < end; e0 += kTfAhead * wpv) {
+            int src[kTfAhead], edge[kTfAhead];
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                const int e = min(e0 + u * wpv, end - 1);
+                src[u] = nbr[e];
+                edge[u] = (int)perm[e];
+            }
+            float2 s0[kTfAhead], s1[kTfAhead];
+            float xs[kTfAhead];
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                tf_load_sten_t<FACTORS>(lsten, edge[u], R, lr, a.sten_stride, s0[u], s1[u]);
+                xs[u] = x[(size_t)src[u] * Cin + li];
+            }
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                const bool on = e0 + u * wpv < end;
+                const float d = xs[u] - xd;
+                ang.x += on ? d * s1[u].x : 0.f;
+                ang.y += on ? d * s1[u].y : 0.f;
+                mag += on ? xs[u] * soft_abs(s0[u]) : 0.f;
+                s1sum.x += on ? s1[u].x : 0.f;
+                s1sum.y += on ? s1[u].y : 0.f;
+            }
+        }
+    };
+    if (a.sten_stride == 0) gather(std::true_type{});
+    else gather(std::false_type{});
     ang = make_float2(-ang.x, -ang.y);
     if (wpv > 1) {
         if (lane < IR) { s_ang[wave][lane] = ang; s_mag[wave][lane] = mag; s_s1[wave][lane] = s1sum; }
@@ -114,8 +152,8 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
         for (int i = 0; i < Cin; ++i) {
             float2 A = make_float2(0.f, 0.f);
             float M = 0.f;
-            const float* wa = zA + ((size_t)lane * Cin + i) * R;
-            const float* wm = zM + ((size_t)lane * Cin + i) * R;
+            const float* wa = s_zA + (lane * Cin + i) * R;
+            const float* wm = s_zM + (lane * Cin + i) * R;
             for (int r = 0; r < R; ++r) {
                 const float2 sa = s_ang[wave][i * R + r];
                 A.x += sa.x * wa[r];
@@ -146,6 +184,7 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_
     __shared__ float s_gM[kTfWaves][kWave * kTfMaxIn];
     __shared__ float s_t[kTfWaves][kTfMaxIn * kTfMaxR];
     __shared__ float2 s_cs[kWave * kTfMaxIn];
+    __shared__ float s_zA[kWave * kTfMaxIn * kTfMaxR], s_zM[kWave * kTfMaxIn * kTfMaxR];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Cin = a.Cin, R = a.R, O = a.O, IR = Cin * R;
@@ -154,6 +193,7 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_
         sincosf(phase[idx], &s, &c);
         s_cs[idx] = make_float2(c, s);
     }
+    tf_stage_filters(s_zA, s_zM, zA, zM, O * IR);
     __syncthreads();
     const int gw = blockIdx.x * kTfWaves + wave;
     const int li = lane < IR ? lane / R : 0, lr = lane < IR ? lane - (lane / R) * R : 0;
@@ -176,8 +216,8 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_
                 float2 A = make_float2(0.f, 0.f);
                 float M = 0.f;
                 const int oc = lane < O ? lane : 0;
-                const float* wa = zA + ((size_t)oc * Cin + i) * R;
-                const float* wm = zM + ((size_t)oc * Cin + i) * R;
+                const float* wa = s_zA + (oc * Cin + i) * R;
+                const float* wm = s_zM + (oc * Cin + i) * R;
 #pragma unroll
                 for (int r = 0; r < kTfMaxR; ++r)
                     if (r < R) {
@@ -217,7 +257,7 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_vertex_
         float gm = 0.f;
         if (lane < IR) {
             for (int o = 0; o < O; ++o) {
-                const float wa = zA[((size_t)o * Cin + li) * R + lr], wm = zM[((size_t)o * Cin + li) * R + lr];
+                const float wa = s_zA[(o * Cin + li) * R + lr], wm = s_zM[(o * Cin + li) * R + lr];
                 const float2 t = s_gA[wave][o * Cin + li];
                 ga.x += t.x * wa;
                 ga.y += t.y * wa;
@@ -294,15 +334,33 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_input_k
     const int lc = lane < IR ? lane : 0;
     float acc = 0.f;
     const int beg = active ? rowptr[j] : 0, end = active ? rowptr[j + 1] : 0;
-    for (int e = beg + sub; e < end; e += wpv) {
-        const int dst = nbr[e];
-        const int edge = (int)perm[e];
-        float2 s0, s1;
-        tf_load_sten(lsten, edge, R, lr, a.sten_stride, s0, s1);
-        const float2 ga = g_ang[(size_t)dst * IR + lc];
-        const float gm = g_mag[(size_t)dst * IR + lc];
-        acc += gm * soft_abs(s0) - (ga.x * s1.x + ga.y * s1.y);
-    }
+    auto gather = [&](auto factors) {
+        constexpr bool FACTORS = decltype(factors)::value;
+        for (int e0 = beg + sub; e0 < end; e0 += kTfAhead * wpv) {
+            int dst[kTfAhead], edge[kTfAhead];
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                const int e = min(e0 + u * wpv, end - 1);
+                dst[u] = nbr[e];
+                edge[u] = (int)perm[e];
+            }
+            float2 s0[kTfAhead], s1[kTfAhead], ga[kTfAhead];
+            float gm[kTfAhead];
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                tf_load_sten_t<FACTORS>(lsten, edge[u], R, lr, a.sten_stride, s0[u], s1[u]);
+                ga[u] = g_ang[(size_t)dst[u] * IR + lc];
+                gm[u] = g_mag[(size_t)dst[u] * IR + lc];
+            }
+#pragma unroll
+            for (int u = 0; u < kTfAhead; ++u) {
+                const float t = gm[u] * soft_abs(s0[u]) - (ga[u].x * s1[u].x + ga[u].y * s1[u].y);
+                acc += (e0 + u * wpv < end) ? t : 0.f;
+            }
+        }
+    };
+    if (a.sten_stride == 0) gather(std::true_type{});
+    else gather(std::false_type{});
     if (lane < IR) s_t[wave][lane] = acc;
     if (wpv > 1) __syncthreads();
     if (sub != 0 || !active) return;
