@@ -27,14 +27,19 @@ __device__ __forceinline__ float2 filter_entry(const float* __restrict__ zonal, 
         const float* p = sph + (oir * (2 * B) + b) * 2;
         return make_float2(p[0], p[1]);
     }
-    float2 c;
-    if (f == B) c = make_float2(zonal[oir], 0.f);
-    else if (f > B) { const float* p = sph + (oir * B + (f - B - 1)) * 2; c = make_float2(p[0], p[1]); }
-    else { const float* p = sph + (oir * B + (B - 1 - f)) * 2; c = make_float2(p[0], -p[1]); }
+    // every request unconditional and from a valid address (the coefficient of |f - B| = 0 is the zonal one: the spherical slot read for it
+    // is entry 0 and dropped by a select): behind data-dependent branches the loads wait for one another -- the packing and finishing
+    // launches are chains of such round trips, not bandwidth
+    const int q = f >= B ? f - B : B - f;
+    const float z = zonal[oir];
+    float2 sp = make_float2(0.f, 0.f);
+    if (B > 0) sp = *reinterpret_cast<const float2*>(sph + (oir * B + (q > 0 ? q - 1 : 0)) * 2);
+    float ph = 0.f;
+    if (ftype == 1) ph = phase[((size_t)o * I + i) * (B + 1) + q];
+    float2 c = q == 0 ? make_float2(z, 0.f) : make_float2(sp.x, f > B ? sp.y : -sp.y);
     if (ftype == 1) {
-        const int q = f >= B ? f - B : B - f;
         float s, co;
-        sincosf(phase[((size_t)o * I + i) * (B + 1) + q], &s, &co);
+        sincosf(ph, &s, &co);
         c = cmul(c, make_float2(co, s));
     }
     return c;
