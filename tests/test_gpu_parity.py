@@ -1464,3 +1464,44 @@ def test_echo_head_matches_the_dense_layers_in_double_precision(dev, N, D, C, Q,
     y2 = _EchoHeadFn.apply(*leaves)
     grads2 = torch.autograd.grad(y2, leaves, gy)
     assert torch.equal(y, y2) and all(torch.equal(p, q) for p, q in zip(grads, grads2))
+
+
+@pytest.mark.gpu
+def test_echo_head_limits_fall_back_to_the_dense_layers(dev):
+    """The native head takes the reference's hidden widths (<= 128 / 64) and at most 64 channels either side; beyond that the entry points
+    say FC_ERR_UNSUPPORTED, a short workspace FC_ERR_WORKSPACE and a missing pointer FC_ERR_BAD_ARGUMENT -- nothing is enqueued -- and
+    ECHOBlock composes its tail of ATen layers inside one node (blocks._EchoTailFn), with the same result as torch's own modules."""
+    import ctypes
+    from fieldconv_amd import _lib, blocks
+    from fieldconv_amd.functional import _p, _stream
+    lib = _lib.load()
+    N, D, C, Q = 64, 40, 8, 5
+    g = torch.Generator().manual_seed(3)
+    d = torch.rand(N, D, generator=g).to(dev)
+    x = torch.complex(torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)).to(dev)
+    for H1, H2, rc_expected in ((256, 64, -2), (128, 96, -2), (128, 64, 0)):
+        W = [torch.randn(*s, generator=g).to(dev) * 0.1 for s in ((H1, D), (H1,), (H2, H1), (H2,), (Q, H2), (Q,), (Q, C), (Q,))]
+        hp = _lib.FcEchoHeadParams(D, H1, H2, C, Q, *[w.data_ptr() for w in W], *([None] * 8))
+        h1, h2, y = torch.empty(N, H1, device=dev), torch.empty(N, H2, device=dev), torch.empty(N, Q, device=dev)
+        nws = lib.fc_echo_head_forward_workspace_bytes(N, ctypes.byref(hp))
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+        rc = lib.fc_echo_head_forward(_p(d), _p(x), ctypes.byref(hp), _p(h1), _p(h2), _p(y), _p(ws), nws, N, _stream())
+        assert rc == rc_expected, (H1, H2, rc)
+        assert blocks.head_supported(d, x, W[0], W[2], W[4], W[6]) == (rc_expected == 0)
+        if rc_expected == 0:
+            assert lib.fc_echo_head_forward(_p(d), None, ctypes.byref(hp), _p(h1), _p(h2), _p(y), _p(ws), nws, N, _stream()) == -1
+            nb = lib.fc_echo_head_backward_workspace_bytes(N, ctypes.byref(hp))
+            assert nb > 0
+            gbuf = [torch.empty_like(w) for w in W]
+            hp2 = _lib.FcEchoHeadParams(D, H1, H2, C, Q, *[w.data_ptr() for w in W], *[t.data_ptr() for t in gbuf])
+            g_d, gx, g_h1 = torch.empty(N, D, device=dev), torch.empty(N, C, dtype=torch.cfloat, device=dev), torch.empty(N, H1, device=dev)
+            short = torch.empty(16, dtype=torch.uint8, device=dev)
+            assert lib.fc_echo_head_backward(_p(d), _p(x), _p(h1), _p(h2), _p(y), ctypes.byref(hp2), _p(g_d), _p(gx), _p(g_h1), _p(short), 16, N,
+                                             _stream()) == -4
+        else:
+            # the module path: one node of ATen layers, equal to the modules' own composition up to the order of its sums
+            leaves = [d.clone().requires_grad_(True), x.clone().requires_grad_(True)] + [w.clone().requires_grad_(True) for w in W]
+            y_node = blocks._EchoTailFn.apply(*leaves)
+            a = torch.where((x.real.abs() < 1e-7) & (x.imag.abs() < 1e-7), torch.zeros_like(x.real), x.abs())
+            y_ref = torch.relu(torch.relu(d @ W[0].t() + W[1]) @ W[2].t() + W[3]) @ W[4].t() + W[5] + a @ W[6].t() + W[7]
+            assert rel_err(H(y_node), H(y_ref)) < 2e-6
