@@ -520,6 +520,35 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (kDevSwitches) {
+            // Development only (FC_DEBUG_BWD bit 5; never in the product library): what would it cost this kernel to ALSO contract the slab
+            // with the filter, gxt[v,i] = sum_k H[v,k] conj(W_f[k,i]) -- the "H-streaming" restructure of the backward pass?  A
+            // cost prototype: wavefronts 0 .. NMT-1 each run the full-K product of one 16-column tile of gxt -- the slab image as first
+            // operand (row-major fragments, four planes), the OTHER image buffer standing in for a filter image resident in LDS (same
+            // reads, same banks; no room for a real one beside two slab images) -- three matrix instructions per real product pair, and
+            // store their tile.  Same instruction, LDS and store volume as the real thing; the values are meaningless.
+            if ((a.dbg & 32) && wave < mg.NMT) {
+                const lds_f16* arow = img + fr * KSI + 8 * fq;
+                const lds_f16* brow = img0 + (buf ^ 1) * kTile * KSI + fr * KSI + 8 * fq;
+                f32x4 xr = {0.f, 0.f, 0.f, 0.f}, xi = xr;
+                for (int kb = 0; kb < KP / 32; ++kb) {
+                    const u32x4 arh = *reinterpret_cast<lds_u32x4*>(arow + kb * 32), arl = *reinterpret_cast<lds_u32x4*>(arow + kb * 32 + KP);
+                    const u32x4 aih = *reinterpret_cast<lds_u32x4*>(arow + kb * 32 + 2 * KP), ail = *reinterpret_cast<lds_u32x4*>(arow + kb * 32 + 3 * KP);
+                    const u32x4 brh = *reinterpret_cast<lds_u32x4*>(brow + kb * 32), brl = *reinterpret_cast<lds_u32x4*>(brow + kb * 32 + KP);
+                    const u32x4 bih = *reinterpret_cast<lds_u32x4*>(brow + kb * 32 + 2 * KP), bil = *reinterpret_cast<lds_u32x4*>(brow + kb * 32 + 3 * KP);
+                    xr = mfma32h(arh, brh, xr); xr = mfma32h(arh, brl, xr); xr = mfma32h(arl, brh, xr);
+                    xr = mfma32h(aih, bih, xr); xr = mfma32h(aih, bil, xr); xr = mfma32h(ail, bih, xr);
+                    xi = mfma32h(aih, brh, xi); xi = mfma32h(aih, brl, xi); xi = mfma32h(ail, brh, xi);
+                    xi = mfma32h(arh, bih, xi); xi = mfma32h(arh, bil, xi); xi = mfma32h(arl, bih, xi);
+                }
+                // a tile of gxt per (slab, column tile): 16 x 16 complex numbers (written over the partials' buffer, wrapped: this mode's
+                // results are not used)
+                const size_t cap = (size_t)gridDim.x * F * KP * IP;
+                const size_t base = (((size_t)tile * F + f) * mg.NMT + wave) * 256 % (cap - 256);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) ggwp[base + (4 * fq + jj) * 16 + fr] = make_float2(xr[jj] * it, xi[jj] * it);
+            }
+        }
     
     };
     int buf = 0;

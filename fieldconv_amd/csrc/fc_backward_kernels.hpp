@@ -70,7 +70,8 @@ struct BwdArgs {
     unsigned long long* stamps;   // development only (fc_debug_stamp_buffer): s_memtime stamps of workgroup 0 of ONE of the two kernels
     int stamp_who;                // 1: the data kernel stamps, 2: the half2 filter-gradient kernel (FC_STAMP_KERNEL=data|filter)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA, bit3 skip the slab dump,
-                         // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump
+                         // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump,
+                         // bit5 the half2 filter kernel also runs a cost prototype of the H-streaming contraction (fc_backward.hip)
 };
 
 // Frequency groups of the gather: NG walks of the edges with MG frequencies (R * MG complex accumulators per lane) each.  NGX forces a
