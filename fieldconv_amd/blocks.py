@@ -415,17 +415,20 @@ class _EchoHeadFn(torch.autograd.Function):
         N = int(d.shape[0])
         D, H1, H2, C, Q = _head_params(d, x, w1, w2, w3, wr)
         with Fn._on(x.device):
-            sizes = [N * D, 2 * N * C, H1 * D, H1, H2 * H1, H2, Q * H2, Q, Q * C, Q, N * H1]
             hp = _lib.FcEchoHeadParams(D, H1, H2, C, Q, w1.data_ptr(), None, w2.data_ptr(), None, w3.data_ptr(), None, wr.data_ptr(), None,
                                        None, None, None, None, None, None, None, None)
             nws = lib.fc_echo_head_backward_workspace_bytes(N, ctypes.byref(hp))
-            buf = torch.empty(sum(-(-s // 4) * 4 for s in sizes) + (nws + 3) // 4, dtype=torch.float32, device=x.device)
-            parts, off = [], 0
-            for s in sizes:
-                parts.append(buf[off:off + s])
-                off += -(-s // 4) * 4
-            g_d, gx, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wr, g_br, g_h1 = parts
-            ws = buf[off:]
+
+            def carve(sizes, extra=0):
+                buf = torch.empty(sum(-(-s // 4) * 4 for s in sizes) + extra, dtype=torch.float32, device=x.device)
+                parts, off = [], 0
+                for s in sizes:
+                    parts.append(buf[off:off + s])
+                    off += -(-s // 4) * 4
+                return parts, buf[off:]
+            # the parameter gradients in a buffer of their own (they may live on as .grad); the flowing gradients and scratch in another
+            (g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wr, g_br), _ = carve([H1 * D, H1, H2 * H1, H2, Q * H2, Q, Q * C, Q])
+            (g_d, gx, g_h1), ws = carve([N * D, 2 * N * C, N * H1], (nws + 3) // 4)
             hp.g_w1, hp.g_b1, hp.g_w2, hp.g_b2 = g_w1.data_ptr(), g_b1.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr()
             hp.g_w3, hp.g_b3, hp.g_wr, hp.g_br = g_w3.data_ptr(), g_b3.data_ptr(), g_wr.data_ptr(), g_br.data_ptr()
             check(lib.fc_echo_head_backward(Fn._p(d), Fn._p(x), Fn._p(h1), Fn._p(h2), Fn._p(g), ctypes.byref(hp), Fn._p(g_d), Fn._p(gx),

@@ -420,21 +420,27 @@ struct EchoHeadFn : public torch::autograd::Function<EchoHeadFn> {
         fc_echo_head_params p = params(d, x, w1, w2, w3, wr);
         const int64_t N = d.size(0);
         const auto opts = d.options().dtype(at::kFloat);
-        // one buffer: g_d, gx, the eight parameter gradients, g_h1 (scratch), the workspace
-        const int64_t sizes[11] = {N * p.D, 2 * N * p.C_in, (int64_t)p.H1 * p.D, p.H1, (int64_t)p.H2 * p.H1, p.H2, (int64_t)p.C_out * p.H2,
-                                   p.C_out, (int64_t)p.C_out * p.C_in, p.C_out, N * p.H1};
-        int64_t off[12];
+        // the parameter gradients in a buffer of their own (they may live on as .grad); the flowing gradients and scratch in another
+        const int64_t psz[8] = {(int64_t)p.H1 * p.D, p.H1, (int64_t)p.H2 * p.H1, p.H2, (int64_t)p.C_out * p.H2, p.C_out, (int64_t)p.C_out * p.C_in,
+                                p.C_out};
+        int64_t poff[9];
+        poff[0] = 0;
+        for (int i = 0; i < 8; ++i) poff[i + 1] = poff[i] + (psz[i] + 3) / 4 * 4;
+        at::Tensor pbuf = at::empty({poff[8]}, opts);
+        auto pg = [&](int i) { return pbuf.narrow(0, poff[i], psz[i]); };
+        const int64_t sizes[3] = {N * p.D, 2 * N * p.C_in, N * p.H1};           // g_d, gx, g_h1 (scratch)
+        int64_t off[4];
         off[0] = 0;
-        for (int i = 0; i < 11; ++i) off[i + 1] = off[i] + (sizes[i] + 3) / 4 * 4;
+        for (int i = 0; i < 3; ++i) off[i + 1] = off[i] + (sizes[i] + 3) / 4 * 4;
         const int64_t nws = (int64_t)api.head_bwd_ws((int32_t)N, &p);
-        at::Tensor buf = at::empty({off[11] + (nws + 3) / 4}, opts);
+        at::Tensor buf = at::empty({off[3] + (nws + 3) / 4}, opts);
         auto piece = [&](int i) { return buf.narrow(0, off[i], sizes[i]); };
-        p.g_w1 = fpm(piece(2)); p.g_b1 = fpm(piece(3)); p.g_w2 = fpm(piece(4)); p.g_b2 = fpm(piece(5));
-        p.g_w3 = fpm(piece(6)); p.g_b3 = fpm(piece(7)); p.g_wr = fpm(piece(8)); p.g_br = fpm(piece(9));
-        check(api.head_bwd(fp(d), fp(x), fp(h1), fp(h2), fp(g), &p, fpm(piece(0)), fpm(piece(1)), fpm(piece(10)), fpm(buf) + off[11], (size_t)nws,
+        p.g_w1 = fpm(pg(0)); p.g_b1 = fpm(pg(1)); p.g_w2 = fpm(pg(2)); p.g_b2 = fpm(pg(3));
+        p.g_w3 = fpm(pg(4)); p.g_b3 = fpm(pg(5)); p.g_wr = fpm(pg(6)); p.g_br = fpm(pg(7));
+        check(api.head_bwd(fp(d), fp(x), fp(h1), fp(h2), fp(g), &p, fpm(piece(0)), fpm(piece(1)), fpm(piece(2)), fpm(buf) + off[3], (size_t)nws,
                            (int32_t)N, stream_of(x)), "fc_echo_head_backward");
-        return {piece(0).view({N, p.D}), at::view_as_complex(piece(1).view({N, p.C_in, 2})), piece(2).view({p.H1, p.D}), piece(3),
-                piece(4).view({p.H2, p.H1}), piece(5), piece(6).view({p.C_out, p.H2}), piece(7), piece(8).view({p.C_out, p.C_in}), piece(9)};
+        return {piece(0).view({N, p.D}), at::view_as_complex(piece(1).view({N, p.C_in, 2})), pg(0).view({p.H1, p.D}), pg(1),
+                pg(2).view({p.H2, p.H1}), pg(3), pg(4).view({p.C_out, p.H2}), pg(5), pg(6).view({p.C_out, p.C_in}), pg(7)};
     }
 };
 
