@@ -23,7 +23,7 @@ SWITCHES = {
     'FC_ECHO_WPV': 'wavefronts per vertex in the ECHO descriptor kernels (1, 2 or 4)',
     'FC_STAMP_KERNEL': 'data | filter: which backward kernel writes in-kernel time stamps (tools/stamps.py)',
     'FC_DEBUG': 'forward kernels: skip phases (WRONG RESULTS; refused by bench.py)',
-    'FC_DEBUG_BWD': 'backward kernels: skip phases; bit 5: cost prototype of the H-streaming contraction in the filter kernel (WRONG RESULTS; refused by bench.py)',
+    'FC_DEBUG_BWD': 'backward kernels: skip phases; bit 5: cost prototype of the H-streaming contraction in the filter kernel, bit 6: of a gather-only data kernel (WRONG RESULTS; refused by bench.py)',
     'FC_DEBUG_RG': "ECHOBlock head's grouped GEMM: 1 no products, 2 no loads, 4 no staging (WRONG RESULTS; refused by bench.py)",
     'FC_DEBUG_RP': 'finishing launch: 1 no partial loads, 2 no parameter-gradient chain (WRONG RESULTS; refused by bench.py)',
     # ---- read by the Python package

@@ -71,7 +71,8 @@ struct BwdArgs {
     int stamp_who;                // 1: the data kernel stamps, 2: the half2 filter-gradient kernel (FC_STAMP_KERNEL=data|filter)
     int dbg;             // development only: bit0 skip gather, bit1 skip gxt MFMA, bit2 skip gW MFMA, bit3 skip the slab dump,
                          // bit4 the half2 filter kernel re-reads its first tile's rows (from L2) instead of walking the dump,
-                         // bit5 the half2 filter kernel also runs a cost prototype of the H-streaming contraction (fc_backward.hip)
+                         // bit5 the half2 filter kernel also runs a cost prototype of the H-streaming contraction (fc_backward.hip),
+                         // bit6 the data kernel as a cost prototype of a gather-only kernel (walk, convert, store; nothing else)
 };
 
 // Frequency groups of the gather: NG walks of the edges with MG frequencies (R * MG complex accumulators per lane) each.  NGX forces a
@@ -320,6 +321,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
 
             stamp(0);
             // ---------------------------------------------------------------- slabs -> gxt_f -> gx
+            // Development only (FC_DEBUG_BWD bit 6, split mode; never in the product library): a cost prototype of a GATHER-ONLY data kernel --
+            // every wavefront walks, converts and stores its own rows of H and nothing else: no LDS slab, no workgroup barrier, no
+            // contraction, no gx (what the H-streaming restructure of the backward pass would need this kernel to become)
+            const bool gather_only = kDevSwitches && SPLIT && (a.dbg & 64);
             float scale = 1.f, inv_scale = 1.f;
             if constexpr (SPLIT) {
                 // one power-of-two scale for this wavefront's vertex and frequency group (fc_tile.hpp, split mode)
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                                         }
                                     }
                                     even = kept;
-                                    split_pair_store(row, oo, hi, lo, lane, halves);
+                                    if (!gather_only) split_pair_store(row, oo, hi, lo, lane, halves);
                                     oo += halves * mg.KI;
                                     if (r & 1) d0 += 2 * O;
                                     asm volatile("" : "+v"(oo), "+v"(d0));
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_data_kernel(
                             dst[a.slab_floats + wave] = scale;
                             dst[a.slab_floats + kTile + wave] = inv_scale;
                         }
+                        if (gather_only) continue;              // (development: no slab, no barrier, no contraction, no gx -- see above)
                         stamp(1);
                         __syncthreads();
                         stamp(2);
