@@ -111,13 +111,19 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_forward_kernel(
             }
 #pragma unroll
             for (int u = 0; u < kTfAhead; ++u) {
+                // (the updated sums are formed exactly as in a per-edge loop -- same fused multiply-adds -- and dropped by a select past the end)
                 const bool on = e0 + u * wpv < end;
                 const float d = xs[u] - xd;
-                ang.x += on ? d * s1[u].x : 0.f;
-                ang.y += on ? d * s1[u].y : 0.f;
-                mag += on ? xs[u] * soft_abs(s0[u]) : 0.f;
-                s1sum.x += on ? s1[u].x : 0.f;
-                s1sum.y += on ? s1[u].y : 0.f;
+                float2 na = ang, ns = s1sum;
+                float nm = mag;
+                na.x += d * s1[u].x;
+                na.y += d * s1[u].y;
+                nm += xs[u] * soft_abs(s0[u]);
+                ns.x += s1[u].x;
+                ns.y += s1[u].y;
+                ang = on ? na : ang;
+                mag = on ? nm : mag;
+                s1sum = on ? ns : s1sum;
             }
         }
     };
@@ -354,8 +360,9 @@ __global__ __launch_bounds__(kTfWaves * kWave) void trans_field_backward_input_k
             }
 #pragma unroll
             for (int u = 0; u < kTfAhead; ++u) {
-                const float t = gm[u] * soft_abs(s0[u]) - (ga[u].x * s1[u].x + ga[u].y * s1[u].y);
-                acc += (e0 + u * wpv < end) ? t : 0.f;
+                float nacc = acc;
+                nacc += gm[u] * soft_abs(s0[u]) - (ga[u].x * s1[u].x + ga[u].y * s1[u].y);       // (as in a per-edge loop; dropped past the end)
+                acc = (e0 + u * wpv < end) ? nacc : acc;
             }
         }
     };

@@ -1268,7 +1268,8 @@ def test_lift_block_reads_the_factor_table(dev, N, k, B, R):
         out.append((y.detach(),) + torch.autograd.grad(y, [x] + params, grad_outputs=gy))
     assert lift_sten._dense is None and sten._dense is None             # nothing was materialised on the way
     for n_, (a, b) in enumerate(zip(*out)):          # (float32 rounding of the on-the-fly columns against torch's; gradients through angle())
-        assert rel_err(H(a), H(b)) < (5e-6 if n_ == 0 else 2e-5), n_
+        err = rel_err(H(a), H(b))
+        assert err < (5e-6 if n_ == 0 else 2e-5), (n_, err)
     # and the stand-in still behaves like the tensor when something else asks
     assert torch.equal(lift_sten[:5], sten.columns(0, 2)[:5]) and lift_sten.abs().shape == (edges.shape[0], R, 2)
 
