@@ -1423,7 +1423,8 @@ def test_fc_resnet_block_in_double_precision(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,D,C,Q,H1,H2', [(1024, 1392, 48, 8, 128, 64), (4999, 156, 16, 64, 128, 64), (37, 29, 5, 3, 128, 64),
-                                           (333, 260, 64, 64, 128, 64), (16, 4, 1, 1, 32, 16), (2050, 75, 7, 10, 96, 48)])
+                                           (333, 260, 64, 64, 128, 64), (16, 4, 1, 1, 32, 16), (2050, 75, 7, 10, 96, 48), (1, 3, 2, 2, 50, 30),
+                                           (129, 513, 33, 17, 127, 63)])
 def test_echo_head_matches_the_dense_layers_in_double_precision(dev, N, D, C, Q, H1, H2):
     """ECHOBlock's tail lin3(relu(lin2(relu(lin1(d))))) + res(softAbs(x)) (reference nn/echo_block.py:95-103) through fc_echo_head_forward /
     fc_echo_head_backward -- fp32 matrix-pipe products, k-split weight gradients, fused masks and bias sums -- against the same layers
