@@ -236,11 +236,47 @@ def fuzz_resnet_block():
     return last
 
 
+def fuzz_echo_head():
+    """ECHOBlock's dense tail (fc_echo_head_*: grouped fp32-MFMA GEMM with k-split weight gradients, fused 16-row kernels) against the
+    same layers in float64 torch: output and all ten gradients."""
+    from fieldconv_amd.blocks import _EchoHeadFn, head_supported
+    N, D = int(rng.integers(1, 6000)), int(rng.integers(1, 1500))
+    C, Q = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+    H1, H2 = int(rng.choice([128, 128, 96, 64, 50, 17])), int(rng.choice([64, 64, 48, 30, 16, 5]))
+    global last
+    last = f'N={N} D={D} C={C} Q={Q} H1={H1} H2={H2}'
+    d = torch.from_numpy(rng.random((N, D)).astype(np.float32)).to(dev)
+    x = cplx(N, C)
+    x[torch.from_numpy(rng.random((N, C)) < 0.03)] = 0
+    x = x.to(dev)
+
+    def lin(o, i):
+        return (torch.from_numpy(((rng.random((o, i)) * 2 - 1) / i ** 0.5).astype(np.float32)).to(dev),
+                torch.from_numpy(((rng.random(o) * 2 - 1) / i ** 0.5).astype(np.float32)).to(dev))
+    params = [t for pair in (lin(H1, D), lin(H2, H1), lin(Q, H2), lin(Q, C)) for t in pair]
+    assert head_supported(d, x, params[0], params[2], params[4], params[6])
+    gy = torch.from_numpy(rng.standard_normal((N, Q)).astype(np.float32)).to(dev)
+    leaves = [d.clone().requires_grad_(True), x.clone().requires_grad_(True)] + [p_.clone().requires_grad_(True) for p_ in params]
+    y = _EchoHeadFn.apply(*leaves)
+    grads = torch.autograd.grad(y, leaves, gy)
+    ref = [t.detach().to(torch.complex128 if t.is_complex() else torch.float64).requires_grad_(True) for t in leaves]
+    d64, x64, w1, b1, w2, b2, w3, b3, wr, br = ref
+    org = (x64.detach().real.abs() < 1e-7) & (x64.detach().imag.abs() < 1e-7)
+    a = torch.where(org, torch.zeros_like(x64.real), x64.abs())
+    y_ref = torch.relu(torch.relu(d64 @ w1.t() + b1) @ w2.t() + b2) @ w3.t() + b3 + a @ wr.t() + br
+    ref_grads = torch.autograd.grad(y_ref, ref, gy.double())
+    errs = [rel(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy())] + \
+           [rel(g_.cpu().numpy(), r_.cpu().numpy()) for g_, r_ in zip(grads, ref_grads)]
+    assert max(errs) < 1e-5, ('head', errs)
+    return last
+
+
 failures = 0
 last = ''
 only = os.environ.get('FUZZ_ONLY')
 for name, fn in (('echo', fuzz_echo), ('trans_field', fuzz_trans_field), ('precomp+graph', fuzz_precomp_and_graph),
-                 ('small-mesh conv', fuzz_small_mesh_conv), ('pointwise', fuzz_pointwise), ('resnet_block', fuzz_resnet_block)):
+                 ('small-mesh conv', fuzz_small_mesh_conv), ('pointwise', fuzz_pointwise), ('echo_head', fuzz_echo_head),
+                 ('resnet_block', fuzz_resnet_block)):
     if only and only != name:
         continue
     ok = 0
