@@ -24,6 +24,7 @@ SWITCHES = {
     'FC_STAMP_KERNEL': 'data | filter: which backward kernel writes in-kernel time stamps (tools/stamps.py)',
     'FC_DEBUG': 'forward kernels: skip phases (WRONG RESULTS; refused by bench.py)',
     'FC_DEBUG_BWD': 'backward kernels: skip phases; bit 5: cost prototype of the H-streaming contraction in the filter kernel, bit 6: of a gather-only data kernel (WRONG RESULTS; refused by bench.py)',
+    'FC_LIN_DIRECT': '0: TangentLin on small meshes through the LDS-staged kernel instead of the direct one',
     'FC_DEBUG_RG': "ECHOBlock head's grouped GEMM: 1 no products, 2 no loads, 4 no staging (WRONG RESULTS; refused by bench.py)",
     'FC_DEBUG_RP': 'finishing launch: 1 no partial loads, 2 no parameter-gradient chain (WRONG RESULTS; refused by bench.py)',
     # ---- read by the Python package
@@ -60,7 +61,7 @@ TEST_SWITCHES = {
 
 # the switches that exist in the development build of the library only (csrc: dev_env under -DFC_DEV_SWITCHES)
 LIBRARY_SWITCHES = ('FC_RING', 'FC_GROUP_SPLIT', 'FC_RING_COMPACT', 'FC_RING_HALVES', 'FC_HALF_TILES', 'FC_FILTER2', 'FC_SPLIT_FINISH',
-                    'FC_EDGE_PARTS_MAX', 'FC_ECHO_WPV', 'FC_STAMP_KERNEL', 'FC_DEBUG', 'FC_DEBUG_BWD', 'FC_DEBUG_RP', 'FC_DEBUG_RG')
+                    'FC_EDGE_PARTS_MAX', 'FC_ECHO_WPV', 'FC_STAMP_KERNEL', 'FC_DEBUG', 'FC_DEBUG_BWD', 'FC_DEBUG_RP', 'FC_DEBUG_RG', 'FC_LIN_DIRECT')
 
 PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')
 WRONG_RESULTS = ('FC_DEBUG', 'FC_DEBUG_BWD', 'FC_DEBUG_RP', 'FC_DEBUG_RG')

@@ -173,12 +173,14 @@ __global__ __launch_bounds__(kLinThreads) void tangent_lin_kernel(const float2* 
     }
 }
 
-// The same product for meshes whose 16-vertex blocks cannot occupy the chip (the split walk above: one block per workgroup, its output
-// tiles dealt to the wavefronts) WITHOUT the filter's way through LDS: a wavefront needs only its own 16 output channels of the filter --
-// requested, with the block's input rows, as one batch of loads straight into the matrix pipe's operand layout (lane l: output channel
-// l & 15, input channels 8 kb + 2 (l >> 4) and the next) -- so the kernel has no LDS, no barrier and one round trip to L2 before its
-// instruction chain, where the staged walk zeroes 67 KB, stages the filter and synchronises twice (10.6 -> us at 4 999 vertices and 64
-// channels).  The products and their order are the staged walk's: bit-identical.  K % 8 == 0, K <= 64, 16-byte aligned rows.
+// The same product WITHOUT the filter's way through LDS (the default whenever its shape conditions hold: it is faster than the staged walk
+// above at every mesh size measured, tools/time_tangent_lin.py: 4.8 against 7.2 us at 1 024 vertices and 48 channels, 12.3 / 18.6 at
+// 20 000, 72 / 96 at 200 000 x 64): one 16-vertex block per workgroup at a time, its output tiles dealt to the wavefronts; a wavefront
+// needs only its own 16 output channels of the filter -- requested once, with each block's input rows, as a batch of loads straight into
+// the matrix pipe's operand layout (lane l: output channel l & 15, input channels 8 kb + 2 (l >> 4) and the next) -- so the kernel has no
+// LDS, no barrier and one round trip to L2 before its instruction chain, where the staged walk zeroes 67 KB, stages the filter and
+// synchronises twice.  The products and their order are the staged walk's: bit-identical.  K % 8 == 0, K <= 64, more than one output
+// tile, 16-byte aligned rows; otherwise the staged walk.
 constexpr int kLinDirectKB = 8;          // k blocks of 16 real entries: up to 64 complex input channels
 
 template <bool TRANSPOSED>
@@ -440,8 +442,10 @@ static int lin_grid(int N) {
 // one 16-vertex block per workgroup at a time, its output tiles dealt to the four wavefronts (tangent_lin_kernel: split), when there is
 // more than one tile and the blocks alone cannot give every SIMD of the chip work
 static bool lin_split(int N, int M) { return M > 16 && (N + 15) / 16 <= 8 * num_cus(); }
-// the split walk without LDS (tangent_lin_direct_kernel): K input channels, rows and filter 16-byte / 8-byte aligned
+// the walk without LDS (tangent_lin_direct_kernel): K input channels, rows and filter 16-byte / 8-byte aligned
 static bool lin_direct(const void* in, const float* wre, const float* wim, int K, int ldw, bool transposed) {
+    static const bool off = [] { const char* e = dev_env("FC_LIN_DIRECT"); return e && atoi(e) == 0; }();       // development: the staged walk
+    if (off) return false;
     if (K % 8 != 0 || K > 8 * kLinDirectKB || (reinterpret_cast<uintptr_t>(in) & 15)) return false;
     return transposed || ((ldw & 1) == 0 && (reinterpret_cast<uintptr_t>(wre) & 7) == 0 && (reinterpret_cast<uintptr_t>(wim) & 7) == 0);
 }
@@ -461,7 +465,7 @@ int tangent_lin_backward_impl(const float* x, const float* gy, const float* re_w
     const size_t lds = 2 * (size_t)lin_plane_floats(I, O) * sizeof(float);
     if (lds > kMaxLds) return FC_ERR_UNSUPPORTED;
     const bool split = lin_split(N, I);
-    if (split && lin_direct(gy, re_w, im_w, O, I, true))
+    if (I > 16 && lin_direct(gy, re_w, im_w, O, I, true))
         hipLaunchKernelGGL(tangent_lin_direct_kernel<true>, dim3(lin_grid_split(N)), dim3(kLinThreads), 0, s, reinterpret_cast<const float2*>(gy),
                            re_w, im_w, reinterpret_cast<float2*>(gx), reinterpret_cast<const float2*>(gx_addend), N, O, I, I);
     else
@@ -488,7 +492,7 @@ int fc_tangent_lin_forward(const float* x, const float* re_w, const float* im_w,
     const size_t lds = 2 * (size_t)fc::lin_plane_floats(O, I) * sizeof(float);
     if (lds > fc::kMaxLds) return FC_ERR_UNSUPPORTED;
     const bool split = fc::lin_split(N, O);
-    if (split && fc::lin_direct(x, re_w, im_w, I, I, false))
+    if (O > 16 && fc::lin_direct(x, re_w, im_w, I, I, false))
         hipLaunchKernelGGL(fc::tangent_lin_direct_kernel<false>, dim3(fc::lin_grid_split(N)), dim3(fc::kLinThreads), 0,
                            static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(x), re_w, im_w, reinterpret_cast<float2*>(y),
                            (const float2*)nullptr, N, I, O, I);

@@ -4,7 +4,7 @@ from fieldconv_amd import _lib
 from fieldconv_amd.functional import _p, _stream
 lib = _lib.load()
 dev = torch.device('cuda:0')
-for N, C in ((20000, 48), (4999, 64), (1024, 48), (40000, 64)):
+for N, C in ((1024, 48), (4999, 64), (20000, 48), (32000, 64), (40000, 64), (100000, 48), (200000, 64), (500000, 32)):
     x = torch.randn(N, C, dtype=torch.cfloat, device=dev)
     re, im = torch.randn(C, C, device=dev), torch.randn(C, C, device=dev)
     y = torch.empty_like(x)
