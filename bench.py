@@ -371,13 +371,17 @@ def host_and_replay_extras(out, step):
         out['eager_over_replay'] = out['ms_per_step'] / out['graph_replay']['ms_per_step']
     except Exception as exc:                      # noqa: BLE001
         out['graph_replay'] = {'error': repr(exc)[:200]}
+    prev_calls = os.environ.get('FIELDCONV_BLOCK_CALLS')
     os.environ['FIELDCONV_BLOCK_CALLS'] = '0'
     try:
         out['host_enqueue_ms_per_step']['per_operator_calls'] = _host_enqueue_ms(step)
         out['per_operator_calls'] = {'ms_per_step': _timeit_ms(step), 'note': 'the same step with every block composed of per-operator autograd '
                                                                             'nodes and foreign calls (FIELDCONV_BLOCK_CALLS=0)'}
-    finally:
-        del os.environ['FIELDCONV_BLOCK_CALLS']
+    finally:           # (back to what the timed region ran with: config.env must describe the measured value)
+        if prev_calls is None:
+            del os.environ['FIELDCONV_BLOCK_CALLS']
+        else:
+            os.environ['FIELDCONV_BLOCK_CALLS'] = prev_calls
 
 
 # ------------------------------------------------------------------------------------------------ mode dp (config 5)

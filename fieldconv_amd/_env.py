@@ -17,17 +17,19 @@ SWITCHES = {
     'FC_RING_COMPACT': '0: no compact LDS plans (aliased partials, half-size record chunks) for the ring-major forward kernel',
     'FC_RING_HALVES': '0: no half tiles in the last round of the ring-major forward kernel',
     'FC_HALF_TILES': '0: no half tiles in the frequency-major kernels; 2: half tiles in the backward kernels too',
+    'FC_BWD_STREAM': '0: the data / filter kernel pair on large meshes too, instead of the H-streaming arrangement (gather + stream + gx kernels)',
     'FC_FILTER2': '0: the LDS-staged half-precision filter-gradient kernel instead of the register-fed one',
     'FC_SPLIT_FINISH': '1: partial sums and parameter-gradient chain as two launches',
     'FC_EDGE_PARTS_MAX': 'cap (log2) on the number of workgroups that share a tile on small meshes',
     'FC_ECHO_WPV': 'wavefronts per vertex in the ECHO descriptor kernels (1, 2 or 4)',
-    'FC_STAMP_KERNEL': 'data | filter: which backward kernel writes in-kernel time stamps (tools/stamps.py)',
+    'FC_STAMP_KERNEL': 'data | filter | stream: which backward kernel writes in-kernel time stamps (tools/stamps.py)',
     'FC_DEBUG': 'forward kernels: skip phases (WRONG RESULTS; refused by bench.py)',
-    'FC_DEBUG_BWD': 'backward kernels: skip phases; bit 5: cost prototype of the H-streaming contraction in the filter kernel, bit 6: of a gather-only data kernel (WRONG RESULTS; refused by bench.py)',
+    'FC_DEBUG_BWD': 'backward kernels: skip phases (bit 0 walk, bit 1 gxt product, bit 2 gW product, bit 3 H stores) (WRONG RESULTS; refused by bench.py)',
     'FC_LIN_DIRECT': '0: TangentLin on small meshes through the LDS-staged kernel instead of the direct one',
     'FC_DEBUG_RG': "ECHOBlock head's grouped GEMM: 1 no products, 2 no loads, 4 no staging (WRONG RESULTS; refused by bench.py)",
     'FC_DEBUG_RP': 'finishing launch: 1 no partial loads, 2 no parameter-gradient chain (WRONG RESULTS; refused by bench.py)',
     # ---- read by the Python package
+    'FIELDCONV_DEV': '1: load libfieldconv_hip_dev.so (the library switches above exist there only; one of them set without this raises)',
     'FIELDCONV_HIP_LIB': 'path of a prebuilt libfieldconv_hip.so (development variants, fieldconv_amd.build.build_variant)',
     'FIELDCONV_DENSE': '1: FCPrecomp stencils through the dense-stencil kernels',
     'FIELDCONV_NO_GEO': '1: 64-byte factored records in the forward pass instead of geometric ones',
@@ -60,7 +62,7 @@ TEST_SWITCHES = {
 }
 
 # the switches that exist in the development build of the library only (csrc: dev_env under -DFC_DEV_SWITCHES)
-LIBRARY_SWITCHES = ('FC_RING', 'FC_GROUP_SPLIT', 'FC_RING_COMPACT', 'FC_RING_HALVES', 'FC_HALF_TILES', 'FC_FILTER2', 'FC_SPLIT_FINISH',
+LIBRARY_SWITCHES = ('FC_BWD_STREAM', 'FC_RING', 'FC_GROUP_SPLIT', 'FC_RING_COMPACT', 'FC_RING_HALVES', 'FC_HALF_TILES', 'FC_FILTER2', 'FC_SPLIT_FINISH',
                     'FC_EDGE_PARTS_MAX', 'FC_ECHO_WPV', 'FC_STAMP_KERNEL', 'FC_DEBUG', 'FC_DEBUG_BWD', 'FC_DEBUG_RP', 'FC_DEBUG_RG', 'FC_LIN_DIRECT')
 
 PREFIXES = ('FC_', 'FIELDCONV_', 'BENCH_')

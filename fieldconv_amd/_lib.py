@@ -107,6 +107,9 @@ SIGNATURES = {
     'fc_backward_data': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
+    'fc_backward_streams': (_c_int32, [_DP, _c_int32]),
+    'fc_backward_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _sz, _DP, _vp]),
+    'fc_backward_stream': (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_finish_params': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _FP, _vp]),
     'fc_backward_all': (ctypes.c_int, [_vp, _vp, _vp, _CP, _c_int32, _vp, _vp, _vp, _FP, _vp, _sz, _DP, _vp]),
@@ -172,18 +175,25 @@ MFMA_MODES = {'': 0, 'split': 0, 'f32': 1, 'f16': 2}       # FC_MFMA -> fc_mfma_
 
 
 def _pick_library():
-    """FIELDCONV_HIP_LIB if given; the development build (-DFC_DEV_SWITCHES) when one of the library's development switches is set
-    in the environment -- the product library does not read any of them -- else the product library."""
+    """FIELDCONV_HIP_LIB if given; else the product library -- which reads no environment variable.  The development build
+    (-DFC_DEV_SWITCHES) is loaded only on request: FIELDCONV_DEV=1.  One of the library's development switches set (to a non-empty
+    value) WITHOUT that request raises: a stray FC_* variable must neither be silently ignored (an A/B run that measures the default
+    twice) nor silently swap the binary a consumer of the package runs."""
     explicit = os.environ.get('FIELDCONV_HIP_LIB')
     if explicit:
         return explicit
     from ._env import LIBRARY_SWITCHES
-    wanted = sorted(k for k in LIBRARY_SWITCHES if k in os.environ)
-    if wanted:
+    wanted = sorted(k for k in LIBRARY_SWITCHES if os.environ.get(k, '') != '')
+    dev = os.environ.get('FIELDCONV_DEV', '') == '1'
+    if wanted and not dev:
+        raise FieldConvNativeError(
+            f'{", ".join(wanted)} set, but the product library has no environment switches: set FIELDCONV_DEV=1 to load the development '
+            f'build ({DEV_LIB_PATH}), or unset the variable(s)')
+    if dev:
         if not os.path.exists(DEV_LIB_PATH):
             raise FieldConvNativeError(
-                f'{", ".join(wanted)} set, but the development library {DEV_LIB_PATH} is not built: the product library has no '
-                'environment switches; build it with `python -m fieldconv_amd.build --dev` (fieldconv_amd.build.build_dev())')
+                f'FIELDCONV_DEV=1, but the development library {DEV_LIB_PATH} is not built: '
+                'build it with `python -m fieldconv_amd.build --dev` (fieldconv_amd.build.build_dev())')
         return DEV_LIB_PATH
     return LIB_PATH
 

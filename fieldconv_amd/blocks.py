@@ -36,6 +36,7 @@ def cpp_nodes():
         if isinstance(lib, ctypes.CDLL):
             from .build import TORCH_NODES_PATH, torch_nodes_needs_build
             if os.path.exists(TORCH_NODES_PATH) and not torch_nodes_needs_build():
+              try:
                 import importlib.util
                 spec = importlib.util.spec_from_file_location('fc_torch_nodes', TORCH_NODES_PATH)
                 mod = importlib.util.module_from_spec(spec)
@@ -46,6 +47,10 @@ def cpp_nodes():
                          'fc_echo_head_forward_workspace_bytes', 'fc_echo_head_backward_workspace_bytes', 'fc_status_string')
                 mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in names})
                 _NODES = mod
+              except Exception as exc:          # noqa: BLE001  (an ABI or symbol mismatch with the installed torch: say so once, use the Python nodes)
+                import warnings
+                warnings.warn(f'fieldconv_amd: fc_torch_nodes.so could not be loaded / bound ({type(exc).__name__}: {exc}); '
+                              'using the Python autograd nodes (more host time per block)')
             else:
                 import warnings
                 warnings.warn('fieldconv_amd: fc_torch_nodes.so is not built for these sources (python -m fieldconv_amd.build --nodes); '
@@ -78,8 +83,9 @@ def _resnet_sizes(lib, graph, mesh, C_in, C_mid, C_out, B):
     if sizes is None:
         bp = FcResnetBlockParams(C_in, C_mid, C_out)
         bref = ctypes.byref(bp)
-        sizes = graph._plans[key] = (lib.fc_resnet_block_saved_bytes(mesh.ref, bref), lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 0),
-                                     lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 1))
+        with Fn._on(graph.rowptr_t.device):      # (the plans follow the CU count of the device the launches will run on, not of the current one)
+            sizes = graph._plans[key] = (lib.fc_resnet_block_saved_bytes(mesh.ref, bref), lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 0),
+                                         lib.fc_resnet_block_workspace_bytes(mesh.ref, bref, 1))
     return sizes
 
 
@@ -272,8 +278,9 @@ class _EchoBlockFn(torch.autograd.Function):
         sizes = graph._plans.get(key)
         if sizes is None:
             bref = ctypes.byref(bp)
-            sizes = graph._plans[key] = (lib.fc_echo_block_saved_bytes(mesh.ref, bref), lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 0),
-                                         lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 1), lib.fc_echo_hist_dim(n_bins))
+            with Fn._on(x.device):
+                sizes = graph._plans[key] = (lib.fc_echo_block_saved_bytes(mesh.ref, bref), lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 0),
+                                             lib.fc_echo_block_workspace_bytes(mesh.ref, bref, 1), lib.fc_echo_hist_dim(n_bins))
         dev = x.device
         with Fn._on(dev):
             desc = torch.empty((graph.N, n_des, sizes[3]), dtype=torch.float32, device=dev)

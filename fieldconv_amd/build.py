@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OUT_DIR = os.path.join(PKG, '_native')
 LIB_PATH = os.path.join(OUT_DIR, 'libfieldconv_hip.so')
 SOURCES = ['fc_api.hip', 'fc_pack.hip', 'fc_forward.hip', 'fc_forward_split.hip', 'fc_forward_ring.hip', 'fc_backward.hip', 'fc_backward_split.hip', 'fc_generic.hip', 'fc_cgemm.hip', 'fc_wide.hip', 'fc_blocks.hip', 'fc_pointwise.hip', 'fc_pointwise_f64.hip', 'fc_echo.hip', 'fc_trans_field.hip', 'fc_lift_echo_generic.hip', 'fc_head.hip', 'fc_graph.hip', 'fc_precomp.hip', 'fc_optim.hip']
-HEADERS = ['fc_common.hpp', 'fc_kernels.hpp', 'fc_tile.hpp', 'fc_forward_kernels.hpp', 'fc_forward_ring.hpp', 'fc_backward_kernels.hpp', os.path.join('..', '..', 'include', 'fieldconv_hip.h')]
+HEADERS = ['fc_common.hpp', 'fc_kernels.hpp', 'fc_tile.hpp', 'fc_forward_kernels.hpp', 'fc_forward_ring.hpp', 'fc_backward_kernels.hpp', 'fc_backward_stream.hpp', os.path.join('..', '..', 'include', 'fieldconv_hip.h')]
 # -fno-slp-vectorize: keep the stencil FMAs as v_fma_f32 with a direct SGPR operand; packed
 # v_pk_fma_f32 needs SGPR pairs built with s_mov and saturates the CU's single scalar ALU.
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fno-slp-vectorize',

@@ -189,15 +189,34 @@ int fc_backward_data_factored(const float* x, const float* gy, const float* rec_
 int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!x || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    (void)records;
-    return fc::backward_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+    return fc::backward_filter_impl(x, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream), records != 0);
+}
+
+int32_t fc_backward_streams(const fc_dims* dims, int32_t records) {
+    return (fc::dims_supported(dims) && dims->R <= 8 && fc::rows_fit_32bit(dims) && fc::backward_streams(dims, records != 0)) ? 1 : 0;
+}
+
+int fc_backward_gather(const float* gy, const float* rec_s, const fc_csr* by_source, void* workspace, size_t workspace_bytes,
+                       const fc_dims* dims, void* stream) {
+    if (!gy || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (dims->E > 0 && (!rec_s || !by_source->runs)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc_backward_streams(dims, 1)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_stream_impl(nullptr, gy, rec_s, by_source, nullptr, nullptr, workspace, workspace_bytes, dims,
+                                    static_cast<hipStream_t>(stream), 1);
+}
+
+int fc_backward_stream(const float* x, const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes, const fc_dims* dims,
+                       void* stream) {
+    if (!x || !wpk_bwd || !gx || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+    if (!fc_backward_streams(dims, 1)) return FC_ERR_UNSUPPORTED;
+    return fc::backward_stream_impl(x, nullptr, nullptr, nullptr, wpk_bwd, gx, workspace, workspace_bytes, dims,
+                                    static_cast<hipStream_t>(stream), 2);
 }
 
 int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream) {
     if (!gw_eff || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (!fc::dims_supported(dims)) return FC_ERR_UNSUPPORTED;
-    (void)records;
-    return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream));
+    return fc::backward_finish_impl(gw_eff, workspace, workspace_bytes, dims, static_cast<hipStream_t>(stream), records != 0);
 }
 
 static int check_finish_params(const fc_filter_params* params, const fc_dims* dims) {
@@ -227,7 +246,8 @@ int fc_backward_finish_params(float* gw_eff, void* workspace, size_t workspace_b
         if (rc != FC_OK || !params->bias_partials) return rc;
         return fc::bias_partials_reduce_impl(params->bias_partials, params->bias_nparts, dims->O, params->g_bias, static_cast<hipStream_t>(stream));
     }
-    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream));
+    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, nullptr,
+                                           records != 0);
 }
 
 int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s, const fc_csr* by_source, int32_t records,
@@ -255,7 +275,8 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     if (rc != FC_OK) return rc;
     if (!params) return fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
     if (!defer) return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
-    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, gx);
+    return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, gx,
+                                           records != 0);
 }
 
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,

@@ -2,6 +2,7 @@
 // kernel and the mode dispatch (data kernel: fc_backward_kernels.hpp).
 #include <stdio.h>
 #include "fc_backward_kernels.hpp"
+#include "fc_backward_stream.hpp"
 
 namespace fc {
 
@@ -139,12 +140,6 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_kernel(
 // Two variants: fc_backward_filter_half_kernel stages the fp32 slabs in LDS (LDS-DMA, double-buffered; one image, two
 // barriers per slab; FC_FILTER2=0), fc_backward_filter_half2_kernel (default, below it) converts straight from registers
 // loaded one slab ahead into one of two images, with one barrier per slab.
-typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
-
 __device__ __forceinline__ f32x4 mfma16h(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
 }
@@ -575,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_filter_half2_kernel(
 
 // gw_eff[o][i][r][f] = 1/F sum_p gwp[p][f][r*O+o][i]
 __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __restrict__ gw, int P, int F, int R,
-                                    int O, int I, int KP, int IP, int pairs /* k = dump_k(r, o) */) {
+                                    int O, int I, int KP, int IP, int pairs /* 1: k = dump_k(r, o); 2: k = o*R + r */) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over (f, k<R*O, i<I), i fastest
     const int total = F * R * O * I;
     if (idx >= total) return;
@@ -601,7 +596,10 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
     }
     const float sc = 1.f / (float)F;
     int r = k / O, o = k - r * O;
-    if (pairs && k < (R >> 1) * 2 * O) {
+    if (pairs == 2) {           // o-major (the streaming arrangement)
+        o = k / R;
+        r = k - o * R;
+    } else if (pairs && k < (R >> 1) * 2 * O) {
         const int pr = k / (2 * O), rem = k - pr * 2 * O;
         r = 2 * pr + (rem & 1);
         o = rem >> 1;
@@ -609,11 +607,72 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
     gw[(((size_t)o * I + i) * R + r) * F + f] = make_float2(s.x * sc, s.y * sc);
 }
 
+// ------------------------------------------------------------------------------------ H-streaming arrangement (fc_backward_stream.hpp)
+template <int R, int B>
+static int launch_gather(const float2* gy, const float* rec, const fc_csr* g, char* hrec, const StreamArgs& a, const StreamPlan& p,
+                         hipStream_t stream) {
+    auto kern = fc_backward_gather_kernel<R, B>;
+    const size_t lds = (size_t)kWaves * kRingChunks * 1024;
+    const int grid = p.ntiles < num_cus() ? p.ntiles : num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, gy, rec, g->rowptr, g->runs, hrec, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+template <int T>
+static int launch_stream(const float2* x, const char* hrec, const float* wpk, float2* gwp, float2* gxt, const StreamArgs& a,
+                         const StreamPlan& p, hipStream_t stream) {
+    auto kern = fc_backward_stream_kernel<T>;
+    static bool lds_ok[kMaxDevices] = {};
+    if (!allow_full_lds(reinterpret_cast<const void*>(kern), p.lds, lds_ok)) return FC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds, stream, x, hrec, wpk, gwp, gxt, a);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+// stage bits: 1 the gather kernel, 2 the streaming kernel + gx (fc_backward_gather / fc_backward_stream time them apart)
+int backward_stream_impl(const float* x, const float* gy, const float* rec, const fc_csr* g, const float* wpk, float* gx, void* ws,
+                         size_t ws_bytes, const fc_dims* d, hipStream_t stream, int stages) {
+    const StreamPlan p = plan_stream(d, split_mode(), true);
+    if (!p.ok) return FC_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < p.hrec_bytes + p.gwp_bytes + p.gxt_bytes) return FC_ERR_WORKSPACE;
+    const StreamArgs a = make_stream_args(d, p);
+    char* hrec = static_cast<char*>(ws);
+    float2* gwp = reinterpret_cast<float2*>(hrec + p.hrec_bytes);
+    float2* gxt = reinterpret_cast<float2*>(hrec + p.hrec_bytes + p.gwp_bytes);
+    const float2* x2 = reinterpret_cast<const float2*>(x);
+    int rc = FC_ERR_UNSUPPORTED;
+    if (stages & 1) {
+        const float2* gy2 = reinterpret_cast<const float2*>(gy);
+#define FC_GATHER_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_gather<RR, BB>(gy2, rec, g, hrec, a, p, stream);
+        FC_GATHER_CASE(2, 1) FC_GATHER_CASE(4, 1) FC_GATHER_CASE(6, 1) FC_GATHER_CASE(8, 1)
+        FC_GATHER_CASE(2, 2) FC_GATHER_CASE(4, 2) FC_GATHER_CASE(6, 2)
+        FC_GATHER_CASE(2, 3) FC_GATHER_CASE(4, 3)
+#undef FC_GATHER_CASE
+        if (rc != FC_OK) return rc;
+    }
+    if (!(stages & 2)) return FC_OK;
+    if (p.T <= 2) rc = launch_stream<2>(x2, hrec, wpk, gwp, gxt, a, p, stream);
+    else if (p.T <= 4) rc = launch_stream<4>(x2, hrec, wpk, gwp, gxt, a, p, stream);
+    else rc = launch_stream<6>(x2, hrec, wpk, gwp, gxt, a, p, stream);
+    if (rc != FC_OK) return rc;
+    const size_t count = (size_t)d->N * d->I;
+    const dim3 grid((unsigned)((count + 255) / 256));
+    float2* gx2 = reinterpret_cast<float2*>(gx);
+    if (d->B == 1) hipLaunchKernelGGL(fc_backward_gx_kernel<1>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
+    else if (d->B == 2) hipLaunchKernelGGL(fc_backward_gx_kernel<2>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
+    else hipLaunchKernelGGL(fc_backward_gx_kernel<3>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
+    return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+}
+
+bool backward_streams(const fc_dims* d, bool factored) { return plan_stream(d, split_mode(), factored).ok; }
+
 bool backward_fits(const fc_dims* d) { return plan_backward(d, split_mode()).ok_factored; }
 
 size_t backward_workspace_bytes(const fc_dims* d) {
     const BwdPlan p = plan_backward(d, split_mode());
-    return p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;
+    const size_t pair = p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;
+    const StreamPlan sp = plan_stream(d, split_mode(), true);          // (records or not is the launch's choice: room for either)
+    const size_t stream = sp.ok ? sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes + 256 : 0;
+    return pair > stream ? pair : stream;
 }
 
 template <int T>
@@ -645,7 +704,8 @@ static int launch_backward_filter(const float2* x, const float* hdump, float2* g
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
+int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored) {
+    if (backward_streams(d, factored)) return FC_OK;        // (the streaming kernel behind the gather has left the partials already)
     const BwdPlan p = plan_backward(d, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
@@ -667,6 +727,16 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
 
 // Which kernels a backward pass with these dims launches (fc_describe_kernels).
 void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
+    {
+        const StreamPlan sp = plan_stream(d, split_mode(), records != 0);
+        if (sp.ok) {
+            snprintf(buf, n, "fc_backward_gather_kernel<records,split-f16> tiles=%d; fc_backward_stream_kernel (H once for gxt and gW: %d gxt + %d gW "
+                     "wavefronts, W_f in registers, records by LDS-DMA) grid=%dx%d; fc_backward_gx_kernel; module parameters: "
+                     "fc_backward_finish_params (sum of the partials + parameter chain) in one launch; explicit filter: fc_backward_finish; cus=%d",
+                     sp.ntiles, sp.G, sp.NW, sp.P, sp.F, num_cus());
+            return;
+        }
+    }
     const BwdPlan p = plan_backward(d, split_mode());
     const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
     static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
@@ -689,7 +759,18 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
 }
 
 // Fixed-order sum of the per-workgroup filter-gradient partials left in the workspace.
-int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream) {
+int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored) {
+    {
+        const StreamPlan sp = plan_stream(d, split_mode(), factored);
+        if (sp.ok) {        // partials [P][F][k = o*R + r][IP]
+            if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes) return FC_ERR_WORKSPACE;
+            const float2* gwp = reinterpret_cast<const float2*>(static_cast<char*>(ws) + sp.hrec_bytes);
+            const int total = sp.F * d->R * d->O * d->I;
+            hipLaunchKernelGGL(fc_reduce_gw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, gwp, reinterpret_cast<float2*>(gw_eff),
+                               sp.P, sp.F, d->R, d->O, d->I, sp.KP, sp.IP, 2);
+            return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
+        }
+    }
     const BwdPlan p = plan_backward(d, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
@@ -701,7 +782,17 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
 }
 
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
-                                int o0, int i0, int Ifull, float* gx_deferred) {
+                                int o0, int i0, int Ifull, float* gx_deferred, bool factored) {
+    {
+        const StreamPlan sp = plan_stream(d, split_mode(), factored);
+        if (sp.ok) {        // partial (p, f, k = o*R + r, i) at ((p*F + f)*KP + k)*IP + i; gx is complete (no partial arrays)
+            if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes) return FC_ERR_WORKSPACE;
+            const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + sp.hrec_bytes);
+            return reduce_param_grads_impl(gwp, (size_t)sp.F * sp.KP * sp.IP, (size_t)sp.IP, (size_t)sp.KP * sp.IP, (size_t)d->R * sp.IP, false, sp.P,
+                                           gw_eff, fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d,
+                                           stream, o0, i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias);
+        }
+    }
     const BwdPlan p = plan_backward(d, split_mode());
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
@@ -722,6 +813,9 @@ extern template int backward_data_impl_mode<true>(FC_BWD_DATA_ARGS);
 
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum) {
+    // large meshes: gather kernel + the kernel that streams H once for gxt and gW + gx -- after this call gx is complete AND the
+    // filter-gradient partials are in the workspace (backward_filter_impl has nothing left to do)
+    if (backward_streams(d, factored)) return backward_stream_impl(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, stream, 3);
     return split_mode() ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum)
                         : backward_data_impl_mode<false>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum);
 }

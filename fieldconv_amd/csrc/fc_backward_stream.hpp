@@ -1,0 +1,747 @@
+// FieldConv backward, the H-STREAMING arrangement for large meshes (split-half mode, record-driven; the maths of
+// fc_backward_kernels.hpp -- reference: torch autograd through nn/field_conv.py:21,130,134).
+//
+//   fc_backward_gather_kernel   every wavefront walks the out-edges of ONE source vertex (lane = output channel), converts its
+//                               30 ring x frequency sums H[j,o,r,f] to split halves and stores them; no LDS slab, no workgroup
+//                               barrier, no contraction.  The entries of a vertex lie O-MAJOR, k = o*R + r, so that a lane's R
+//                               rings are R consecutive halves of a plane row: one 2R-byte store per plane and frequency.  A
+//                               (tile, frequency) record in HBM IS the image the next kernel wants in LDS:
+//                                   [16 vertices][re_hi | re_lo | im_hi | im_lo][KP halves] (+16 halves of row pad), then the
+//                                   vertices' power-of-two scales.
+//   fc_backward_stream_kernel   blockIdx.y = frequency f.  A persistent workgroup brings its records in by LDS-DMA (no register
+//                               staging, no conversion), double-buffered, ONE barrier per record, and takes BOTH products from one pass
+//                               over H:
+//                                   gW[k,i]  += sum_v H[v,k] conj(xt[v,i])      (9 of 16 wavefronts; transposing LDS reads)
+//                                   gxt[v,i]  = sum_k H[v,k] conj(W_f[k,i])     (7 wavefronts; W_f lives in their REGISTERS for the
+//                                                                                whole launch: 4 (row tile, k block) units each)
+//                               The k-partials of gxt cross the wavefronts through a small LDS buffer and leave as fp32 (f, v, i).
+//   fc_backward_gx_kernel       gx from the F gxt slices and x (phase-derivative term included).
+//
+// Against the two-kernel arrangement (data kernel with its own contraction + filter-gradient kernel) the filter no longer
+// travels from L2 through every CU once per 16 vertices, the gather kernel has no slab / barrier skeleton, and H is
+// regrouped by nobody.
+#pragma once
+#include <stdlib.h>
+#include "fc_backward_kernels.hpp"
+
+namespace fc {
+
+constexpr int kStreamUnits = 4;      // (row tile, k block) units of the gxt product per gxt wavefront
+constexpr int kStreamPartStride = 2 * kTile + 4;     // floats per row of a gxt partial tile: 16-byte aligned entry pairs, lane groups on distinct banks
+
+struct StreamPlan {
+    bool ok;
+    int F, KP, IP, NMT, KST, KSI, NU, G, NW, T, ntiles, P, nslots;
+    int img_bytes;       // 16 * KSI halves
+    int rec_bytes;       // image + [16] s_v + [16] 1/s_v, rounded up to whole KiB (DMA pieces)
+    size_t lds;
+    size_t hrec_bytes, gwp_bytes, gxt_bytes;
+    int nt_dump;
+};
+
+struct StreamArgs {
+    int N, I, O, R, F, B;
+    int KP, IP, NMT, KST, KSI, G, NW, ntiles, P, nslots;
+    int img_bytes, rec_bytes;
+    int wKI, wKP;            // channel stride and k entries per row of the packed backward image (k = r*wKI + o)
+    int nt_dump;
+    unsigned long long* stamps;   // development only (fc_debug_stamp_buffer, FC_STAMP_KERNEL=stream): s_memtime stamps of workgroup (0, 0)
+    int dbg;                 // development only (FC_DEBUG_BWD): bit0 no walk, bit1 no gxt product, bit2 no gW product, bit3 no H stores,
+                             // bit4 the stream kernel re-reads its first record (L2), bit5 H stored with the default cache policy, bit6 records last-produced first
+};
+
+// The arrangement serves meshes that fill the machine for several rounds, in the default arithmetic mode, on shapes whose
+// registers and LDS it fits (the reference's default layer -- 48 channels, 6 rings, band limit 2 -- among them); everything
+// else keeps the data / filter kernel pair.
+inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
+    StreamPlan p = {};
+    p.ok = false;
+    static const bool off = [] { const char* e = dev_env("FC_BWD_STREAM"); return e && atoi(e) == 0; }();
+    if (off || !factored || halves != 2 || d->N <= 0) return p;
+    const int R = d->R, O = d->O, I = d->I;
+    p.F = 2 * d->B + 1;
+    if (R < 2 || R > 8 || (R & 1) || p.F * R > 32 || (R * O) % 32 != 0 || I > 64 || O > 64 || d->B > 3) return p;
+    p.KP = R * O;
+    p.IP = round_up(I, 16);
+    p.NMT = p.IP / 16;
+    p.KST = p.KP / 32;
+    if (p.KST < 3) return p;
+    p.KSI = filter_image_stride(p.KP);
+    p.NU = p.NMT * p.KST;
+    p.G = (p.NU + kStreamUnits - 1) / kStreamUnits;
+    p.NW = kWaves - p.G;
+    if (p.NW < p.NMT || p.G < 1) return p;
+    const int row_tiles = p.KP / 16, min_ct_waves = p.NW / p.NMT;
+    p.T = (row_tiles + min_ct_waves - 1) / min_ct_waves;
+    if (p.T > 6) return p;
+    p.nslots = p.G + p.NMT - 1;
+    p.ntiles = (d->N + kTile - 1) / kTile;
+    const int cus = num_cus();
+    if (p.ntiles < 2 * cus) return p;                       // (below: the edge-split / frequency-group / half-tile plans of the kernel pair)
+    p.P = cus / p.F;
+    if (p.P < 1) p.P = 1;
+    p.img_bytes = kTile * p.KSI * 2;
+    p.rec_bytes = round_up(p.img_bytes + 2 * kTile * 4, 1024);
+    if (I & 1) return p;                                     // (x rows travel by 16-byte DMA lanes)
+    p.lds = (size_t)2 * p.rec_bytes + (size_t)2 * 4 * p.IP * kXbStride * 2 + (size_t)3 * kTile * I * 8 + 4 * 64 * 4 + 2 * 8 * 64 * 4 +
+            2 * 64 * 4 + (size_t)2 * p.nslots * kTile * kStreamPartStride * 4;
+    if (kTile * I * 8 > kWaves * 1024 - 1024) return p;
+    if ((size_t)p.ntiles * p.F * p.rec_bytes >= ((size_t)1 << 32) || (size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;
+    if (p.lds > kMaxLds) return p;
+    p.hrec_bytes = (size_t)p.ntiles * p.F * p.rec_bytes + 1024;
+    p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
+    p.gxt_bytes = (size_t)p.F * d->N * I * sizeof(float2);
+    p.nt_dump = p.hrec_bytes > ((size_t)192 << 20) ? 1 : 0;
+    p.ok = true;
+    return p;
+}
+
+inline StreamArgs make_stream_args(const fc_dims* d, const StreamPlan& p) {
+    StreamArgs a;
+    a.N = d->N; a.I = d->I; a.O = d->O; a.R = d->R; a.F = p.F; a.B = d->B;
+    a.KP = p.KP; a.IP = p.IP; a.NMT = p.NMT; a.KST = p.KST; a.KSI = p.KSI; a.G = p.G; a.NW = p.NW; a.ntiles = p.ntiles; a.P = p.P;
+    a.nslots = p.nslots;
+    a.img_bytes = p.img_bytes; a.rec_bytes = p.rec_bytes;
+    const MmaGeom gw = make_mma_geom(d->I, d->R, d->O, 2);
+    a.wKI = gw.KI; a.wKP = gw.KP;
+    a.nt_dump = p.nt_dump;
+    static const int dbg = [] { const char* e = dev_env("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    static const bool stamp_me = [] { const char* e = dev_env("FC_STAMP_KERNEL"); return e && e[0] == 's'; }();
+    a.stamps = stamp_me ? debug_stamp_buffer() : nullptr;
+    return a;
+}
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+// R halves (one per ring) of one plane as R/2 dwords, stored with one instruction
+template <int R, bool NT>
+__device__ __forceinline__ void store_plane_row(uint32_t* dst, const uint32_t (&w)[R / 2]) {
+    if constexpr (R == 2) {
+        if (NT) __builtin_nontemporal_store(w[0], dst); else *dst = w[0];
+    } else if constexpr (R == 4) {
+        typedef u32x2 __attribute__((aligned(4))) u2;
+        const u32x2 v = {w[0], w[1]};
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u2*>(dst)); else *reinterpret_cast<u2*>(dst) = v;
+    } else if constexpr (R == 6) {
+        typedef u32x3 __attribute__((aligned(4))) u3;
+        const u32x3 v = {w[0], w[1], w[2]};
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u3*>(dst)); else *reinterpret_cast<u3*>(dst) = v;
+    } else {
+        typedef u32x4 __attribute__((aligned(4))) u4;
+        const u32x4 v = {w[0], w[1], w[2], w[3]};
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst)); else *reinterpret_cast<u4*>(dst) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+template <int R, int B>
+__global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
+    const float2* __restrict__ ggy, const float* __restrict__ gsten, const int32_t* __restrict__ growptr,
+    const int32_t* __restrict__ gruns, char* __restrict__ hrec, const StreamArgs a) {
+    constexpr int F = 2 * B + 1;
+    static_assert(F * R <= 32 && (R & 1) == 0, "one walk per vertex, an even ring count");
+    constexpr int RECF = factored_record_floats(B);
+    constexpr int LOG_CR = factored_log_chunk_records(B);
+    constexpr int CR = 1 << LOG_CR;
+    constexpr int NR = kRingChunks;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const ring = reinterpret_cast<float*>(smem) + wave * NR * 256;      // [NR][256] floats per wavefront
+    const int O = a.O;
+    const int ol = lane < O ? lane : 0;       // lanes >= O gather channel 0 and are never stored
+
+    auto dma_chunk = [&](const int first, const int ch) {
+        const float* src = gsten + ((size_t)first + ((size_t)ch << LOG_CR)) * RECF + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (ch & (NR - 1)) * 256), 16, 0, 0);
+    };
+    auto slot_range = [&](const int tile, int& b, int& e, int (&run)[R]) {
+        b = 0;
+        e = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) run[q] = 0;
+        const int j = tile * kTile + wave;
+        if (tile < a.ntiles && j < a.N) {
+            b = growptr[j];
+            e = growptr[j + 1];
+#pragma unroll
+            for (int q = 0; q < R; ++q) run[q] = gruns[(size_t)j * kRunStride + q];
+        }
+    };
+    auto rec_ptr = [&](const int s) {
+        if constexpr (CR * RECF == 256) return ring + ((s * RECF) & (NR * 256 - 1));
+        else return ring + ((s >> LOG_CR) & (NR - 1)) * 256 + (s & (CR - 1)) * RECF;
+    };
+
+    const int grid = gridDim.x;
+    int beg = 0, end = 0, ro[R];
+    {
+        slot_range(first_tile_of_block(), beg, end, ro);
+        const int nch = (end - beg + CR - 1) >> LOG_CR;
+        for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
+    }
+    for (int tile = first_tile_of_block(); tile < a.ntiles; tile += grid) {
+        int nbeg = 0, nend = 0, nro[R];
+        slot_range(tile + grid, nbeg, nend, nro);
+        const int nslots = end - beg;
+        const int nch = (nslots + CR - 1) >> LOG_CR;
+        f32x2 h[R][F];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int f = 0; f < F; ++f) h[r][f] = f32x2{0.f, 0.f};
+
+        // ---------------------------------------------------------------- the walk (fc_backward_data_kernel's, one group)
+        float2 ga = make_float2(0.f, 0.f), gb = ga;
+        if (nslots > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+            const int d0 = __float_as_int(rec_ptr(0)[3]);
+            const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
+            ga = gather_row(ggy, d0, 8u * O, 8u * ol);
+            gb = gather_row(ggy, d1, 8u * O, 8u * ol);
+        }
+        auto slot = [&](auto qc, const int s, float2& gcur) {
+            constexpr int Q = decltype(qc)::value;
+            const float* rp = rec_ptr(s);
+            const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+            const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
+            const f32x2 gv = f32x2{gcur.x, gcur.y};
+            gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
+            const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
+            f32x2 ph[F], z[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                ph[f] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
+                z[f] = cmul_conj_pk_step1(gv, ph[f]);
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) z[f] = cmul_conj_pk_step2(gv, ph[f], z[f]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) h[Q][f] = __builtin_elementwise_fma(w0v, z[f], h[Q][f]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) h[Q + 1][f] = __builtin_elementwise_fma(w1v, z[f], h[Q + 1][f]);
+        };
+        if (!(kDevSwitches && (a.dbg & 1))) {
+            static_for<0, R - 1>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                int s = ro[Q];
+                const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                while (s < run_end) {
+                    const int m = s & (CR - 1);
+                    if (m == 0 && s > 0) {       // entering a chunk: the one before it is consumed, its ring slot refilled
+                        const int ch = s >> LOG_CR;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                    }
+                    const int stop = min(run_end, s - m + CR);
+                    if ((s & 1) && s < stop) {
+                        slot(qc, s, gb);
+                        ++s;
+                    }
+                    for (; s + 1 < stop; s += 2) {
+                        slot(qc, s, ga);
+                        slot(qc, s + 1, gb);
+                    }
+                    if (s < stop) {
+                        slot(qc, s, ga);
+                        ++s;
+                    }
+                }
+            });
+        }
+        {   // my source is done: stream the first record chunks of my next tile's source
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
+            for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
+        }
+
+        // ---------------------------------------------------------------- scale, split, store
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int f = 0; f < F; ++f) mx = fmaxf(mx, fmaxf(fabsf(h[r][f].x), fabsf(h[r][f].y)));
+        mx = wave_max_nonneg(mx);
+        float scale, inv_scale;
+        split_scale(mx, scale, inv_scale);
+        if (mx == 0.f) inv_scale = 0.f;           // an all-zero row drops out of the second operand x~ / s_v and its column scales
+        char* const rec0 = hrec + (size_t)tile * F * a.rec_bytes;
+        const int row_off = wave * a.KSI * 2 + lane * R * 2;       // bytes: my vertex's row, my R entries of a plane
+        auto rows = [&](auto nt_c) {
+            constexpr bool NT = decltype(nt_c)::value;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                uint32_t hi[R], lo[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    f16x2 h2, l2;
+                    split_halves2(h[r][f], scale, h2, l2);
+                    hi[r] = __builtin_bit_cast(uint32_t, h2);
+                    lo[r] = __builtin_bit_cast(uint32_t, l2);
+                }
+                constexpr uint32_t kLow = 0x05040100u, kHigh = 0x07060302u;      // (b.lo16, a.lo16) / (b.hi16, a.hi16) of perm(a, b)
+                uint32_t p0[R / 2], p1[R / 2], p2[R / 2], p3[R / 2];
+#pragma unroll
+                for (int dd = 0; dd < R / 2; ++dd) {
+                    p0[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kLow);       // re_hi
+                    p1[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kLow);       // re_lo
+                    p2[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kHigh);      // im_hi
+                    p3[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kHigh);      // im_lo
+                }
+                if (lane < O && !(kDevSwitches && (a.dbg & 8))) {
+                    char* const dst = rec0 + (size_t)f * a.rec_bytes + row_off;
+                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst), p0);
+                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 2), p1);
+                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 4), p2);
+                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 6), p3);
+                }
+                if (lane == 0) {
+                    float* tail = reinterpret_cast<float*>(rec0 + (size_t)f * a.rec_bytes + a.img_bytes);
+                    tail[wave] = scale;
+                    tail[kTile + wave] = inv_scale;
+                }
+            }
+        };
+        if (a.nt_dump && !(kDevSwitches && (a.dbg & 32))) rows(std::true_type{}); else rows(std::false_type{});
+        beg = nbeg;
+        end = nend;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ro[q] = nro[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stream
+// T = 16x16 complex gW tiles a gW wavefront owns.
+//
+// Timeline of record k (ONE workgroup barrier per record).  Up to the barrier a wavefront only waits for its pieces of
+// record k; everything else happens BEHIND the barrier, where it overlaps with the other wavefronts' matrix work:
+//   barrier(k) | DMA of record k+1 starts (its buffer was last read before the barrier) | x rows of record k+3 requested |
+//   gxt of record k-1 leaves (fixed-order sum of the k-partials) | second operand of record k+1 (x~ / s_v * t[i] in halves,
+//   planes [i][vertex]) from the column magnitudes written one record earlier | column magnitudes of record k+2 |
+//   products of record k (role of the wavefront) | wait for my DMA pieces | barrier(k+1)
+// Every LDS buffer is written in one barrier interval and read in the next, two copies each.
+template <int T>
+__global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
+    const float2* __restrict__ gx_, const char* __restrict__ hrec, const float* __restrict__ gwpk,
+    float2* __restrict__ ggwp /* [P][F][KP][IP], k = o*R + r */, float2* __restrict__ ggxt /* [F][N][I] */, const StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KP = a.KP, IP = a.IP, KSI = a.KSI, I = a.I, F = a.F, N = a.N;
+    const int xplane = IP * kXbStride;
+    const int xrs = I * 8;                                              // bytes of an x row (a multiple of 16)
+    const int xtile = kTile * xrs;                                      // a tile's rows: contiguous in x
+    lds_f16* const xb0 = (lds_f16*)(smem + 2 * a.rec_bytes);          // [2][c_hi, c_lo, d_hi, d_lo][IP][kXbStride] halves: second operand of gW
+    char* const xrow0 = smem + 2 * a.rec_bytes + 2 * 4 * xplane * 2;    // [3][16 vertices][I] complex: the x rows of a tile (DMA)
+    float* const tail0 = reinterpret_cast<float*>(xrow0 + 3 * xtile);   // [4][64]: [16] s_v, [16] 1/s_v of a record (DMA)
+    float* const pmax0 = tail0 + 4 * 64;                                // [2][8 row pairs][64]  max over the pair of |x[v][i]|^2 / s_v^2
+    float* const tinv0 = pmax0 + 2 * 8 * 64;                            // [2][64]  1 / t[i]
+    float* const part0 = tinv0 + 2 * 64;                                // [2][nslots][16][kStreamPartStride]  k-partials of gxt
+    const int part_floats = a.nslots * kTile * kStreamPartStride;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y;
+    const int m = f - a.B;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool is_gxt = wave < a.G;
+    // The launch is bound by the instructions its wavefronts issue (every vector instruction holds a SIMD for four cycles; a SIMD runs
+    // wavefronts w, w+4, w+8, w+12), so the per-record chores are dealt to even out the SIMDs next to the matrix roles:
+    //   row pair j of the second operand -> wavefronts 0,1,2, 4,5,6, 8,9;   the fixed-order sum of the gxt partials -> 3,7, 10,11, 14,15
+    const int op_pair = (wave & 3) == 3 || wave > 9 ? -1 : wave - (wave >> 2);
+    const int red_idx = wave == 3 ? 0 : wave == 7 ? 1 : wave == 10 ? 2 : wave == 11 ? 3 : wave == 14 ? 4 : wave == 15 ? 5 : -1;
+
+    // ---- my records: tiles blockIdx.x + k*P.  Everything a record needs arrives by LDS-DMA issued with instructions the compiler does
+    // not track (fc_common.hpp) and is waited for once, in front of the record's barrier: between a record's requests and that wait the
+    // wavefront executes NO vector-memory wait (no load whose value is used, no spill) -- vmcnt counts in issue order, and one early
+    // wait behind a freshly requested record is that record's whole HBM latency.
+    const int nrec = ((int)blockIdx.x < a.ntiles) ? (a.ntiles - (int)blockIdx.x + a.P - 1) / a.P : 0;
+    const int npieces = a.rec_bytes >> 10;
+    const int nxp = (xtile + 1023) >> 10;               // KiB pieces of a tile's x rows
+    // (development: bit 4 -- always my first record, from L2; bit 6 -- my records last-produced first)
+    const bool rev = kDevSwitches && (a.dbg & 64);
+    auto tile_of = [&](const int k) { return (int)blockIdx.x + (rev ? nrec - 1 - k : k) * a.P; };
+    const uint32_t lane16 = lane * 16;
+    // the image of record k (whole KiB pieces) ...
+    auto dma_rec = [&](const int k) {
+        if (k >= nrec) return;
+        const char* src = hrec + ((size_t)tile_of((kDevSwitches && (a.dbg & 16)) ? 0 : k) * F + f) * a.rec_bytes;
+        char* dst = smem + (k & 1) * a.rec_bytes;
+        for (int p = wave; p < npieces; p += kWaves) lds_dma16_saddr(src + p * 1024, lane16, dst + p * 1024);
+    };
+    // ... and the x rows of a tile (contiguous in x; a tile past the end of the mesh re-reads the last rows: finite values, their 1 / s_v is 0)
+    // with the record's scales
+    auto dma_x = [&](const int k) {
+        if (k >= nrec) return;
+        const int tile = tile_of(k);
+        if (wave < nxp) {
+            // (per-lane offsets, clamped into x: N * I * 8 < 4 GiB, plan_stream)
+            const uint32_t voff = min((uint32_t)tile * (uint32_t)xtile + (uint32_t)wave * 1024u + lane16, (uint32_t)N * (uint32_t)xrs - 16u);
+            const int left = xtile - wave * 1024;
+            if (left >= 1024) lds_dma16_saddr(gx_, voff, xrow0 + (k % 3) * xtile + wave * 1024);
+            else lds_dma16_saddr_lanes(gx_, voff, xrow0 + (k % 3) * xtile + wave * 1024, (1ull << (left / 16)) - 1ull);
+        } else if (wave == 15) {
+            lds_dma4_saddr(hrec + ((size_t)tile * F + f) * a.rec_bytes + a.img_bytes, lane * 4, tail0 + (k & 3) * 64);
+        }
+    };
+    // Second operand of gW for record k: x~[v][i] / s_v * t[i] in halves, planes [i][vertex], t[i] = power-of-two scale of column i over
+    // the tile's vertices -- in two steps, one record apart, so that nobody forms a 16-row maximum alone:
+    //   pair_max(k): my two rows' max of |x|^2 / s_v^2 per column -> pmax
+    //   pair_rows(k): t[i] from the eight pair maxima; my two rows rotated, scaled, split and stored as (v, v+1) dwords
+    auto pair_max = [&](const int k) {
+        if (k >= nrec || op_pair < 0) return;
+        const char* rows = xrow0 + (k % 3) * xtile + (2 * op_pair) * xrs;
+        const float* tl = tail0 + (k & 3) * 64 + kTile + 2 * op_pair;
+        const int lc = lane < I ? lane : 0;
+        const float2 x0 = *reinterpret_cast<const float2*>(rows + lc * 8), x1 = *reinterpret_cast<const float2*>(rows + xrs + lc * 8);
+        const float i0_ = tl[0], i1_ = tl[1];
+        const float m0 = (x0.x * x0.x + x0.y * x0.y) * (i0_ * i0_), m1 = (x1.x * x1.x + x1.y * x1.y) * (i1_ * i1_);
+        pmax0[((k & 1) * 8 + op_pair) * 64 + lane] = lane < I ? fmaxf(m0, m1) : 0.f;
+    };
+    const int pm_ = m < 0 ? -m : m;
+    auto pair_rows = [&](const int k) {
+        if (k >= nrec || op_pair < 0) return;
+        lds_f16* const xb = xb0 + (k & 1) * 4 * xplane;
+        const char* rows = xrow0 + (k % 3) * xtile + (2 * op_pair) * xrs;
+        const float* tl = tail0 + (k & 3) * 64 + kTile + 2 * op_pair;
+        const float* pm = pmax0 + (k & 1) * 8 * 64 + lane;
+        const int lc = lane < I ? lane : 0;
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = pm[j * 64];
+        float2 xv[2];
+        float inv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            xv[e] = *reinterpret_cast<const float2*>(rows + e * xrs + lc * 8);
+            inv[e] = tl[e];
+        }
+        float cm2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cm2 = fmaxf(cm2, pv[j]);
+        const float cm = __builtin_amdgcn_sqrtf(cm2) * 1.000001f;      // (never below the true value: v_sqrt_f32 is good to an ulp)
+        float t, inv_t;
+        split_scale(cm, t, inv_t);
+        uint32_t hh[2], ll[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float2 x = lane < I ? xv[e] : make_float2(0.f, 0.f);
+            const float2 u = unit_conj(x);
+            float2 pw = pm_ == 0 ? make_float2(1.f, 0.f) : u;              // u^|m| (wave-uniform selection), conjugated for m < 0
+            if (pm_ >= 2) pw = cmul(pw, u);
+            if (pm_ >= 3) pw = cmul(pw, u);
+            if (m < 0) pw.y = -pw.y;
+            const float2 xt = cmul(x, pw);                                   // rotated feature of the source row
+            f16x2 hi, lo;
+            split_halves2(f32x2{xt.x, xt.y}, inv[e] * t, hi, lo);
+            hh[e] = __builtin_bit_cast(uint32_t, hi);
+            ll[e] = __builtin_bit_cast(uint32_t, lo);
+        }
+        if (lane < IP) {
+            constexpr uint32_t kLow = 0x05040100u, kHigh = 0x07060302u;      // (b.lo16, a.lo16) / (b.hi16, a.hi16) of perm(a, b)
+            lds_u32* p = (lds_u32*)xb + (lane * kXbStride) / 2 + op_pair;      // entries (v, v + 1) of row i = lane
+            p[0] = __builtin_amdgcn_perm(hh[1], hh[0], kLow);                  // c_hi
+            p[xplane / 2] = __builtin_amdgcn_perm(ll[1], ll[0], kLow);         // c_lo
+            p[2 * (xplane / 2)] = __builtin_amdgcn_perm(hh[1], hh[0], kHigh);  // d_hi
+            p[3 * (xplane / 2)] = __builtin_amdgcn_perm(ll[1], ll[0], kHigh);  // d_lo
+        }
+        if (op_pair == 0) tinv0[(k & 1) * 64 + lane] = inv_t;
+    };
+    // gxt of record k leaves: entries (v, v+1; i), fixed-order sum of the partials of row tile i / 16 (the vertex scales were divided out
+    // when the partials were stored), filter-row scale divided out.  Six wavefronts, two complex entries per thread and round.
+    const rsrc_t gxt_rs = make_rsrc(ggxt + (size_t)f * N * I, (uint32_t)((size_t)N * I * 8));
+    float rsc[2] = {0.f, 0.f};               // filter-row scales of my (at most two) entries' channels
+    if (red_idx >= 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int e = red_idx * 64 + lane + n * 6 * 64;
+            if (e < 8 * IP && e % IP < I) rsc[n] = gwpk[e % IP];
+        }
+    }
+    auto reduce_gxt = [&](const int k) {
+        if (red_idx < 0) return;
+        const float* pp0 = part0 + (k & 1) * part_floats;
+        const int j0 = tile_of(k) * kTile;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int e = red_idx * 64 + lane + n * 6 * 64;
+            if (e >= 8 * IP) break;
+            const int vp = e / IP, ri = e - vp * IP;           // vertices 2 vp, 2 vp + 1; channel ri
+            const int r_mt = ri >> 4;
+            const int r_lo = (r_mt * a.KST) / kStreamUnits, r_n = ((r_mt + 1) * a.KST - 1) / kStreamUnits - r_lo + 1;
+            const float* pp = pp0 + ((r_lo + r_mt) * kTile + (ri & 15)) * kStreamPartStride + 4 * vp;
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < r_n; ++g) s4 += *reinterpret_cast<const f32x4*>(pp + g * kTile * kStreamPartStride);
+            const float wsc = rsc[n];
+            const int j = j0 + 2 * vp;
+            if (ri < I) {
+                if (j < N) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.x * wsc, s4.y * wsc}), gxt_rs, (j * I + ri) * 8, 0, 0);
+                if (j + 1 < N)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.z * wsc, s4.w * wsc}), gxt_rs, ((j + 1) * I + ri) * 8, 0, 0);
+            }
+        }
+    };
+
+    Stamper stamp{(kDevSwitches && a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + wave * 256 : nullptr, 0};
+    stamp.realtime(29);
+    stamp(28);
+    dma_rec(0);
+    dma_x(0);
+    dma_x(1);
+    dma_x(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    pair_max(0);
+    pair_max(1);
+    __syncthreads();
+    pair_rows(0);
+
+    // up to the barrier of record k, and what follows it for every wavefront alike
+    auto head = [&](const int k) {
+        stamp(10);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // my pieces of record k (and of the rows behind it) have landed; my LDS stores are done
+        stamp(0);
+        __builtin_amdgcn_s_barrier();
+        stamp(2);
+        if (k > 0) reduce_gxt(k - 1);       // (LDS reads and stores: ahead of the requests below, nothing waits behind them)
+        dma_rec(k + 1);
+        dma_x(k + 3);
+        stamp(4);
+        pair_rows(k + 1);
+        pair_max(k + 2);
+        stamp(1);
+    };
+
+    if (is_gxt) {
+        // ---- gxt role: units u = 4*wave .. +3 of the NMT*KST (row tile mt over i, k block kb) grid, mt-major; their filter fragments
+        // W_f[i = mt*16 + fr][k' = kb*32 + 8*fq + j] (conjugated, 1/F folded in, row-scaled halves: the packed backward image, whose k is
+        // ring-major) stay in registers for the whole launch.  Every request is unconditional and from a valid address (a wavefront's
+        // dead units re-read the last one): behind a branch per element the 128 two-byte loads of a lane become 128 round trips.
+        u32x4 wrh[kStreamUnits], wrl[kStreamUnits], wih[kStreamUnits], wil[kStreamUnits];
+        const int u0 = wave * kStreamUnits;
+        const int NU = a.NMT * a.KST;
+        {
+            const uint16_t* const wplanes = reinterpret_cast<const uint16_t*>(gwpk + IP) + (size_t)f * 4 * IP * a.wKP;
+            const int plane_sz = IP * a.wKP;
+            uint32_t raw[kStreamUnits][4][8];
+#pragma unroll
+            for (int ui = 0; ui < kStreamUnits; ++ui) {
+                const int u = min(u0 + ui, NU - 1);
+                const int mt = u / a.KST, kb = u - mt * a.KST;
+                const int row = (mt * 16 + fr) * 32;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kq = kb * 32 + 8 * fq + e;          // k' = o*R + r
+                    const int o = kq / a.R, r = kq - o * a.R;
+                    const int kk = r * a.wKI + o;
+                    const int off = (kk >> 5) * IP * 32 + row + (kk & 31);
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) raw[ui][pl][e] = wplanes[pl * plane_sz + off];
+                }
+            }
+#pragma unroll
+            for (int ui = 0; ui < kStreamUnits; ++ui) {
+                auto pk = [&](const int pl) {
+                    return u32x4{raw[ui][pl][0] | (raw[ui][pl][1] << 16), raw[ui][pl][2] | (raw[ui][pl][3] << 16),
+                                 raw[ui][pl][4] | (raw[ui][pl][5] << 16), raw[ui][pl][6] | (raw[ui][pl][7] << 16)};
+                };
+                wrh[ui] = pk(0);
+                wrl[ui] = pk(1);
+                wih[ui] = pk(2);
+                wil[ui] = pk(3);
+            }
+        }
+        const int hbase = fr * KSI + 8 * fq;
+        for (int k = 0; k < nrec; ++k) {
+            head(k);
+            const lds_f16* const img = (const lds_f16*)(smem + (k & 1) * a.rec_bytes) + hbase;
+            if (!(kDevSwitches && (a.dbg & 2))) {
+                float* const pp = part0 + (k & 1) * part_floats + (4 * fq) * kStreamPartStride + 2 * fr;
+                const float isv = tail0[(k & 3) * 64 + kTile + fr];      // 1 / s_v of my column of the partial tiles (a power of two, or 0)
+                // re = (Wre Hre) - (Wim Him): the two sums in accumulators of their own, subtracted when the tile leaves (no sign flips of
+                // the fragments)
+                f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = are, arn = are;
+                int mt_prev = u0 / a.KST;
+                // (D layout of a partial tile: column = vertex = lane&15, row = 4*(lane>>4)+j; slot = wavefront + row tile)
+                auto put = [&](const int mt_) {
+                    float* q = pp + (wave + mt_) * kTile * kStreamPartStride;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float2*>(q + j * kStreamPartStride) = make_float2((are[j] - arn[j]) * isv, aim[j] * isv);
+                };
+                // H fragments of a unit: row fr of the image, k block kb, the four planes (re_hi, re_lo, im_hi, im_lo).  ONE set of registers:
+                // the next unit's real planes are requested as soon as this unit's six instructions on them are issued, the imaginary
+                // planes likewise (a second set does not fit beside the filter fragments)
+                u32x4 h[4];
+                auto hrow_of = [&](const int ui) { return img + (min(u0 + ui, NU - 1) % a.KST) * 32; };
+                {
+                    const lds_f16* hrow = hrow_of(0);
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) h[pl] = *reinterpret_cast<lds_u32x4*>(hrow + pl * KP);
+                }
+#pragma unroll
+                for (int ui = 0; ui < kStreamUnits; ++ui) {
+                    const int u = u0 + ui;
+                    const bool live = u < NU;
+                    if (live) {
+                        const int mt = u / a.KST;
+                        if (mt != mt_prev) {
+                            put(mt_prev);
+                            are = f32x4{0.f, 0.f, 0.f, 0.f};
+                            aim = are;
+                            arn = are;
+                            mt_prev = mt;
+                        }
+                        are = mfma32h(wrl[ui], h[0], are); aim = mfma32h(wil[ui], h[0], aim);
+                        are = mfma32h(wrh[ui], h[1], are); aim = mfma32h(wih[ui], h[1], aim);
+                        are = mfma32h(wrh[ui], h[0], are); aim = mfma32h(wih[ui], h[0], aim);
+                    }
+                    if (ui + 1 < kStreamUnits) {
+                        const lds_f16* hn = hrow_of(ui + 1);
+                        h[0] = *reinterpret_cast<lds_u32x4*>(hn);
+                        h[1] = *reinterpret_cast<lds_u32x4*>(hn + KP);
+                    }
+                    if (live) {
+                        aim = mfma32h(wrl[ui], h[2], aim); arn = mfma32h(wil[ui], h[2], arn);
+                        aim = mfma32h(wrh[ui], h[3], aim); arn = mfma32h(wih[ui], h[3], arn);
+                        aim = mfma32h(wrh[ui], h[2], aim); arn = mfma32h(wih[ui], h[2], arn);
+                    }
+                    if (ui + 1 < kStreamUnits) {
+                        const lds_f16* hn = hrow_of(ui + 1);
+                        h[2] = *reinterpret_cast<lds_u32x4*>(hn + 2 * KP);
+                        h[3] = *reinterpret_cast<lds_u32x4*>(hn + 3 * KP);
+                    }
+                }
+                put(mt_prev);
+            }
+            stamp(3);
+        }
+    } else {
+        // ---- gW role: my tiles all lie in ONE column tile (i0), the row tiles of that column are dealt round-robin to the wavefronts that
+        // share it (fc_backward_filter_half2_kernel's arithmetic)
+        const int jw = wave - a.G;
+        const int my_ct = jw % a.NMT, my_idx = jw / a.NMT;
+        const int ct_waves = (a.NW - my_ct + a.NMT - 1) / a.NMT;
+        const int i0 = my_ct * 16;
+        int gw_h[T];                // first k of my row tiles; -1: unused slot
+#pragma unroll
+        for (int n = 0; n < T; ++n) {
+            const int rt = my_idx + n * ct_waves;
+            gw_h[n] = (rt * 16 < KP) ? rt * 16 : -1;
+        }
+        const int a_lane = (8 * (fq & 1) + ((lane & 15) >> 2)) * KSI + 4 * (lane & 3) + (fq >= 2 ? KP : 0);
+        const int a_hi_off = fq >= 2 ? KP : 0;               // (re_hi | im_hi) = the (re) fragment's address + this
+        const int b_lane = i0 * kXbStride + fr * kXbStride + 8 * (fq & 1);    // B fragment: plane[i = i0 + fr][vertices 8*(g&1) .. +7]
+        const bool upper = fq >= 2;
+        const uint32_t lo_im_sign = upper ? 0u : 0x80008000u;
+        f32x4 gre[T], gim[T];
+#pragma unroll
+        for (int n = 0; n < T; ++n) { gre[n] = f32x4{0.f, 0.f, 0.f, 0.f}; gim[n] = gre[n]; }
+        for (int k = 0; k < nrec; ++k) {
+            head(k);
+            const lds_f16* const img = (const lds_f16*)(smem + (k & 1) * a.rec_bytes) + a_lane;
+            const lds_f16* const bp = xb0 + (k & 1) * 4 * xplane + b_lane;
+            if (!(kDevSwitches && (a.dbg & 4))) {
+                // second operand, once per record.  The MFMA's 32 k entries are two blocks of the 16 vertices; with H = a + ib and
+                // X = c + id in halves, re = a c + b d takes THREE instructions: (a_hi | a_lo)[c_hi; c_hi] + (b_hi | b_lo)[d_hi; d_hi] +
+                // (a_hi | b_hi)[c_lo; d_lo] -- the two hi*lo products share one -- and im = b c - a d likewise with [-d_lo; c_lo].
+                const u32x4 c_hh = *reinterpret_cast<lds_u32x4*>(bp);
+                const u32x4 d_hh = *reinterpret_cast<lds_u32x4*>(bp + 2 * xplane);
+                const u32x4 lo_re = *reinterpret_cast<lds_u32x4*>(bp + (upper ? 3 : 1) * xplane);      // [c_lo; d_lo]
+                u32x4 lo_im = *reinterpret_cast<lds_u32x4*>(bp + (upper ? 1 : 3) * xplane);            // [-d_lo; c_lo]
+                const float it = tinv0[(k & 1) * 64 + i0 + fr];
+                const u32x4 sign = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+                const u32x4 nd_hh = d_hh ^ sign;
+                lo_im ^= u32x4{lo_im_sign, lo_im_sign, lo_im_sign, lo_im_sign};
+                // first operand: (hi | lo) of the real and of the imaginary part of H^T, and (re_hi | im_hi), by transposing reads; the
+                // next tile's are requested before this tile's matrix instructions
+                u32x4 af[2][3];
+                auto load_a = [&](const int n, u32x4 (&dst)[3]) {
+                    const lds_f16* ap = img + (gw_h[n] >= 0 ? gw_h[n] : 0);
+                    const lds_f16* ah = ap + a_hi_off;
+                    const u32x2 r0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap)));
+                    const u32x2 r1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * KSI)));
+                    const u32x2 i0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP)));
+                    const u32x2 i1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 2 * KP + 4 * KSI)));
+                    const u32x2 h0_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ah)));
+                    const u32x2 h1_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ah + 4 * KSI)));
+                    dst[0] = u32x4{r0.x, r0.y, r1.x, r1.y};
+                    dst[1] = u32x4{i0_.x, i0_.y, i1_.x, i1_.y};
+                    dst[2] = u32x4{h0_.x, h0_.y, h1_.x, h1_.y};
+                };
+                load_a(0, af[0]);
+#pragma unroll
+                for (int n = 0; n < T; ++n) {
+                    if (n + 1 < T) load_a(n + 1, af[(n + 1) & 1]);
+                    if (gw_h[n] >= 0) {
+                        const u32x4 are = af[n & 1][0], aim = af[n & 1][1], ahi = af[n & 1][2];
+                        // H conj(X), H = a + ib, X = c + id:  re = a c + b d,  im = b c - a d
+                        f32x4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
+                        re = mfma32h(ahi, lo_re, re);  im = mfma32h(ahi, lo_im, im);
+                        re = mfma32h(are, c_hh, re);   im = mfma32h(aim, c_hh, im);
+                        re = mfma32h(aim, d_hh, re);   im = mfma32h(are, nd_hh, im);
+                        gre[n] += re * it;
+                        gim[n] += im * it;
+                    }
+                }
+            }
+            stamp(3);
+        }
+        // flush my gW partial
+#pragma unroll
+        for (int n = 0; n < T; ++n) {
+            if (gw_h[n] >= 0) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int kk = gw_h[n] + 4 * fq + jj;
+                    const int i = i0 + fr;
+                    ggwp[(((size_t)blockIdx.x * F + f) * KP + kk) * IP + i] = make_float2(gre[n][jj], gim[n][jj]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (nrec > 0) reduce_gxt(nrec - 1);
+    stamp(30);
+    stamp.realtime(31);
+}
+
+// ------------------------------------------------------------------------------------------------ gx
+// gx[j,i] = sum_f gxt_f conj(u^m) + [x != 0] (i x / |x|^2) sum_f m Im(conj(gxt_f) x u^m),  u = exp(-i angle(x))  (1 inside the origin box)
+template <int B>
+__global__ __launch_bounds__(256) void fc_backward_gx_kernel(const float2* __restrict__ gx_, const float2* __restrict__ ggxt,
+                                                             float2* __restrict__ ggx, const size_t count /* N*I */) {
+    constexpr int F = 2 * B + 1;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    float2 z[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) z[f] = ggxt[(size_t)f * count + idx];
+    const float2 x = gx_[idx];
+    const float2 u1 = unit_conj(x);
+    float2 up[B + 1];
+    up[0] = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int q = 1; q <= B; ++q) up[q] = cmul(up[q - 1], u1);
+    const float inv2 = is_origin(x) ? 0.f : 1.f / (x.x * x.x + x.y * x.y);
+    float2 acc = make_float2(0.f, 0.f);
+    float eq = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int mm = f - B;
+        float2 c = up[mm < 0 ? -mm : mm];
+        if (mm < 0) c.y = -c.y;
+        const float2 xtv = cmul(x, c);
+        const float2 out = cmul_conj(z[f], c);
+        acc.x += out.x;
+        acc.y += out.y;
+        eq += (float)mm * (z[f].x * xtv.y - z[f].y * xtv.x);
+    }
+    const float q = eq * inv2;
+    acc.x += -x.y * q;
+    acc.y += x.x * q;
+    ggx[idx] = acc;
+}
+
+}  // namespace fc

@@ -109,6 +109,33 @@ __device__ __forceinline__ void lds_dma16_untracked_lanes(const void* src_lane, 
                  : : "s"(dst), "v"(src_lane), "s"(mask) : "memory", "m0");
 }
 
+// The same with the wave-uniform part of the source address in an SGPR pair and the per-lane part as a 32-bit offset
+// (global_load_lds ... v_off, s[base]): no 64-bit pointer per lane to keep alive across a loop.
+__device__ __forceinline__ void lds_dma16_saddr(const void* src_uniform, uint32_t lane_off, const void* lds_dst_uniform) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_uniform);
+    const uint64_t base = (uint64_t)(uintptr_t)src_uniform;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint64_t sb = ((uint64_t)hi << 32) | lo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane_off), "s"(sb) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma16_saddr_lanes(const void* src_uniform, uint32_t lane_off, const void* lds_dst_uniform,
+                                                      unsigned long long mask) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_uniform);
+    const uint64_t base = (uint64_t)(uintptr_t)src_uniform;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint64_t sb = ((uint64_t)hi << 32) | lo;
+    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
+                 : : "s"(dst), "v"(lane_off), "s"(sb), "s"(mask) : "memory", "m0");
+}
+// 4 bytes per lane (256 bytes per wavefront)
+__device__ __forceinline__ void lds_dma4_saddr(const void* src_uniform, uint32_t lane_off, const void* lds_dst_uniform) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_uniform);
+    const uint64_t base = (uint64_t)(uintptr_t)src_uniform;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint64_t sb = ((uint64_t)hi << 32) | lo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(dst), "v"(lane_off), "s"(sb) : "memory", "m0");
+}
+
 // Records per LDS-ring chunk (log2): the largest power of two whose records fit one 1 KiB global_load_lds.
 __host__ __device__ constexpr int factored_log_chunk_records(int B) {
     const int per_kib = 256 / factored_record_floats(B);

@@ -40,8 +40,13 @@ size_t backward_workspace_bytes(const fc_dims* d);
 //  finishes the pass adds them: backward_finish_params_impl's gx_deferred)
 int backward_data_impl(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum = false);
-int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
-int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream);
+// (factored: the launch is record-driven -- with plan_stream() the H-streaming arrangement has done the filter kernel's work inside
+//  backward_data_impl, and the partials lie k = o*R + r)
+int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored = false);
+bool backward_streams(const fc_dims* d, bool factored);
+int backward_stream_impl(const float* x, const float* gy, const float* rec, const fc_csr* g, const float* wpk, float* gx, void* ws,
+                         size_t ws_bytes, const fc_dims* d, hipStream_t stream, int stages);
+int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored = false);
 // records != 0: images for the record-driven entry points (fc_forward_factored / _geometric, fc_backward_fused)
 int pack_filter_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, hipStream_t stream);
 int pack_filter_params_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd,
@@ -85,7 +90,7 @@ __host__ __device__ inline int dump_k(int r, int o, int R, int O, bool pairs) {
 }
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
                                 int o0 = 0, int i0 = 0, int Ifull = 0,
-                                float* gx_deferred = nullptr);
+                                float* gx_deferred = nullptr, bool factored = false);
 int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,
                            hipStream_t stream);
 int pack_filter_params_block_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd, float* wpk_bwd,

@@ -80,6 +80,11 @@ __device__ __forceinline__ u32x4 buffer_load16(rsrc_t r, int voffset_bytes, int 
 }
 typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) _Float16 lds_f16;
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;        // ds_read_b64_tr_b16 operand
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
 
 // One slab (one angular frequency) through the MFMA pipe for this wavefront's (output tile mt,
 // k partition kp): acc (re, im) += W[mt*16.., k] * slab[vertex, k], complex via four real products

@@ -164,16 +164,16 @@ int fc_backward_wide(const float* x, const float* gy, const float* sten_or_rec_s
             rc = fc::backward_data_impl(xb + ib * bstride, gyb + ob * bstride, sten_or_rec_s, by_source, wpk, part, cws, cws_bytes, &d, records != 0,
                                         st);
             if (rc != FC_OK) return rc;
-            rc = fc::backward_filter_impl(xb + ib * bstride, cws, cws_bytes, &d, st);
+            rc = fc::backward_filter_impl(xb + ib * bstride, cws, cws_bytes, &d, st, records != 0);
             if (rc != FC_OK) return rc;
             if (params) {
                 fc_filter_params block_params = *params;             // (the bias rider belongs to the whole layer: after the blocks)
                 block_params.bias_partials = nullptr;
                 block_params.bias_nparts = 0;
                 block_params.g_bias = nullptr;
-                rc = fc::backward_finish_params_impl(gwb, cws, cws_bytes, &d, &block_params, st, ob * blk, ib * blk, I);
+                rc = fc::backward_finish_params_impl(gwb, cws, cws_bytes, &d, &block_params, st, ob * blk, ib * blk, I, nullptr, records != 0);
             } else {            // explicit filter: the block's gradient goes into its block of gw_eff (rows o, bi*R*F numbers each)
-                rc = fc::backward_finish_impl(gwb, cws, cws_bytes, &d, st);
+                rc = fc::backward_finish_impl(gwb, cws, cws_bytes, &d, st, records != 0);
                 const int rf = dims->R * (2 * dims->B + 1);
                 if (rc == FC_OK)
                     rc = fc::copy_block(gw_eff + 2 * (((size_t)ob * blk * I + (size_t)ib * blk) * rf), I * rf, gwb, bi * rf, bo, bi * rf, st);

@@ -119,8 +119,9 @@ def check_at_config4_size(rank, world, lo, n_owned, plan, fe, fs, x_all, gy_all,
     c_y = rel(y_owned.detach().numpy(), ys.detach().cpu().numpy()[lo:lo + n_owned])
     c_gx = rel(gx.numpy(), gxs.cpu().numpy()[lo:lo + n_owned])
     c_gw = rel(gW.numpy(), gWs.cpu().numpy())
-    print(f'rank {rank}: config-4 size n_owned={n_owned} halo={plan.n_halo} edges(union)={fe.shape[0]} sampled rows: err y={e_y:.2e} gx={e_gx:.2e} '
-          f'({100 * frac_remote:.1f} % of the sampled out-edges end on the other rank); against one process on the union mesh: '
+    print(f'rank {rank}/{world}: config-4 size n_owned={n_owned} halo={plan.n_halo} ({100 * plan.n_halo / n_owned:.1f} %) send={plan.send_counts} '
+          f'recv={plan.recv_counts} edges(union)={fe.shape[0]} sampled rows: err y={e_y:.2e} gx={e_gx:.2e} '
+          f'({100 * frac_remote:.1f} % of the sampled out-edges end on another rank); against one process on the union mesh: '
           f'y={c_y:.2e} gx={c_gx:.2e} gW={c_gw:.2e}', flush=True)
     assert plan.n_halo > 0.02 * n_owned
     assert e_y < 1e-5 and e_gx < 1e-5

@@ -10,9 +10,11 @@ import pytest
 from conftest import ROOT, free_port
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_partitioned_fieldconv_gloo(world):
-    env = dict(os.environ, OMP_NUM_THREADS='2', MASTER_ADDR='127.0.0.1')
+    """world = 8: BASELINE configs[3]'s partition count -- parts with three to five neighbours and peers that exchange nothing
+    (zero counts in the all-to-all-v) -- on a small mesh."""
+    env = dict(os.environ, OMP_NUM_THREADS='1' if world > 4 else '2', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_worker.py')]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)

@@ -1170,6 +1170,12 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
         for native in ('cpp', 'python', False):
             monkeypatch.setenv('FIELDCONV_BLOCK_CALLS', '1' if native else '0')
             monkeypatch.setenv('FIELDCONV_CPP_NODES', '1' if native == 'cpp' else '0')
+            # per-operator leg of the ECHOBlock: its dense tail through torch's own Linear / ReLU nodes (FIELDCONV_ECHO_TAIL=0), so that
+            # the comparison below really is native head against the dense layers
+            if not native and name == 'echo':
+                monkeypatch.setenv('FIELDCONV_ECHO_TAIL', '0')
+            else:
+                monkeypatch.delenv('FIELDCONV_ECHO_TAIL', raising=False)
             args = inputs[name]()
             y = mod(*args)
             seen, todo, found = set(), [y.grad_fn], None
@@ -1195,8 +1201,8 @@ def test_block_level_entry_points_match_the_per_operator_path(dev, monkeypatch, 
                 continue
             if name == 'echo':
                 # ECHOBlock's dense tail (three Linear layers + the residual on |x|) runs through the library's own kernels on the block-level
-                # path (fc_echo_head_*: fp32 matrix-pipe products, sums in another order) and through torch's Linear / ReLU nodes otherwise:
-                # the same arithmetic width, not the same bits (test_echo_head_matches_the_dense_layers_in_double_precision pins it to fp64)
+                # path (fc_echo_head_*: fp32 matrix-pipe products, sums in another order) and -- on this leg, FIELDCONV_ECHO_TAIL=0 -- through
+                # torch's Linear / ReLU nodes: the same arithmetic width, not the same bits (test_echo_head_matches_the_dense_layers_in_double_precision pins it to fp64)
                 assert rel_err(H(a), H(b)) < 1e-5, name
             else:
                 assert torch.equal(a, b), name

@@ -400,7 +400,12 @@ def test_kernel_description_and_gpu_count_need_no_gpu():
     assert lib.fc_describe_kernels(ctypes.byref(d), 2, buf, len(buf)) == 0
     text = buf.value.decode()
     if os.environ.get('FC_MFMA') in (None, '') and os.environ.get('FC_RING') in (None, ''):
-        assert 'fc_forward_ring_kernel<geometric records,split-f16>' in text and 'fc_backward_filter_half2_kernel' in text, text
+        assert 'fc_forward_ring_kernel<geometric records,split-f16>' in text, text
+        if os.environ.get('FC_BWD_STREAM') in (None, ''):         # config 2 runs the H-streaming arrangement
+            assert 'fc_backward_gather_kernel' in text and 'fc_backward_stream_kernel' in text and 'fc_backward_gx_kernel' in text, text
+        # a FAUST-sized mesh (313 tiles) keeps the data / filter kernel pair
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(4999, 150000, 48, 48, 6, 2)), 2, buf, len(buf)) == 0
+        assert b'fc_backward_filter_half2_kernel' in buf.value, buf.value
     small = _lib.FcDims(1024, 131072, 48, 48, 6, 2)
     assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and b'frequency-major' in buf.value
     assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(100, 10, 48, 48, 9, 2)), 1, buf, len(buf)) == -2

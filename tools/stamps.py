@@ -19,6 +19,7 @@ LABELS_FWD = {0: 'run gathered (2 targets)', 1: 'rows converted', 2: 'barrier: s
 
 
 LABELS_DATA = {10: 'tile start', 0: 'gathered', 1: 'slab converted + kept', 2: 'barrier: slab', 3: 'contracted', 4: 'barrier: partials', 5: 'gx terms'}
+LABELS_STREAM = {10: 'record start', 0: 'my DMA landed', 2: 'barrier', 4: 'next DMA + gxt reduce', 1: 'next x~ operand', 3: 'products'}
 LABELS_FILTER = {10: 'tile start', 1: 'row regrouped', 0: 'x~ operand + next rows requested', 2: 'barrier', 3: 'MFMAs'}
 
 
@@ -29,10 +30,13 @@ def main():
     ap.add_argument('--tiles', type=int, default=2)
     ap.add_argument('--warm', type=int, default=5, help='steps before the stamped one (a few hundred: the settled clock)')
     args = ap.parse_args()
-    if args.which in ('data', 'filter'):                # which of the two backward kernels stamps (read once by the library)
+    if args.which in ('data', 'filter', 'stream'):                # which of the two backward kernels stamps (read once by the library)
         os.environ['FC_STAMP_KERNEL'] = args.which
     if not os.environ.get('FIELDCONV_HIP_LIB'):       # (a development variant built by tools/build_variants.sh)
-        __graft_entry__.build()
+        from fieldconv_amd import build as _b
+        if _b.needs_build() or _b.dev_needs_build():
+            __graft_entry__.build()
+        os.environ['FIELDCONV_HIP_LIB'] = _b.DEV_LIB_PATH     # the stamps exist in the development build only
     from fieldconv_amd import _lib
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.nn import FieldConv
@@ -66,7 +70,7 @@ def main():
     torch.cuda.synchronize()
     lib.fc_debug_stamp_buffer(None)
     st = buf.cpu().view(16, 256)
-    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_DATA
+    labels = LABELS_FWD if args.which == 'fwd' else LABELS_FILTER if args.which == 'filter' else LABELS_STREAM if args.which == 'stream' else LABELS_DATA
     t0 = min([int(st[w, 0]) & ((1 << 56) - 1) for w in range(16) if int(st[w, 0])] or [0])
     # per-wave totals by phase (cycles spent BEFORE each label), over the whole launch
     import collections

@@ -90,6 +90,14 @@ def bwd_data():
         lib.fc_backward_data(_p(x), _p(gy), _p(graph.sten_s), ctypes.byref(cs), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), _stream())
 
 
+def bwd_gather():
+    lib.fc_backward_gather(_p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(ws), nb, ctypes.byref(dims), _stream())
+
+
+def bwd_stream():
+    lib.fc_backward_stream(_p(x), _p(wb), _p(gx), _p(ws), nb, ctypes.byref(dims), _stream())
+
+
 def bwd_filter():
     lib.fc_backward_filter(_p(x), _p(ws), nb, ctypes.byref(dims), REC, _stream())
 
@@ -124,6 +132,9 @@ if 'f' in which:
     print(f'FC_DEBUG={tag} {kind} fwd median/min us: %.1f %.1f' % timeit(fwd))
 if 'b' in which:
     print(f'FC_DEBUG={tag} {kind} bwd_data median/min us: %.1f %.1f' % timeit(bwd_data))
+    if FACT and lib.fc_backward_streams(ctypes.byref(dims), REC):
+        print(f'FC_DEBUG={tag} {kind} bwd_gather median/min us: %.1f %.1f' % timeit(bwd_gather))
+        print(f'FC_DEBUG={tag} {kind} bwd_stream(+gx) median/min us: %.1f %.1f' % timeit(bwd_stream))
     print(f'FC_DEBUG={tag} {kind} bwd_filter median/min us: %.1f %.1f' % timeit(bwd_filter))
     print(f'FC_DEBUG={tag} {kind} finish median/min us: %.1f %.1f' % timeit(finish))
     print('gx checksum: %.9e %.9e' % (gx.abs().double().sum().item(), gx[::97].real.double().sum().item()))
