@@ -901,6 +901,21 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     # writes gx; the filter kernel's contract traffic is x and the filter gradient (its H input is a temporary)
     contract = (('fc_forward', fwd_b, fwd_f), ('fc_backward_data', bwd_b - wbytes - 8 * n_local * C, bwd_f - gemm_f),
                 ('fc_backward_filter', wbytes + 8 * n_local * C, gemm_f))
+    # Large meshes run the H-streaming arrangement (fc_backward_streams): 'fc_backward_data' then brackets the GATHER kernel (records, indices,
+    # the cotangent rows; H is a temporary) and 'fc_backward_filter' the STREAMING kernel + gx (x in, gx out, the filter in, its gradient
+    # out; both contractions: their flops)
+    streaming = False
+    try:
+        from fieldconv_amd import _lib as _l
+        from fieldconv_amd.functional import make_dims
+        import ctypes as _ct
+        streaming = bool(factored and _l.load().fc_backward_streams(_ct.byref(make_dims(mesh_graph, C, C, B)), 1))
+    except Exception:       # noqa: BLE001
+        streaming = False
+    if streaming:
+        gather_b = E * (8 * R * F + 8) + 8 * n_local + 8 * n_local * C
+        contract = (('fc_forward', fwd_b, fwd_f), ('fc_backward_data', gather_b, bwd_f - 2 * gemm_f),
+                    ('fc_backward_filter', bwd_b - gather_b, 2 * gemm_f))
 
     def kernel_report(kt):
         kt = dict(kt)
@@ -924,7 +939,10 @@ def run_layer(args, world, rank, dev, use_dist, backend):
     dom = max(per_kernel, key=lambda n: per_kernel[n]['avg_ms']) if per_kernel else None
     roofline = None
     if dom:
-        roofline = {'bound': 'hbm', 'kernel': dom + '_kernel', 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+        kname = dom + '_kernel'
+        if streaming and dom != 'fc_forward':
+            kname = 'fc_backward_gather_kernel' if dom == 'fc_backward_data' else 'fc_backward_stream_kernel (+ fc_backward_gx_kernel)'
+        roofline = {'bound': 'hbm', 'kernel': kname, 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': per_kernel[dom]['hbm_frac'], 'traffic': per_kernel[dom].get('hbm_bytes_per_launch'),
                     'avg_launch_ms': per_kernel[dom]['avg_ms'], 'algorithmic_bytes_per_launch': per_kernel[dom]['algorithmic_bytes'],
                     'mfma_busy': per_kernel[dom].get('mfma_busy'), 'valu_busy': per_kernel[dom].get('valu_busy'),
@@ -939,6 +957,8 @@ def run_layer(args, world, rank, dev, use_dist, backend):
         c = counters.get(dom, {})
         if c.get('valu_insts'):
             useful = E * ((2 + 2 * B) * 2 + 2 * F) if dom != 'fc_backward_filter' else None
+            if streaming and dom == 'fc_backward_data':
+                useful = E * (2 * F + 2 * F)         # gather kernel: F complex products with the record's phases + 2F ring updates per edge
             roofline['issue'] = {'vector_insts_per_launch': c['valu_insts'], 'scalar_insts_per_launch': c.get('salu_insts'),
                                  'gather_arithmetic_insts_per_launch': useful,
                                  'useful_frac': (useful / c['valu_insts']) if useful else None, 'valu_busy': c.get('valu_busy')}

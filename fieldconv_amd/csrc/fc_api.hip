@@ -276,7 +276,7 @@ int fc_backward_all(const float* x, const float* gy, const float* sten_or_rec_s,
     if (!params) return fc_backward_finish(gw_eff, workspace, workspace_bytes, dims, records, stream);
     if (!defer) return fc_backward_finish_params(gw_eff, workspace, workspace_bytes, dims, records, params, stream);
     return fc::backward_finish_params_impl(gw_eff, workspace, workspace_bytes, dims, params, static_cast<hipStream_t>(stream), 0, 0, 0, gx,
-                                           records != 0);
+                                           records != 0, x);
 }
 
 int fc_forward_params(const float* x, const float* sten_or_records, const fc_csr* by_target, int32_t kind,

@@ -618,17 +618,18 @@ static int launch_gather(const float2* gy, const float* rec, const fc_csr* g, ch
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-template <int T>
+template <int T, int KPT = 0, int IT = 0>
 static int launch_stream(const float2* x, const char* hrec, const float* wpk, float2* gwp, float2* gxt, const StreamArgs& a,
                          const StreamPlan& p, hipStream_t stream) {
-    auto kern = fc_backward_stream_kernel<T>;
+    auto kern = fc_backward_stream_kernel<T, KPT, IT>;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), p.lds, lds_ok)) return FC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds, stream, x, hrec, wpk, gwp, gxt, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-// stage bits: 1 the gather kernel, 2 the streaming kernel + gx (fc_backward_gather / fc_backward_stream time them apart)
+// stage bits: 1 the gather kernel, 2 the streaming kernel + gx (fc_backward_gather / fc_backward_stream time them apart), 4 without the gx
+// kernel (fc_backward_all with module parameters: the finishing launch forms gx)
 int backward_stream_impl(const float* x, const float* gy, const float* rec, const fc_csr* g, const float* wpk, float* gx, void* ws,
                          size_t ws_bytes, const fc_dims* d, hipStream_t stream, int stages) {
     const StreamPlan p = plan_stream(d, split_mode(), true);
@@ -650,10 +651,11 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
         if (rc != FC_OK) return rc;
     }
     if (!(stages & 2)) return FC_OK;
-    if (p.T <= 2) rc = launch_stream<2>(x2, hrec, wpk, gwp, gxt, a, p, stream);
+    if (p.T == 6 && p.KP == 288 && d->I == 48) rc = launch_stream<6, 288, 48>(x2, hrec, wpk, gwp, gxt, a, p, stream);      // the reference's default layer
+    else if (p.T <= 2) rc = launch_stream<2>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else if (p.T <= 4) rc = launch_stream<4>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else rc = launch_stream<6>(x2, hrec, wpk, gwp, gxt, a, p, stream);
-    if (rc != FC_OK) return rc;
+    if (rc != FC_OK || (stages & 4)) return rc;         // (4: gx is left to the launch that finishes the pass)
     const size_t count = (size_t)d->N * d->I;
     const dim3 grid((unsigned)((count + 255) / 256));
     float2* gx2 = reinterpret_cast<float2*>(gx);
@@ -782,15 +784,19 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
 }
 
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
-                                int o0, int i0, int Ifull, float* gx_deferred, bool factored) {
+                                int o0, int i0, int Ifull, float* gx_deferred, bool factored, const float* x_for_gx) {
     {
         const StreamPlan sp = plan_stream(d, split_mode(), factored);
-        if (sp.ok) {        // partial (p, f, k = o*R + r, i) at ((p*F + f)*KP + k)*IP + i; gx is complete (no partial arrays)
-            if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes) return FC_ERR_WORKSPACE;
+        if (sp.ok) {        // partial (p, f, k = o*R + r, i) at ((p*F + f)*KP + k)*IP + i
+            if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes) return FC_ERR_WORKSPACE;
             const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + sp.hrec_bytes);
+            // gx_deferred (fc_backward_all): the gx kernel was left out -- gx is formed from the gxt slices by extra workgroups of this launch
+            const bool ride = gx_deferred && x_for_gx;
+            const float* gxt = reinterpret_cast<const float*>(static_cast<char*>(ws) + sp.hrec_bytes + sp.gwp_bytes);
             return reduce_param_grads_impl(gwp, (size_t)sp.F * sp.KP * sp.IP, (size_t)sp.IP, (size_t)sp.KP * sp.IP, (size_t)d->R * sp.IP, false, sp.P,
                                            gw_eff, fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d,
-                                           stream, o0, i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias);
+                                           stream, o0, i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias, ride ? gxt : nullptr,
+                                           ride ? gx_deferred : nullptr, (size_t)d->N * d->I, 0, ride ? -d->B : 0, ride ? x_for_gx : nullptr);
         }
     }
     const BwdPlan p = plan_backward(d, split_mode());
@@ -815,7 +821,7 @@ int backward_data_impl(const float* x, const float* gy, const float* sten, const
                        void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum) {
     // large meshes: gather kernel + the kernel that streams H once for gxt and gW + gx -- after this call gx is complete AND the
     // filter-gradient partials are in the workspace (backward_filter_impl has nothing left to do)
-    if (backward_streams(d, factored)) return backward_stream_impl(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, stream, 3);
+    if (backward_streams(d, factored)) return backward_stream_impl(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, stream, defer_gx_sum ? 7 : 3);
     return split_mode() ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum)
                         : backward_data_impl_mode<false>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum);
 }

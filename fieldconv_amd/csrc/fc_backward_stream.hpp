@@ -70,7 +70,7 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     p.NU = p.NMT * p.KST;
     p.G = (p.NU + kStreamUnits - 1) / kStreamUnits;
     p.NW = kWaves - p.G;
-    if (p.NW < p.NMT || p.G < 1) return p;
+    if (p.NW < p.NMT || p.NW < 8 || p.G < 1) return p;        // (eight gW wavefronts build the row pairs of the second operand)
     const int row_tiles = p.KP / 16, min_ct_waves = p.NW / p.NMT;
     p.T = (row_tiles + min_ct_waves - 1) / min_ct_waves;
     if (p.T > 6) return p;
@@ -86,6 +86,7 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     p.lds = (size_t)2 * p.rec_bytes + (size_t)2 * 4 * p.IP * kXbStride * 2 + (size_t)3 * kTile * I * 8 + 4 * 64 * 4 + 2 * 8 * 64 * 4 +
             2 * 64 * 4 + (size_t)2 * p.nslots * kTile * kStreamPartStride * 4;
     if (kTile * I * 8 > kWaves * 1024 - 1024) return p;
+    if ((size_t)8 * p.IP * make_mma_geom(I, R, O, 2).KP > p.lds) return p;       // (frequency f's filter planes are staged through LDS once)
     if ((size_t)p.ntiles * p.F * p.rec_bytes >= ((size_t)1 << 32) || (size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;
     if (p.lds > kMaxLds) return p;
     p.hrec_bytes = (size_t)p.ntiles * p.F * p.rec_bytes + 1024;
@@ -322,12 +323,15 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
 //   planes [i][vertex]) from the column magnitudes written one record earlier | column magnitudes of record k+2 |
 //   products of record k (role of the wavefront) | wait for my DMA pieces | barrier(k+1)
 // Every LDS buffer is written in one barrier interval and read in the next, two copies each.
-template <int T>
+// KPT / IT: k entries per row and channel count as compile-time constants (0: from the arguments) -- the fragment reads of the
+// default layer then carry their plane / row offsets as immediates instead of a vector add each.
+template <int T, int KPT = 0, int IT = 0>
 __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     const float2* __restrict__ gx_, const char* __restrict__ hrec, const float* __restrict__ gwpk,
     float2* __restrict__ ggwp /* [P][F][KP][IP], k = o*R + r */, float2* __restrict__ ggxt /* [F][N][I] */, const StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int KP = a.KP, IP = a.IP, KSI = a.KSI, I = a.I, F = a.F, N = a.N;
+    const int KP = KPT ? KPT : a.KP, I = IT ? IT : a.I, IP = IT ? round_up(IT, 16) : a.IP, KSI = KPT ? filter_image_stride(KPT) : a.KSI;
+    const int F = a.F, N = a.N;
     const int xplane = IP * kXbStride;
     const int xrs = I * 8;                                              // bytes of an x row (a multiple of 16)
     const int xtile = kTile * xrs;                                      // a tile's rows: contiguous in x
@@ -347,10 +351,14 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     const int fr = lane & 15, fq = lane >> 4;
     const bool is_gxt = wave < a.G;
     // The launch is bound by the instructions its wavefronts issue (every vector instruction holds a SIMD for four cycles; a SIMD runs
-    // wavefronts w, w+4, w+8, w+12), so the per-record chores are dealt to even out the SIMDs next to the matrix roles:
-    //   row pair j of the second operand -> wavefronts 0,1,2, 4,5,6, 8,9;   the fixed-order sum of the gxt partials -> 3,7, 10,11, 14,15
-    const int op_pair = (wave & 3) == 3 || wave > 9 ? -1 : wave - (wave >> 2);
-    const int red_idx = wave == 3 ? 0 : wave == 7 ? 1 : wave == 10 ? 2 : wave == 11 ? 3 : wave == 14 ? 4 : wave == 15 ? 5 : -1;
+    // wavefronts w, w+4, w+8, w+12) and by the memory pipe's issue rate, so the per-record chores are dealt by what the matrix roles leave
+    // (in-kernel stamps, cycles per record: gxt products 1 800, gW products 2 600; the interval's 45 requests 1 300 per wavefront when
+    // seven issue them, a row pair of the second operand 1 400, the gxt sum 800):
+    //   gxt wavefronts: the requests, and (the first six) the fixed-order sum of the gxt partials;
+    //   gW wavefronts:  one row pair of the second operand each (the first eight)
+    const int op_pair = (wave >= a.G && wave - a.G < 8) ? wave - a.G : -1;
+    const int red_idx = wave < 6 && wave < a.G ? wave : -1;
+    const int n_red = a.G < 6 ? a.G : 6;
 
     // ---- my records: tiles blockIdx.x + k*P.  Everything a record needs arrives by LDS-DMA issued with instructions the compiler does
     // not track (fc_common.hpp) and is waited for once, in front of the record's barrier: between a record's requests and that wait the
@@ -363,27 +371,33 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     const bool rev = kDevSwitches && (a.dbg & 64);
     auto tile_of = [&](const int k) { return (int)blockIdx.x + (rev ? nrec - 1 - k : k) * a.P; };
     const uint32_t lane16 = lane * 16;
-    // the image of record k (whole KiB pieces) ...
-    auto dma_rec = [&](const int k) {
-        if (k >= nrec) return;
-        const char* src = hrec + ((size_t)tile_of((kDevSwitches && (a.dbg & 16)) ? 0 : k) * F + f) * a.rec_bytes;
-        char* dst = smem + (k & 1) * a.rec_bytes;
-        for (int p = wave; p < npieces; p += kWaves) lds_dma16_saddr(src + p * 1024, lane16, dst + p * 1024);
-    };
-    // ... and the x rows of a tile (contiguous in x; a tile past the end of the mesh re-reads the last rows: finite values, their 1 / s_v is 0)
-    // with the record's scales
-    auto dma_x = [&](const int k) {
-        if (k >= nrec) return;
-        const int tile = tile_of(k);
-        if (wave < nxp) {
-            // (per-lane offsets, clamped into x: N * I * 8 < 4 GiB, plan_stream)
-            const uint32_t voff = min((uint32_t)tile * (uint32_t)xtile + (uint32_t)wave * 1024u + lane16, (uint32_t)N * (uint32_t)xrs - 16u);
-            const int left = xtile - wave * 1024;
-            if (left >= 1024) lds_dma16_saddr(gx_, voff, xrow0 + (k % 3) * xtile + wave * 1024);
-            else lds_dma16_saddr_lanes(gx_, voff, xrow0 + (k % 3) * xtile + wave * 1024, (1ull << (left / 16)) - 1ull);
-        } else if (wave == 15) {
-            lds_dma4_saddr(hrec + ((size_t)tile * F + f) * a.rec_bytes + a.img_bytes, lane * 4, tail0 + (k & 3) * 64);
+    // The requests of a barrier interval -- the image of record k + 1 (whole KiB pieces), the x rows of tile k + 3 (contiguous in x; a
+    // tile past the end of the mesh re-reads the last bytes: finite values, their 1 / s_v is 0) and that record's scales -- are dealt to
+    // the first `nd` wavefronts (the gxt role: it has the shorter interval, and a wavefront that issues six pieces into a busy memory
+    // pipe stands there for a thousand cycles)
+    auto dma_piece = [&](const int q, const int krec, const int kx) {
+        if (q < npieces) {
+            if (krec < nrec) {
+                const char* src = hrec + ((size_t)tile_of((kDevSwitches && (a.dbg & 16)) ? 0 : krec) * F + f) * a.rec_bytes;
+                lds_dma16_saddr(src + q * 1024, lane16, smem + (krec & 1) * a.rec_bytes + q * 1024);
+            }
+        } else if (kx < nrec) {
+            const int tile = tile_of(kx);
+            const int xq = q - npieces;
+            if (xq < nxp) {
+                // (per-lane offsets, clamped into x: N * I * 8 < 4 GiB, plan_stream)
+                const uint32_t voff = min((uint32_t)tile * (uint32_t)xtile + (uint32_t)xq * 1024u + lane16, (uint32_t)N * (uint32_t)xrs - 16u);
+                const int left = xtile - xq * 1024;
+                if (left >= 1024) lds_dma16_saddr(gx_, voff, xrow0 + (kx % 3) * xtile + xq * 1024);
+                else lds_dma16_saddr_lanes(gx_, voff, xrow0 + (kx % 3) * xtile + xq * 1024, (1ull << (left / 16)) - 1ull);
+            } else {
+                lds_dma4_saddr(hrec + ((size_t)tile * F + f) * a.rec_bytes + a.img_bytes, lane * 4, tail0 + (kx & 3) * 64);
+            }
         }
+    };
+    auto requests = [&](const int krec, const int kx, const int nd) {
+        if (wave < nd)
+            for (int q = wave; q < npieces + nxp + 1; q += nd) dma_piece(q, krec, kx);
     };
     // Second operand of gW for record k: x~[v][i] / s_v * t[i] in halves, planes [i][vertex], t[i] = power-of-two scale of column i over
     // the tile's vertices -- in two steps, one record apart, so that nobody forms a 16-row maximum alone:
@@ -451,51 +465,77 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     // gxt of record k leaves: entries (v, v+1; i), fixed-order sum of the partials of row tile i / 16 (the vertex scales were divided out
     // when the partials were stored), filter-row scale divided out.  Six wavefronts, two complex entries per thread and round.
     const rsrc_t gxt_rs = make_rsrc(ggxt + (size_t)f * N * I, (uint32_t)((size_t)N * I * 8));
-    float rsc[2] = {0.f, 0.f};               // filter-row scales of my (at most two) entries' channels
-    if (red_idx >= 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int e = red_idx * 64 + lane + n * 6 * 64;
-            if (e < 8 * IP && e % IP < I) rsc[n] = gwpk[e % IP];
+    // my entry of the first round (the only one up to 48 channels): filter-row scale, first partial's LDS offset (floats) | slots << 16 |
+    // vertex pair << 20 | channel << 24
+    float rsc = 0.f;
+    int rin = -1;
+    auto red_entry = [&](const int e, float& sc, int& in) {
+        sc = 0.f;
+        in = -1;
+        if (e < 8 * IP) {
+            const int vp = e / IP, ri = e - vp * IP;           // vertices 2 vp, 2 vp + 1; channel ri
+            const int r_mt = ri >> 4;
+            const int r_lo = (r_mt * a.KST) / kStreamUnits, r_n = ((r_mt + 1) * a.KST - 1) / kStreamUnits - r_lo + 1;
+            if (ri < I) {
+                sc = gwpk[ri];
+                in = (((r_lo + r_mt) * kTile + (ri & 15)) * kStreamPartStride + 4 * vp) | (r_n << 16) | (vp << 20) | (ri << 24);
+            }
         }
-    }
+    };
+    if (red_idx >= 0) red_entry(red_idx * 64 + lane, rsc, rin);
+    const int red_round = n_red * 64;
     auto reduce_gxt = [&](const int k) {
         if (red_idx < 0) return;
         const float* pp0 = part0 + (k & 1) * part_floats;
         const int j0 = tile_of(k) * kTile;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int e = red_idx * 64 + lane + n * 6 * 64;
-            if (e >= 8 * IP) break;
-            const int vp = e / IP, ri = e - vp * IP;           // vertices 2 vp, 2 vp + 1; channel ri
-            const int r_mt = ri >> 4;
-            const int r_lo = (r_mt * a.KST) / kStreamUnits, r_n = ((r_mt + 1) * a.KST - 1) / kStreamUnits - r_lo + 1;
-            const float* pp = pp0 + ((r_lo + r_mt) * kTile + (ri & 15)) * kStreamPartStride + 4 * vp;
+        auto one = [&](const float sc, const int in) {
+            if (in < 0) return;
+            const float* pp = pp0 + (in & 0xffff);
+            const int r_n = (in >> 16) & 15, vp2 = 2 * ((in >> 20) & 15), ri = in >> 24;
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
             for (int g = 0; g < r_n; ++g) s4 += *reinterpret_cast<const f32x4*>(pp + g * kTile * kStreamPartStride);
-            const float wsc = rsc[n];
-            const int j = j0 + 2 * vp;
-            if (ri < I) {
-                if (j < N) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.x * wsc, s4.y * wsc}), gxt_rs, (j * I + ri) * 8, 0, 0);
-                if (j + 1 < N)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.z * wsc, s4.w * wsc}), gxt_rs, ((j + 1) * I + ri) * 8, 0, 0);
-            }
+            const int ob = ((j0 + vp2) * I + ri) * 8;
+            if (j0 + vp2 < N) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.x * sc, s4.y * sc}), gxt_rs, ob, 0, 0);
+            if (j0 + vp2 + 1 < N)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s4.z * sc, s4.w * sc}), gxt_rs, ob + I * 8, 0, 0);
+        };
+        one(rsc, rin);
+        for (int e = red_idx * 64 + lane + red_round; e < 8 * IP; e += red_round) {       // further rounds (64 channels, fewer gxt wavefronts): their mapping is formed on the spot
+            float sc2;
+            int in2;
+            red_entry(e, sc2, in2);
+            one(sc2, in2);
         }
     };
 
     Stamper stamp{(kDevSwitches && a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + wave * 256 : nullptr, 0};
     stamp.realtime(29);
     stamp(28);
-    dma_rec(0);
-    dma_x(0);
-    dma_x(1);
-    dma_x(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    pair_max(0);
-    pair_max(1);
-    __syncthreads();
-    pair_rows(0);
+    // ---- the filter fragments of the gxt role: units u = 4*wave .. +3 of the NMT*KST (row tile mt over i, k block kb) grid, mt-major;
+    // W_f[i = mt*16 + fr][k' = kb*32 + 8*fq + j] (conjugated, 1/F folded in, row-scaled halves) stay in registers for the whole launch.
+    // The packed backward image is ring-major (k = r*KI + o) where the records are o-major (k' = o*R + r): frequency f's four planes come
+    // into LDS once (whole KiB pieces, all wavefronts; nothing else lives there yet) and every lane picks its 128 halves from there --
+    // picked from global memory they were 128 two-byte requests per lane on seven wavefronts of every CU: a quarter of the launch.
+    {
+        const int wbytes = 4 * IP * a.wKP * 2;
+        const char* wsrc = reinterpret_cast<const char*>(gwpk + IP) + (size_t)f * wbytes;
+        for (int p = wave; p < (wbytes >> 10); p += kWaves) lds_dma16_saddr(wsrc + p * 1024, lane16, smem + p * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // (the gxt wavefronts pick their fragments here; then, behind one more barrier -- the LDS is free for the records -- every wavefront:)
+    auto first_requests = [&]() {
+        __syncthreads();
+        requests(0, 0, kWaves);
+        requests(nrec, 1, kWaves);          // (no image: the x rows and scales of records 1 and 2)
+        requests(nrec, 2, kWaves);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        pair_max(0);
+        pair_max(1);
+        __syncthreads();
+        pair_rows(0);
+    };
 
     // up to the barrier of record k, and what follows it for every wavefront alike
     auto head = [&](const int k) {
@@ -504,9 +544,7 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
         stamp(0);
         __builtin_amdgcn_s_barrier();
         stamp(2);
-        if (k > 0) reduce_gxt(k - 1);       // (LDS reads and stores: ahead of the requests below, nothing waits behind them)
-        dma_rec(k + 1);
-        dma_x(k + 3);
+        requests(k + 1, k + 3, a.G);
         stamp(4);
         pair_rows(k + 1);
         pair_max(k + 2);
@@ -514,44 +552,42 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     };
 
     if (is_gxt) {
-        // ---- gxt role: units u = 4*wave .. +3 of the NMT*KST (row tile mt over i, k block kb) grid, mt-major; their filter fragments
-        // W_f[i = mt*16 + fr][k' = kb*32 + 8*fq + j] (conjugated, 1/F folded in, row-scaled halves: the packed backward image, whose k is
-        // ring-major) stay in registers for the whole launch.  Every request is unconditional and from a valid address (a wavefront's
-        // dead units re-read the last one): behind a branch per element the 128 two-byte loads of a lane become 128 round trips.
-        u32x4 wrh[kStreamUnits], wrl[kStreamUnits], wih[kStreamUnits], wil[kStreamUnits];
+        // ---- gxt role
         const int u0 = wave * kStreamUnits;
         const int NU = a.NMT * a.KST;
+        u32x4 wrh[kStreamUnits], wrl[kStreamUnits], wih[kStreamUnits], wil[kStreamUnits];
         {
-            const uint16_t* const wplanes = reinterpret_cast<const uint16_t*>(gwpk + IP) + (size_t)f * 4 * IP * a.wKP;
+            typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+            lds_u16* const wl = (lds_u16*)smem;
             const int plane_sz = IP * a.wKP;
-            uint32_t raw[kStreamUnits][4][8];
 #pragma unroll
             for (int ui = 0; ui < kStreamUnits; ++ui) {
                 const int u = min(u0 + ui, NU - 1);
                 const int mt = u / a.KST, kb = u - mt * a.KST;
                 const int row = (mt * 16 + fr) * 32;
+                uint32_t v[4][4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int kq = kb * 32 + 8 * fq + e;          // k' = o*R + r
-                    const int o = kq / a.R, r = kq - o * a.R;
-                    const int kk = r * a.wKI + o;
-                    const int off = (kk >> 5) * IP * 32 + row + (kk & 31);
+                for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t pr[4][2];
 #pragma unroll
-                    for (int pl = 0; pl < 4; ++pl) raw[ui][pl][e] = wplanes[pl * plane_sz + off];
+                    for (int e = 0; e < 2; ++e) {
+                        const int kq = kb * 32 + 8 * fq + 2 * jj + e;          // k' = o*R + r
+                        const int o = kq / a.R, r = kq - o * a.R;
+                        const int kk = r * a.wKI + o;
+                        const int off = (kk >> 5) * IP * 32 + row + (kk & 31);
+#pragma unroll
+                        for (int pl = 0; pl < 4; ++pl) pr[pl][e] = wl[pl * plane_sz + off];
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) v[pl][jj] = pr[pl][0] | (pr[pl][1] << 16);
                 }
-            }
-#pragma unroll
-            for (int ui = 0; ui < kStreamUnits; ++ui) {
-                auto pk = [&](const int pl) {
-                    return u32x4{raw[ui][pl][0] | (raw[ui][pl][1] << 16), raw[ui][pl][2] | (raw[ui][pl][3] << 16),
-                                 raw[ui][pl][4] | (raw[ui][pl][5] << 16), raw[ui][pl][6] | (raw[ui][pl][7] << 16)};
-                };
-                wrh[ui] = pk(0);
-                wrl[ui] = pk(1);
-                wih[ui] = pk(2);
-                wil[ui] = pk(3);
+                wrh[ui] = u32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
+                wrl[ui] = u32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
+                wih[ui] = u32x4{v[2][0], v[2][1], v[2][2], v[2][3]};
+                wil[ui] = u32x4{v[3][0], v[3][1], v[3][2], v[3][3]};
             }
         }
+        first_requests();
         const int hbase = fr * KSI + 8 * fq;
         for (int k = 0; k < nrec; ++k) {
             head(k);
@@ -616,10 +652,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
                 put(mt_prev);
             }
             stamp(3);
+            if (k > 0) reduce_gxt(k - 1);
         }
     } else {
         // ---- gW role: my tiles all lie in ONE column tile (i0), the row tiles of that column are dealt round-robin to the wavefronts that
         // share it (fc_backward_filter_half2_kernel's arithmetic)
+        first_requests();
         const int jw = wave - a.G;
         const int my_ct = jw % a.NMT, my_idx = jw / a.NMT;
         const int ct_waves = (a.NW - my_ct + a.NMT - 1) / a.NMT;
@@ -681,12 +719,24 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
                         re = mfma32h(ahi, lo_re, re);  im = mfma32h(ahi, lo_im, im);
                         re = mfma32h(are, c_hh, re);   im = mfma32h(aim, c_hh, im);
                         re = mfma32h(aim, d_hh, re);   im = mfma32h(are, nd_hh, im);
-                        gre[n] += re * it;
-                        gim[n] += im * it;
+                        // (packed: two fp32 products per instruction)
+                        {
+                            const f32x2 it2 = {it, it};
+                            f32x2 g0 = {gre[n].x, gre[n].y}, g1 = {gre[n].z, gre[n].w}, g2 = {gim[n].x, gim[n].y}, g3 = {gim[n].z, gim[n].w};
+                            g0 = __builtin_elementwise_fma(f32x2{re.x, re.y}, it2, g0);
+                            g1 = __builtin_elementwise_fma(f32x2{re.z, re.w}, it2, g1);
+                            g2 = __builtin_elementwise_fma(f32x2{im.x, im.y}, it2, g2);
+                            g3 = __builtin_elementwise_fma(f32x2{im.z, im.w}, it2, g3);
+                            gre[n] = f32x4{g0.x, g0.y, g1.x, g1.y};
+                            gim[n] = f32x4{g2.x, g2.y, g3.x, g3.y};
+                        }
                     }
                 }
             }
             stamp(3);
+            // gxt of the record before leaves now, not right behind the barrier: its partials stay valid until the next barrier, and the
+            // stores find a memory pipe that the interval's requests have left
+            if (k > 0) reduce_gxt(k - 1);
         }
         // flush my gW partial
 #pragma unroll
@@ -708,40 +758,14 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ gx
-// gx[j,i] = sum_f gxt_f conj(u^m) + [x != 0] (i x / |x|^2) sum_f m Im(conj(gxt_f) x u^m),  u = exp(-i angle(x))  (1 inside the origin box)
+// gx from the F gxt slices and x (fc_common.hpp: gx_from_slices) -- as a launch of its own behind the per-kernel entry points; behind
+// fc_backward_all with module parameters the same arithmetic rides in the launch that finishes the pass (fc_pack.hip)
 template <int B>
 __global__ __launch_bounds__(256) void fc_backward_gx_kernel(const float2* __restrict__ gx_, const float2* __restrict__ ggxt,
                                                              float2* __restrict__ ggx, const size_t count /* N*I */) {
-    constexpr int F = 2 * B + 1;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
-    float2 z[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) z[f] = ggxt[(size_t)f * count + idx];
-    const float2 x = gx_[idx];
-    const float2 u1 = unit_conj(x);
-    float2 up[B + 1];
-    up[0] = make_float2(1.f, 0.f);
-#pragma unroll
-    for (int q = 1; q <= B; ++q) up[q] = cmul(up[q - 1], u1);
-    const float inv2 = is_origin(x) ? 0.f : 1.f / (x.x * x.x + x.y * x.y);
-    float2 acc = make_float2(0.f, 0.f);
-    float eq = 0.f;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const int mm = f - B;
-        float2 c = up[mm < 0 ? -mm : mm];
-        if (mm < 0) c.y = -c.y;
-        const float2 xtv = cmul(x, c);
-        const float2 out = cmul_conj(z[f], c);
-        acc.x += out.x;
-        acc.y += out.y;
-        eq += (float)mm * (z[f].x * xtv.y - z[f].y * xtv.x);
-    }
-    const float q = eq * inv2;
-    acc.x += -x.y * q;
-    acc.y += x.x * q;
-    ggx[idx] = acc;
+    ggx[idx] = gx_from_slices<B>(gx_[idx], ggxt, idx, count);
 }
 
 }  // namespace fc

@@ -270,6 +270,40 @@ __device__ __forceinline__ float2 unit_power(float2 u, int m) {
     return p;
 }
 
+// gx[j,i] = sum_f gxt_f conj(u^m) + [x != 0] (i x / |x|^2) sum_f m Im(conj(gxt_f) x u^m),  u = exp(-i angle(x))  (1 inside the origin box):
+// the input gradient from the F slices gxt_f (complex numbers `stride` apart) of the adjoint of the rotated copies
+// (autograd of reference nn/field_conv.py:128-130)
+template <int B>
+__device__ __forceinline__ float2 gx_from_slices(const float2 x, const float2* __restrict__ gxt, const size_t idx, const size_t stride) {
+    constexpr int F = 2 * B + 1;
+    float2 z[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) z[f] = gxt[(size_t)f * stride + idx];
+    const float2 u1 = unit_conj(x);
+    float2 up[B + 1];
+    up[0] = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int q = 1; q <= B; ++q) up[q] = cmul(up[q - 1], u1);
+    const float inv2 = is_origin(x) ? 0.f : 1.f / (x.x * x.x + x.y * x.y);
+    float2 acc = make_float2(0.f, 0.f);
+    float eq = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int mm = f - B;
+        float2 c = up[mm < 0 ? -mm : mm];
+        if (mm < 0) c.y = -c.y;
+        const float2 xtv = cmul(x, c);
+        const float2 out = cmul_conj(z[f], c);
+        acc.x += out.x;
+        acc.y += out.y;
+        eq += (float)mm * (z[f].x * xtv.y - z[f].y * xtv.x);
+    }
+    const float q = eq * inv2;
+    acc.x += -x.y * q;
+    acc.y += x.x * q;
+    return acc;
+}
+
 // In-kernel time stamps (development): lane 0 of every wavefront of workgroup 0 appends (label << 56 | s_memtime).
 struct Stamper {
     unsigned long long* p;      // wave-uniform: this wavefront's 256 slots, or nullptr

@@ -78,7 +78,8 @@ int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, s
                             const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
                             float* g_phase, const fc_dims* d, hipStream_t stream, int o0 = 0, int i0 = 0, int Ifull = 0,
                             const float* bias_partials = nullptr, int bias_nparts = 0, float* g_bias = nullptr,
-                            const float* gx_parts = nullptr, float* gx = nullptr, size_t gx_count = 0, size_t gx_stride = 0, int gx_nparts = 0);
+                            const float* gx_parts = nullptr, float* gx = nullptr, size_t gx_count = 0, size_t gx_stride = 0, int gx_nparts = 0,
+                            const float* gx_x = nullptr);
 // the rider as a launch of its own (fc_pointwise.hip): g_bias[c] = fixed-order sum over p of partials[p][c]
 int bias_partials_reduce_impl(const float* partials, int nparts, int C, float* g_bias, hipStream_t stream);
 
@@ -90,7 +91,7 @@ __host__ __device__ inline int dump_k(int r, int o, int R, int O, bool pairs) {
 }
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
                                 int o0 = 0, int i0 = 0, int Ifull = 0,
-                                float* gx_deferred = nullptr, bool factored = false);
+                                float* gx_deferred = nullptr, bool factored = false, const float* x_for_gx = nullptr);
 int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, const fc_dims* d, int records, int o0, int i0, int Ifull,
                            hipStream_t stream);
 int pack_filter_params_block_impl(const float* zonal, const float* sph, const float* phase, int ftype, float* wpk_fwd, float* wpk_bwd,

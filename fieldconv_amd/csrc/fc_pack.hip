@@ -355,11 +355,23 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
     float* __restrict__ g_sph, float* __restrict__ g_phase, const int O, const int I, const int R, const int B, const int po0,
     const int pi0, const int Ifull, const float* __restrict__ bias_partials, const int bias_nparts, float* __restrict__ g_bias,
     const int bias_block0, const f32x4* __restrict__ gx_parts, f32x4* __restrict__ gx, const size_t gx_count4, const size_t gx_stride4,
-    const int gx_nparts, const size_t gx_tail_floats, const int gx_block0, const int dbg) {
+    const int gx_nparts, const size_t gx_tail_floats, const int gx_block0, const float2* __restrict__ gx_x, const int dbg) {
     // (po0, pi0, Ifull: the filter is the block [po0, po0 + O) x [pi0, pi0 + I) of parameter tensors with Ifull input channels)
     __shared__ float2 part[kRpGroups][kRpPairs * 8 * 7];     // [group][(r*F + f)*16 + pair]
     __shared__ float2 gws[kRpPairs * 8 * 7];                 // [pair][r][f]
     __shared__ float gph[kRpPairs * 8 * (kMaxB + 1)];        // [pair][r][q]
+    if ((int)blockIdx.x >= gx_block0 && gx_nparts < 0) {
+        // second rider, H-streaming arrangement (fc_backward_stream.hpp): gx from the F gxt slices the streaming kernel left and x --
+        // fc_backward_gx_kernel's arithmetic; gx_parts: the slices, gx_count4: complex numbers per slice, -gx_nparts: the band limit
+        const size_t idx = (size_t)((int)blockIdx.x - gx_block0) * kRpThreads + threadIdx.x;
+        if (idx >= gx_count4) return;
+        const float2* gxt = reinterpret_cast<const float2*>(gx_parts);
+        float2* out = reinterpret_cast<float2*>(gx);
+        const float2 xv = gx_x[idx];
+        out[idx] = gx_nparts == -1 ? gx_from_slices<1>(xv, gxt, idx, gx_count4)
+                 : gx_nparts == -2 ? gx_from_slices<2>(xv, gxt, idx, gx_count4) : gx_from_slices<3>(xv, gxt, idx, gx_count4);
+        return;
+    }
     if ((int)blockIdx.x >= gx_block0) {
         // second rider: gx = the sum of the backward data kernel's partial arrays in part order (fc_sum_parts_kernel's arithmetic)
         const size_t idx = (size_t)((int)blockIdx.x - gx_block0) * kRpThreads + threadIdx.x;
@@ -459,7 +471,8 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
 int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, size_t so, bool ring_pairs, int P, float* gw_eff,
                             const float* zonal, const float* sph, const float* phase, int ftype, float* g_zonal, float* g_sph,
                             float* g_phase, const fc_dims* d, hipStream_t stream, int o0, int i0, int Ifull, const float* bias_partials,
-                            int bias_nparts, float* g_bias, const float* gx_parts, float* gx, size_t gx_count, size_t gx_stride, int gx_nparts) {
+                            int bias_nparts, float* g_bias, const float* gx_parts, float* gx, size_t gx_count, size_t gx_stride, int gx_nparts,
+                            const float* gx_x) {
     if (d->R > 8 || d->B > kMaxB || kRpPairs * d->R > kRpThreads) return FC_ERR_UNSUPPORTED;
     const int nit = (d->I + kRpPairs - 1) / kRpPairs;
     const RpStrides st{sp, sr, sf, so, ring_pairs ? 1 : 0};
@@ -467,13 +480,14 @@ int reduce_param_grads_impl(const float* gwp, size_t sp, size_t sr, size_t sf, s
     static const int dbg = [] { const char* e = dev_env("FC_DEBUG_RP"); return e ? atoi(e) : 0; }();      // development: 1 no partial loads, 2 no parameter chain
     const int bias_blocks = (bias_partials && bias_nparts > 0 && g_bias) ? (d->O + kRpThreads / 64 - 1) / (kRpThreads / 64) : 0;
     const bool sum_gx = gx_parts && gx && gx_nparts > 1;
-    const size_t gx_floats = gx_count * 2, gx_count4 = sum_gx ? (gx_floats + 3) / 4 : 0;
+    const bool from_slices = gx_parts && gx && gx_x && gx_nparts < 0;      // (gx_nparts = -band limit: gx from the gxt slices, one complex number per thread)
+    const size_t gx_floats = gx_count * 2, gx_count4 = from_slices ? gx_count : sum_gx ? (gx_floats + 3) / 4 : 0;
     const int gx_blocks = (int)((gx_count4 + kRpThreads - 1) / kRpThreads);
     hipLaunchKernelGGL(fc_reduce_param_grads_kernel, dim3(main_blocks + bias_blocks + gx_blocks), dim3(kRpThreads), 0, stream,
                        reinterpret_cast<const float2*>(gwp), st, P, reinterpret_cast<float2*>(gw_eff), zonal, sph, phase, ftype, g_zonal, g_sph,
                        g_phase, d->O, d->I, d->R, d->B, o0, i0, Ifull > 0 ? Ifull : d->I, bias_partials, bias_nparts, g_bias, main_blocks,
                        reinterpret_cast<const f32x4*>(gx_parts), reinterpret_cast<f32x4*>(gx), gx_count4, gx_stride / 2, gx_nparts,
-                       gx_floats % 4, main_blocks + bias_blocks, dbg);
+                       gx_floats % 4, main_blocks + bias_blocks, reinterpret_cast<const float2*>(gx_x), dbg);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 

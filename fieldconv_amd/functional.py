@@ -331,6 +331,17 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
         check(lib.fc_backward_all(_p(x), _p(gy), _p(sten), plan.cref_s, plan.records, _p(wpk_b), _p(gx), gwp,
                                   ctypes.byref(fp) if fp is not None else None, wsp, nbytes, plan.dref, st), 'fc_backward_all')
         return gx, gw, pgrads
+    if kernel_timer.enabled and graph.on_gx is None and graph.factored and lib.fc_backward_streams(plan.dref, plan.records):
+        # the H-streaming arrangement's two halves bracketed apart (the per-kernel timing pass of bench.py): gather | stream + gx
+        with _timed('fc_backward_data'):
+            check(lib.fc_backward_gather(_p(gy), _p(sten), plan.cref_s, wsp, nbytes, plan.dref, st), 'fc_backward_gather')
+        with _timed('fc_backward_filter'):
+            check(lib.fc_backward_stream(_p(x), _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_stream')
+        if fp is not None:
+            check(lib.fc_backward_finish_params(gwp, wsp, nbytes, plan.dref, plan.records, ctypes.byref(fp), st), 'fc_backward_finish_params')
+        else:
+            check(lib.fc_backward_finish(_p(gw), wsp, nbytes, plan.dref, plan.records, st), 'fc_backward_finish')
+        return gx, gw, pgrads
     with _timed('fc_backward_data'):
         if graph.factored:
             check(lib.fc_backward_data_factored(_p(x), _p(gy), _p(sten), plan.cref_s, _p(wpk_b), _p(gx), wsp, nbytes, plan.dref,

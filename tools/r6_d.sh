@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r6e
-o=gpurun_out/r6e
+mkdir -p gpurun_out/r6h
+o=gpurun_out/r6h
 timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "config2 or whole_tensors or small_cotangent" > $o/pytest.log 2>&1
 echo "pytest rc=$?" >> $o/pytest.log
 WHICH=b timeout 300 python tools/time_kernels.py geo > $o/t_prod.log 2>&1
