@@ -169,6 +169,29 @@ def other_mode(args, env_extra, what, y, gx):
         return {'value': None, 'note': f'failed: {type(exc).__name__}: {exc}'}
 
 
+def mode_leg(mode, keep):
+    """`python bench.py --mode <mode>` (25 steps after 5, with its own bounded CPU baseline) in a child process -> the compact form of
+    its line: value, ms per step (literal and settled), dominant-kernel roofline fraction, CPU baseline, and the extras named in `keep`."""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), '--mode', mode, '--steps', '25', '--warmup', '5']
+        env = {k_: v for k_, v in os.environ.items() if not k_.startswith('FC_')}
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        roof = line.get('roofline') or {}
+        leg = {'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'],
+               'settled_ms_per_step': (line.get('settled') or {}).get('ms_per_step'),
+               'workload': (line.get('config') or {}).get('workload'),
+               'roofline': {k_: roof.get(k_) for k_ in ('kernel', 'frac', 'achieved', 'unit', 'avg_launch_ms')} if roof else None,
+               'cpu_baseline': line.get('cpu_baseline')}
+        for k_ in keep:
+            if k_ in line:
+                v = line[k_]
+                leg[k_] = {kk: v[kk] for kk in ('ms_per_step', 'value', 'block_level_calls', 'per_operator_calls') if kk in v} if isinstance(v, dict) else v
+        return leg
+    except Exception as exc:           # noqa: BLE001  (an extra: never the reason for a failed bench)
+        return {'value': None, 'note': f'failed: {type(exc).__name__}: {exc}'[:300]}
+
+
 def committed_counters(kernel_names):
     """Counter-derived figures cannot be taken inside the timed run (rocprofv3 serialises the kernels); they come from
     the committed rocprof passes of the same command, stamped with the digest of the sources the library was built
@@ -1043,6 +1066,10 @@ def run_layer(args, world, rank, dev, use_dist, backend):
             out['reduced_precision'] = other_mode(args, {'FC_MFMA': 'f16'}, 'single f16 halves with per-row power-of-two scales, fp32 '
                                                   'accumulation (FC_MFMA=f16): the bf16-class leg of SURVEY 8(d) -- the MFMA rate of bf16, '
                                                   'three more mantissa bits, the scales make up for the range', y_def, gx_def)
+        # configs[2] and configs[4] of BASELINE.json, compact: the lines `--mode net` / `--mode dp` print, each from a child process of
+        # its own behind everything that is timed here (segmentation.ipynb:165-236 / correspondence.ipynb Net; one rank)
+        out['config3_segmentation_net'] = mode_leg('net', ('eager_over_replay', 'graph_replay', 'new_mesh_every_step', 'host_enqueue_ms_per_step'))
+        out['config5_correspondence_net_one_rank'] = mode_leg('dp', ())
         if args.support == 'p95':
             try:
                 other, _ = child_run(args, {}, extra_args=['--support', 'all'], dump=False)

@@ -7,3 +7,4 @@ __version__ = '0.1.0'
 
 from . import nn, transforms, utils  # noqa: F401,E402
 from . import optim  # noqa: F401,E402
+from ._lib import arithmetic  # noqa: F401,E402   (`with fieldconv_amd.arithmetic('f32'):` -- arithmetic mode of the convolutions launched inside)

@@ -8,7 +8,7 @@ benchmark the default), and (b) tests/test_host_logic.py can check that no switc
 import os
 
 SWITCHES = {
-    # ---- read by the binding and handed to the library explicitly (fc_set_mfma_mode)
+    # ---- read by the binding and put into the dims of every call it makes (fc_dims::mode; fieldconv_amd.arithmetic(...) overrides it per block)
     'FC_MFMA': 'f32: fp32-MFMA contractions throughout; f16: single halves (reduced precision); default: split halves',
     # ---- read by libfieldconv_hip_dev.so ONLY (the product library reads no variable; fieldconv_amd/_lib.py loads the development build
     #      when one of these is set): once per process
@@ -52,6 +52,7 @@ SWITCHES = {
 
 # read by the test suite only (tests/test_gpu_parity.py); known names, so that a shell that still has them set can run bench.py
 TEST_SWITCHES = {
+    'FC_FULL_MODES': '1: tests/test_gpu_modes.py sweeps every development switch instead of the eight kernel-family / arithmetic modes',
     'FC_FUZZ_SHAPES': 'number of shapes in the seeded sweep against the oracle (default 40)',
     'FC_FUZZ_SEED': 'seed of that sweep',
     'FC_FUZZ_WIDE': '1: the sweep also draws layers wider than 64 channels and (n_rings, band_limit) pairs outside the compiled set',

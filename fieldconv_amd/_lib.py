@@ -14,7 +14,12 @@ _sz = ctypes.c_size_t
 
 
 class FcDims(ctypes.Structure):
-    _fields_ = [('N', _c_int32), ('E', _c_int32), ('I', _c_int32), ('O', _c_int32), ('R', _c_int32), ('B', _c_int32)]
+    """fc_dims.  `mode` (fc_mfma_mode: the arithmetic of the contractions) travels with every call; left out, it is the binding's
+    current mode (current_mode(): FC_MFMA of the environment, or the innermost `arithmetic(...)` block)."""
+    _fields_ = [('N', _c_int32), ('E', _c_int32), ('I', _c_int32), ('O', _c_int32), ('R', _c_int32), ('B', _c_int32), ('mode', _c_int32)]
+
+    def __init__(self, N=0, E=0, I=0, O=0, R=0, B=0, mode=None):
+        super().__init__(N, E, I, O, R, B, current_mode() if mode is None else mode)
 
 
 class FcCsr(ctypes.Structure):
@@ -36,7 +41,10 @@ class FcEpilogue(ctypes.Structure):
 class FcMesh(ctypes.Structure):
     """fc_mesh: one mesh's support graph as the block-level entry points take it"""
     _fields_ = [('N', _c_int32), ('E', _c_int32), ('R', _c_int32), ('B', _c_int32), ('kind', _c_int32),
-                ('by_target', ctypes.POINTER(FcCsr)), ('by_source', ctypes.POINTER(FcCsr)), ('fwd', _vp), ('bwd', _vp)]
+                ('by_target', ctypes.POINTER(FcCsr)), ('by_source', ctypes.POINTER(FcCsr)), ('fwd', _vp), ('bwd', _vp), ('mode', _c_int32)]
+
+    def __init__(self, N=0, E=0, R=0, B=0, kind=0, by_target=None, by_source=None, fwd=None, bwd=None, mode=None):
+        super().__init__(N, E, R, B, kind, by_target, by_source, fwd, bwd, current_mode() if mode is None else mode)
 
 
 class FcResnetBlockParams(ctypes.Structure):
@@ -73,7 +81,6 @@ _FP = ctypes.POINTER(FcFilterParams)
 # name -> (restype, argtypes); must list every symbol declared in include/fieldconv_hip.h
 SIGNATURES = {
     'fc_abi_version': (ctypes.c_int, []),
-    'fc_set_mfma_mode': (ctypes.c_int, [_c_int32]),
     'fc_dev_switches': (ctypes.c_int, []),
     'fc_debug_stamp_buffer': (None, [_vp]),
     'fc_status_string': (ctypes.c_char_p, [ctypes.c_int]),
@@ -171,7 +178,42 @@ class FieldConvNativeError(RuntimeError):
     pass
 
 
-MFMA_MODES = {'': 0, 'split': 0, 'f32': 1, 'f16': 2}       # FC_MFMA -> fc_mfma_mode
+MFMA_MODES = {'': 0, 'split': 0, 'f32': 1, 'f16': 2}       # FC_MFMA / arithmetic(...) -> fc_mfma_mode
+
+import threading as _threading
+
+_MODE = _threading.local()
+
+
+def current_mode():
+    """fc_mfma_mode the binding puts into the dims of the calls it makes now: the innermost `arithmetic(...)` block of this thread, else
+    FC_MFMA of the environment (default: split halves).  The library itself keeps no mode and reads no variable."""
+    stack = getattr(_MODE, 'stack', None)
+    if stack:
+        return stack[-1]
+    mode = os.environ.get('FC_MFMA', '')
+    if mode not in MFMA_MODES:
+        raise FieldConvNativeError(f"FC_MFMA={mode!r}: expected one of 'split' (default), 'f32', 'f16'")
+    return MFMA_MODES[mode]
+
+
+class arithmetic:
+    """`with fieldconv_amd.arithmetic('f32'):` -- the convolutions launched inside run in that arithmetic mode ('split', 'f32',
+    'f16'); a forward pass and its backward pass must run in the same one (the packed filter images follow the mode)."""
+
+    def __init__(self, mode):
+        if mode not in MFMA_MODES:
+            raise FieldConvNativeError(f"arithmetic({mode!r}): expected one of 'split', 'f32', 'f16'")
+        self.mode = MFMA_MODES[mode]
+
+    def __enter__(self):
+        if not hasattr(_MODE, 'stack'):
+            _MODE.stack = []
+        _MODE.stack.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _MODE.stack.pop()
 
 
 def _pick_library():
@@ -199,8 +241,8 @@ def _pick_library():
 
 
 def load(path=None):
-    """dlopen the library and bind every entry point; raises if it is not built.  The arithmetic mode is passed on explicitly
-    (FC_MFMA -> fc_set_mfma_mode): the library itself reads no environment variable."""
+    """dlopen the library and bind every entry point; raises if it is not built.  The arithmetic mode travels in the dims of every
+    call (FcDims.mode, current_mode()): the library itself keeps no mode and reads no environment variable."""
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
@@ -214,11 +256,7 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    mode = os.environ.get('FC_MFMA', '')
-    if mode not in MFMA_MODES:
-        raise FieldConvNativeError(f"FC_MFMA={mode!r}: expected one of 'split' (default), 'f32', 'f16'")
-    if lib.fc_set_mfma_mode(MFMA_MODES[mode]) != 0:
-        raise FieldConvNativeError('fc_set_mfma_mode failed')
+    current_mode()          # (a bad FC_MFMA fails here, not at the first convolution)
     _LIB = lib
     return lib
 

@@ -72,7 +72,7 @@ def _graph_ref(nodes, graph, B):
             kind, fwd, bwd = 0, graph.sten_t, graph.sten_s
         opt = lambda t: t if t is not None else empty
         ref = graph._plans[key] = nodes.GraphRef([graph.rowptr_t, opt(graph.nbr_t), opt(graph.runs_t), graph.rowptr_s, opt(graph.nbr_s),
-                                                  opt(graph.runs_s), opt(fwd), opt(bwd)], graph.N, graph.E, graph.R, int(B), kind)
+                                                  opt(graph.runs_s), opt(fwd), opt(bwd)], graph.N, graph.E, graph.R, int(B), kind | (_lib.current_mode() << 8))
     return ref
 
 

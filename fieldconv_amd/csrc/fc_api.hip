@@ -15,7 +15,7 @@ bool shape_compiled(int R, int B) {
 }
 
 static bool dims_valid(const fc_dims* d) {
-    return d && d->N > 0 && d->E >= 0 && d->I > 0 && d->O > 0 && d->R > 0 && d->B >= 0;
+    return d && d->N > 0 && d->E >= 0 && d->I > 0 && d->O > 0 && d->R > 0 && d->B >= 0 && d->mode >= FC_MFMA_SPLIT_F16 && d->mode <= FC_MFMA_F16;
 }
 
 static bool dims_supported(const fc_dims* d) {
@@ -43,15 +43,9 @@ extern "C" {
 
 void fc_debug_stamp_buffer(void* device_buffer) { fc::g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
-int fc_abi_version(void) { return 10; }
+int fc_abi_version(void) { return 11; }
 
 int fc_dev_switches(void) { return fc::kDevSwitches ? 1 : 0; }
-
-int fc_set_mfma_mode(int32_t mode) {
-    if (mode < FC_MFMA_SPLIT_F16 || mode > FC_MFMA_F16) return FC_ERR_BAD_ARGUMENT;
-    fc::set_split_mode(mode == FC_MFMA_F32 ? 0 : mode == FC_MFMA_F16 ? 1 : 2);
-    return FC_OK;
-}
 
 const char* fc_status_string(int s) {
     switch (s) {

@@ -632,7 +632,7 @@ static int launch_stream(const float2* x, const char* hrec, const float* wpk, fl
 // kernel (fc_backward_all with module parameters: the finishing launch forms gx)
 int backward_stream_impl(const float* x, const float* gy, const float* rec, const fc_csr* g, const float* wpk, float* gx, void* ws,
                          size_t ws_bytes, const fc_dims* d, hipStream_t stream, int stages) {
-    const StreamPlan p = plan_stream(d, split_mode(), true);
+    const StreamPlan p = plan_stream(d, halves_of(d), true);
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hrec_bytes + p.gwp_bytes + p.gxt_bytes) return FC_ERR_WORKSPACE;
     const StreamArgs a = make_stream_args(d, p);
@@ -665,14 +665,14 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
-bool backward_streams(const fc_dims* d, bool factored) { return plan_stream(d, split_mode(), factored).ok; }
+bool backward_streams(const fc_dims* d, bool factored) { return plan_stream(d, halves_of(d), factored).ok; }
 
-bool backward_fits(const fc_dims* d) { return plan_backward(d, split_mode()).ok_factored; }
+bool backward_fits(const fc_dims* d) { return plan_backward(d, halves_of(d)).ok_factored; }
 
 size_t backward_workspace_bytes(const fc_dims* d) {
-    const BwdPlan p = plan_backward(d, split_mode());
+    const BwdPlan p = plan_backward(d, halves_of(d));
     const size_t pair = p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;
-    const StreamPlan sp = plan_stream(d, split_mode(), true);          // (records or not is the launch's choice: room for either)
+    const StreamPlan sp = plan_stream(d, halves_of(d), true);          // (records or not is the launch's choice: room for either)
     const size_t stream = sp.ok ? sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes + 256 : 0;
     return pair > stream ? pair : stream;
 }
@@ -708,7 +708,7 @@ static int launch_backward_filter(const float2* x, const float* hdump, float2* g
 
 int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored) {
     if (backward_streams(d, factored)) return FC_OK;        // (the streaming kernel behind the gather has left the partials already)
-    const BwdPlan p = plan_backward(d, split_mode());
+    const BwdPlan p = plan_backward(d, halves_of(d));
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const BwdArgs a = make_args(d, p);
@@ -730,7 +730,7 @@ int backward_filter_impl(const float* x, void* ws, size_t ws_bytes, const fc_dim
 // Which kernels a backward pass with these dims launches (fc_describe_kernels).
 void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
     {
-        const StreamPlan sp = plan_stream(d, split_mode(), records != 0);
+        const StreamPlan sp = plan_stream(d, halves_of(d), records != 0);
         if (sp.ok) {
             snprintf(buf, n, "fc_backward_gather_kernel<records,split-f16> tiles=%d; fc_backward_stream_kernel (H once for gxt and gW: %d gxt + %d gW "
                      "wavefronts, W_f in registers, records by LDS-DMA) grid=%dx%d; fc_backward_gx_kernel; module parameters: "
@@ -739,8 +739,8 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
             return;
         }
     }
-    const BwdPlan p = plan_backward(d, split_mode());
-    const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
+    const BwdPlan p = plan_backward(d, halves_of(d));
+    const char* mode = halves_of(d) == 2 ? "split-f16" : halves_of(d) == 1 ? "f16" : "f32";
     static const bool staged = [] { const char* e = dev_env("FC_FILTER2"); return e && atoi(e) == 0; }();
     static const bool split_finish = [] { const char* e = dev_env("FC_SPLIT_FINISH"); return e && atoi(e) != 0; }();
     // what ends the pass follows the same switches the launches use (fc_api.hip: fc_backward_all / fc_backward_finish_params)
@@ -763,7 +763,7 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
 // Fixed-order sum of the per-workgroup filter-gradient partials left in the workspace.
 int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, hipStream_t stream, bool factored) {
     {
-        const StreamPlan sp = plan_stream(d, split_mode(), factored);
+        const StreamPlan sp = plan_stream(d, halves_of(d), factored);
         if (sp.ok) {        // partials [P][F][k = o*R + r][IP]
             if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes) return FC_ERR_WORKSPACE;
             const float2* gwp = reinterpret_cast<const float2*>(static_cast<char*>(ws) + sp.hrec_bytes);
@@ -773,7 +773,7 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
             return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
         }
     }
-    const BwdPlan p = plan_backward(d, split_mode());
+    const BwdPlan p = plan_backward(d, halves_of(d));
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const float2* gwp = reinterpret_cast<const float2*>(static_cast<char*>(ws) + p.hdump_bytes);
@@ -786,7 +786,7 @@ int backward_finish_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims
 int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const fc_dims* d, const fc_filter_params* fp, hipStream_t stream,
                                 int o0, int i0, int Ifull, float* gx_deferred, bool factored, const float* x_for_gx) {
     {
-        const StreamPlan sp = plan_stream(d, split_mode(), factored);
+        const StreamPlan sp = plan_stream(d, halves_of(d), factored);
         if (sp.ok) {        // partial (p, f, k = o*R + r, i) at ((p*F + f)*KP + k)*IP + i
             if (!ws || ws_bytes < sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes) return FC_ERR_WORKSPACE;
             const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + sp.hrec_bytes);
@@ -799,7 +799,7 @@ int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const 
                                            ride ? gx_deferred : nullptr, (size_t)d->N * d->I, 0, ride ? -d->B : 0, ride ? x_for_gx : nullptr);
         }
     }
-    const BwdPlan p = plan_backward(d, split_mode());
+    const BwdPlan p = plan_backward(d, halves_of(d));
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes) return FC_ERR_WORKSPACE;
     const float* gwp = reinterpret_cast<const float*>(static_cast<char*>(ws) + p.hdump_bytes);
@@ -822,7 +822,7 @@ int backward_data_impl(const float* x, const float* gy, const float* sten, const
     // large meshes: gather kernel + the kernel that streams H once for gxt and gW + gx -- after this call gx is complete AND the
     // filter-gradient partials are in the workspace (backward_filter_impl has nothing left to do)
     if (backward_streams(d, factored)) return backward_stream_impl(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, stream, defer_gx_sum ? 7 : 3);
-    return split_mode() ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum)
+    return halves_of(d) ? backward_data_impl_mode<true>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum)
                         : backward_data_impl_mode<false>(x, gy, sten, g, wpk, gx, ws, ws_bytes, d, factored, stream, defer_gx_sum);
 }
 

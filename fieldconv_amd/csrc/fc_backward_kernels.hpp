@@ -628,7 +628,7 @@ static int launch_backward_data(const float2* x, const float2* gy, const float* 
 template <bool SPLIT>
 int backward_data_impl_mode(const float* x, const float* gy, const float* sten, const fc_csr* g, const float* wpk, float* gx,
                             void* ws, size_t ws_bytes, const fc_dims* d, bool factored, hipStream_t stream, bool defer_gx_sum) {
-    const BwdPlan p = plan_backward(d, SPLIT ? split_mode() : 0);
+    const BwdPlan p = plan_backward(d, SPLIT ? halves_of(d) : 0);
     if (!(factored ? p.ok_factored : p.ok)) return FC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < p.hdump_bytes + p.gwp_bytes + p.gxp_bytes) return FC_ERR_WORKSPACE;
     const BwdArgs a = make_args(d, p);

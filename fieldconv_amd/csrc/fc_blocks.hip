@@ -33,7 +33,7 @@ static bool mesh_valid(const fc_mesh* m, bool need_records) {
     return true;
 }
 
-static fc_dims conv_dims(const fc_mesh* m, int I, int O) { return fc_dims{m->N, m->E, I, O, m->R, m->B}; }
+static fc_dims conv_dims(const fc_mesh* m, int I, int O) { return fc_dims{m->N, m->E, I, O, m->R, m->B, m->mode}; }
 
 // ---- FCResNetBlock ----------------------------------------------------------------------------------------------------------
 struct ResnetPlan {

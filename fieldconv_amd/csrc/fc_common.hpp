@@ -19,7 +19,7 @@ namespace fc {
 // Development switches (the FC_* variables of fieldconv_amd/_env.py: older kernel families for A/B runs, phase skipping, stamps) exist
 // only in a library compiled with -DFC_DEV_SWITCHES (fieldconv_amd.build.build_dev: libfieldconv_hip_dev.so).  The product library never
 // reads the environment -- a stray variable in a C-ABI consumer's process cannot change which kernels run -- and dev_env() folds to
-// "not set", so every switch takes its default at compile time.  The arithmetic mode (FC_MFMA) is an explicit call: fc_set_mfma_mode.
+// "not set", so every switch takes its default at compile time.  The arithmetic mode travels in the dims of every call (fc_dims::mode).
 #ifdef FC_DEV_SWITCHES
 inline const char* dev_env(const char* name) { return getenv(name); }
 constexpr bool kDevSwitches = true;

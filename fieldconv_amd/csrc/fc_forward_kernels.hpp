@@ -529,7 +529,7 @@ int forward_impl_mode(const float* x, const float* sten, const fc_csr* g, const 
     const bool factored = kind != 0;
     FwdArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;
-    a.g = make_mma_geom(d->O, d->R, d->I, SPLIT ? split_mode() : 0);
+    a.g = make_mma_geom(d->O, d->R, d->I, SPLIT ? halves_of(d) : 0);
     a.ntiles = (d->N + kTile - 1) / kTile;
     // without a workspace the tiles are not split (same result, fewer workgroups)
     a.parts_log2 = (ws && ws_bytes >= forward_workspace_bytes_impl(d, kind)) ? forward_parts_log2(d, kind) : 0;

@@ -8,9 +8,9 @@ namespace fc {
 // The record-driven forward pass runs the ring-major kernels (two 8-wavefront workgroups per CU) in the default
 // two-halves mode; FC_RING=0 keeps the frequency-major ones (one 16-wavefront workgroup per CU; also what FC_MFMA=f32 / f16
 // run).  Read once per process.  Config 2 on MI355X: 138 us against 150 us.
-bool ring_enabled() {
+bool ring_enabled(const fc_dims* d) {
     static const bool on = [] { const char* e = dev_env("FC_RING"); return !(e && atoi(e) == 0); }();
-    return on && split_mode() == 2;
+    return on && halves_of(d) == 2;
 }
 
 // Meshes of up to 256 tiles (4096 vertices) are one round of the frequency-major kernels (one 16-vertex tile per CU, with
@@ -20,16 +20,16 @@ bool ring_enabled() {
 // ring-major kernels for any size (tests).
 bool forward_ring_fits(const fc_dims* d) {
     static const bool force = [] { const char* e = dev_env("FC_RING"); return e && atoi(e) == 2; }();
-    if (!ring_enabled() || !plan_ring(d->O, 2 * d->B + 1, d->I, split_mode()).ok) return false;
+    if (!ring_enabled(d) || !plan_ring(d->O, 2 * d->B + 1, d->I, halves_of(d)).ok) return false;
     return force || (d->N + kTile - 1) / kTile > num_cus();
 }
 
 // Which kernel a forward launch with these dims takes (fc_describe_kernels); kind as in forward_impl.
 void describe_forward(const fc_dims* d, int kind, char* buf, size_t n) {
-    const char* mode = split_mode() == 2 ? "split-f16" : split_mode() == 1 ? "f16" : "f32";
+    const char* mode = halves_of(d) == 2 ? "split-f16" : halves_of(d) == 1 ? "f16" : "f32";
     const char* rec = kind == 2 ? "geometric records" : kind == 1 ? "factored records" : "dense rows";
     if (kind != 0 && forward_ring_fits(d)) {
-        const RingPlan p = plan_ring(d->O, 2 * d->B + 1, d->I, split_mode());
+        const RingPlan p = plan_ring(d->O, 2 * d->B + 1, d->I, halves_of(d));
         snprintf(buf, n, "fc_forward_ring_kernel<%s,%s> (ring-major, 2 workgroups x 8 wavefronts per CU, %zu B LDS, %d %s record chunks%s)",
                  rec, mode, p.lds, p.nr, p.logh ? "half-size" : "1 KiB", p.alias ? ", partials aliased onto the slab" : "");
     } else {
@@ -56,7 +56,7 @@ static int launch_forward_ring(const float2* x, const float* rec, const fc_csr* 
 int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,
                       void* ws, size_t ws_bytes, const fc_epilogue* epi, hipStream_t stream) {
     const int F = 2 * d->B + 1;
-    const RingPlan p = plan_ring(d->O, F, d->I, split_mode());
+    const RingPlan p = plan_ring(d->O, F, d->I, halves_of(d));
     if (!p.ok) return FC_ERR_UNSUPPORTED;
     RingArgs a;
     a.N = d->N; a.I = d->I; a.O = d->O;

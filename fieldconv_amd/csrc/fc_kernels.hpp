@@ -58,7 +58,7 @@ size_t packed_filter_floats_fwd(const fc_dims* d, int records);
 size_t packed_filter_floats_bwd(const fc_dims* d, int records);
 
 // ring-major record kernels (fc_forward_ring.hpp)
-bool ring_enabled();
+bool ring_enabled(const fc_dims* d);
 bool forward_ring_fits(const fc_dims* d);
 size_t packed_ring_image_floats(int M, int F, int channels, int R, int halves);
 int forward_ring_impl(const float* x, const float* rec, const fc_csr* g, const float* wpk, float* y, const fc_dims* d, int kind,

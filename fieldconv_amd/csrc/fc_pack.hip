@@ -198,12 +198,12 @@ static unsigned pack_blocks(const MmaGeom& g, int F) {      // F: slabs of plane
 static bool ring_forward_image(const fc_dims* d, int records) { return (records & 1) && forward_ring_fits(d); }
 
 size_t packed_filter_floats_fwd(const fc_dims* d, int records) {
-    if (ring_forward_image(d, records)) return packed_ring_image_floats(d->O, 2 * d->B + 1, d->I, d->R, split_mode());
-    return packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, split_mode());
+    if (ring_forward_image(d, records)) return packed_ring_image_floats(d->O, 2 * d->B + 1, d->I, d->R, halves_of(d));
+    return packed_image_floats(d->O, d->R, d->I, 2 * d->B + 1, halves_of(d));
 }
 size_t packed_filter_floats_bwd(const fc_dims* d, int records) {
     (void)records;
-    return packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, split_mode());
+    return packed_image_floats(d->I, d->R, d->O, 2 * d->B + 1, halves_of(d));
 }
 
 // -> workgroups of the launch (0: nothing to write)
@@ -211,8 +211,8 @@ static unsigned pack_args(PackArgs& a, int ftype, bool want_fwd, bool want_bwd, 
     a.O = d->O; a.I = d->I; a.R = d->R; a.B = d->B; a.F = 2 * d->B + 1; a.ftype = ftype;
     a.o0 = o0; a.i0 = i0; a.Ifull = Ifull > 0 ? Ifull : d->I;
     a.ring_f = ring_forward_image(d, records & 1) ? 1 : 0;
-    a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, split_mode()) : make_mma_geom(d->O, d->R, d->I, split_mode());
-    a.gb = make_mma_geom(d->I, d->R, d->O, split_mode());
+    a.gf = a.ring_f ? ring_geom(d->O, a.F, d->I, halves_of(d)) : make_mma_geom(d->O, d->R, d->I, halves_of(d));
+    a.gb = make_mma_geom(d->I, d->R, d->O, halves_of(d));
     a.blocks_f = want_fwd ? pack_blocks(a.gf, a.ring_f ? a.R : a.F) : 0u;                // no forward image wanted: backward image only
     const unsigned blocks_b = pack_blocks(a.gb, a.F);
     return a.blocks_f + (want_bwd ? blocks_b : 0u);                                       // no backward image wanted: forward image only
@@ -259,11 +259,6 @@ int pack_filter_block_impl(const float* w_eff, float* wpk_fwd, float* wpk_bwd, c
     return launch_pack<false>(w_eff, nullptr, nullptr, nullptr, 0, wpk_fwd, wpk_bwd, d, records, stream, o0, i0, Ifull);
 }
 
-// Arithmetic mode of the contractions: 2 = split halves (default, fp32-grade), 0 = fp32 MFMA, 1 = single f16 halves (reduced
-// precision).  Process-wide and EXPLICIT (fc_set_mfma_mode); the library does not read FC_MFMA from the environment.
-static int g_split_mode = 2;
-int split_mode() { return g_split_mode; }
-void set_split_mode(int mode) { g_split_mode = mode; }
 
 // One thread per (o, i, r): reads gW_eff[o,i,r,:] (F complex) and writes the parameter gradients of
 // its ring; the phase gradient sums over the rings of (o,i) through LDS in a fixed order.

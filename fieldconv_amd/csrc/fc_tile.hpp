@@ -60,10 +60,9 @@ __host__ __device__ inline size_t packed_image_floats(int M, int R, int channels
 // Floats of one LDS slab buffer (16 vertices).
 __host__ __device__ inline int slab_floats(const MmaGeom& g) { return g.split ? kTile * g.KS / 2 : 2 * kTile * g.KS; }
 
-// Halves per operand the library runs with: 2 (split mode, default), 0 with FC_MFMA=f32 (fp32 MFMA),
-// 1 with FC_MFMA=f16 (reduced precision).
-int split_mode();
-void set_split_mode(int mode);
+// Halves per operand of a launch: 2 (split mode, the default: fc_dims::mode = FC_MFMA_SPLIT_F16), 0 (FC_MFMA_F32: fp32 MFMA),
+// 1 (FC_MFMA_F16: reduced precision).  The mode travels with every call in its dims: the library keeps no arithmetic state.
+inline int halves_of(const fc_dims* d) { return d->mode == FC_MFMA_F32 ? 0 : d->mode == FC_MFMA_F16 ? 1 : 2; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

@@ -73,7 +73,7 @@ float* fpm(const at::Tensor& t) { return t.defined() && t.numel() ? static_cast<
 // Built once per (graph, band limit) by the Python side and handed to every node of that mesh.
 struct GraphRef {
     std::vector<at::Tensor> t;          // rowptr_t, nbr_t, runs_t, rowptr_s, nbr_s, runs_s, fwd records / rows, bwd records / rows
-    int64_t N, E, R, B, kind;
+    int64_t N, E, R, B, kind;          // kind: record kind | fc_mfma_mode << 8 (the arithmetic mode of the mesh's convolutions)
     GraphRef(std::vector<at::Tensor> tensors, int64_t n, int64_t e, int64_t r, int64_t b, int64_t k)
         : t(std::move(tensors)), N(n), E(e), R(r), B(b), kind(k) {
         TORCH_CHECK(t.size() == 8, "GraphRef takes 8 tensors");
@@ -82,7 +82,7 @@ struct GraphRef {
         auto ip = [](const at::Tensor& x) { return x.defined() && x.numel() ? static_cast<const int32_t*>(x.data_ptr()) : nullptr; };
         ct = fc_csr{ip(t[0]), ip(t[1]), ip(t[2])};
         cs = fc_csr{ip(t[3]), ip(t[4]), ip(t[5])};
-        m = fc_mesh{(int32_t)N, (int32_t)E, (int32_t)R, (int32_t)B, (int32_t)kind, &ct, &cs, fp(t[6]), fp(t[7])};
+        m = fc_mesh{(int32_t)N, (int32_t)E, (int32_t)R, (int32_t)B, (int32_t)(kind & 255), &ct, &cs, fp(t[6]), fp(t[7]), (int32_t)(kind >> 8)};
     }
 };
 
@@ -274,7 +274,7 @@ struct LiftBlockFn : public torch::autograd::Function<LiftBlockFn> {
         auto ip = [](const at::Tensor& x) { return x.defined() && x.numel() ? static_cast<const int32_t*>(x.data_ptr()) : nullptr; };
         ct = fc_csr{ip(csr[0]), ip(csr[1]), nullptr};
         cs = fc_csr{ip(csr[3]), ip(csr[4]), nullptr};
-        m = fc_mesh{(int32_t)N, (int32_t)E, (int32_t)R, 0, 0, &ct, &cs, nullptr, nullptr};
+        m = fc_mesh{(int32_t)N, (int32_t)E, (int32_t)R, 0, 0, &ct, &cs, nullptr, nullptr, 0};
     }
     static const int64_t* lp(const at::Tensor& t) { return t.defined() && t.numel() ? static_cast<const int64_t*>(t.data_ptr()) : nullptr; }
 

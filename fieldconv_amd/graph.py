@@ -315,8 +315,22 @@ def _shape_compiled(R, B):
 
 
 class SupportGraph:
+    # `_plans`: launch plans and sizes cached per user key -- one dictionary per arithmetic mode of the binding (the packed-image
+    # sizes, workspaces and kernel families of a plan follow fc_dims::mode), see the property below
     __slots__ = ('N', 'E', 'R', 'F', 'rowptr_t', 'nbr_t', 'sten_t', 'rowptr_s', 'nbr_s', 'sten_s', 'factored', 'rec_t',
-                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans', 'on_gx', 'forward_split', 'n_targets', '_is_view')
+                 'rec_s', 'runs_t', 'runs_s', 'geo_t', 'perm_t', 'perm_s', '_keep', '_plans_by_mode', 'on_gx', 'forward_split', 'n_targets', '_is_view')
+
+    @property
+    def _plans(self):
+        from . import _lib
+        return self._plans_by_mode.setdefault(_lib.current_mode(), {})
+
+    @_plans.setter
+    def _plans(self, value):
+        from . import _lib
+        if not hasattr(self, '_plans_by_mode') or not value:
+            self._plans_by_mode = {}
+        self._plans_by_mode[_lib.current_mode()] = value
 
     def __init__(self, supp_edges, supp_sten, N, allow_factored=True, native=None):
         if supp_edges.dim() != 2 or supp_edges.shape[1] != 2:
@@ -467,7 +481,8 @@ class SupportGraph:
         if int(self.rowptr_t[n]) != self.E:
             raise ValueError(f'vertices from {n} on still have in-edges')
         self.n_targets = n
-        self._plans = {k: v for k, v in self._plans.items() if not (isinstance(k[0], str) and k[0] == 'rows')}
+        for mode, plans in list(self._plans_by_mode.items()):
+            self._plans_by_mode[mode] = {k: v for k, v in plans.items() if not (isinstance(k[0], str) and k[0] == 'rows')}
         return self
 
     def _build_native(self, supp_edges, sten, allow_factored):

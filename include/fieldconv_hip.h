@@ -39,6 +39,9 @@ typedef struct fc_dims {
     int32_t O;   /* out_channels                               */
     int32_t R;   /* n_rings                                    */
     int32_t B;   /* band_limit; F = 2B+1 angular frequencies   */
+    int32_t mode; /* fc_mfma_mode: arithmetic of the contractions (0 = FC_MFMA_SPLIT_F16, the default) -- see below.  Part of the dims
+                   * of EVERY call: size queries, packing calls and launches of one convolution carry the same value; two convolutions
+                   * in one process may differ (the library keeps no arithmetic state) */
 } fc_dims;
 
 /* Edge list grouped by one endpoint (CSR).  Slot s in [rowptr[v], rowptr[v+1]) is one edge
@@ -54,14 +57,12 @@ typedef struct fc_csr {
 } fc_csr;
 
 int fc_abi_version(void);
-/* Arithmetic of the three contractions (forward, input gradient, filter gradient).  Process-wide, set EXPLICITLY -- the library reads no
- * environment variable: FC_MFMA_SPLIT_F16 (default) carries every operand as two f16 halves with power-of-two row scales on
- * v_mfma_f32_16x16x32_f16, fp32 accumulation (fp32-grade: 2^-22 of the row maximum); FC_MFMA_F32 runs v_mfma_f32_16x16x4_f32 on fp32
- * operands throughout; FC_MFMA_F16 drops the low halves (reduced precision, ~3e-4).  Packed filter images, workspaces and kernels all
- * follow the mode: set it before the first size query / packing call and do not change it between a packing call and the launches that use
- * its images. */
+/* Arithmetic of the three contractions (forward, input gradient, filter gradient), carried PER CALL in fc_dims::mode / fc_mesh::mode --
+ * no process-wide setter, no environment variable: FC_MFMA_SPLIT_F16 (default) carries every operand as two f16 halves with
+ * power-of-two row scales on v_mfma_f32_16x16x32_f16, fp32 accumulation (fp32-grade: 2^-22 of the row maximum); FC_MFMA_F32 runs
+ * v_mfma_f32_16x16x4_f32 on fp32 operands throughout; FC_MFMA_F16 drops the low halves (reduced precision, ~3e-4).  Packed filter
+ * images, workspaces and kernels all follow the mode: a packing call and the launches that use its images carry the same one. */
 typedef enum fc_mfma_mode { FC_MFMA_SPLIT_F16 = 0, FC_MFMA_F32 = 1, FC_MFMA_F16 = 2 } fc_mfma_mode;
-int fc_set_mfma_mode(int32_t mode);
 /* 1 when this library was compiled with -DFC_DEV_SWITCHES (libfieldconv_hip_dev.so: the FC_* development variables of
  * fieldconv_amd/_env.py select older kernel families, skip phases, write stamps); the product library returns 0 and reads no variable. */
 int fc_dev_switches(void);
@@ -90,7 +91,7 @@ int fc_describe_kernels(const fc_dims* dims, int32_t kind, char* buffer, size_t 
  *   OP inverse row scales (floats), then F x {re_hi, re_lo, im_hi, im_lo} x KP/32 k blocks x OP x 32 halves,
  *   forward rows o, k = r*ceil8(I) + i;  backward rows i, k = r*ceil8(O) + o, conjugated;
  *   OP = ceil16(rows), KP = ceil32(R * ceil8(channels)).
- * In FC_MFMA_F32 mode (fc_set_mfma_mode): F x {re,im} x OP x ceil16(R*channels) floats.
+ * In FC_MFMA_F32 mode (fc_dims::mode): F x {re,im} x OP x ceil16(R*channels) floats.
  * `records`: which family of convolution entry points the images are for -- 0: the dense-stencil ones (fc_forward,
  * fc_backward_data), 1: the record-driven ones (fc_forward_factored, fc_forward_geometric, fc_backward_data_factored).
  * In the default mode the record-driven forward image is RING-major: OP inverse row scales, then
@@ -377,6 +378,7 @@ typedef struct fc_mesh {           /* one mesh's support graph as the convolutio
     const fc_csr* by_source;       /* as for fc_backward_data* */
     const float* fwd;              /* sten_t / rec_t / geo_t, by kind, in by_target slot order */
     const float* bwd;              /* sten_s (kind 0) or rec_s, in by_source slot order */
+    int32_t mode;                  /* fc_mfma_mode of the block's convolutions (0: the default) */
 } fc_mesh;
 
 /* FCResNetBlock: out = modReLU_2(res(x) + conv2(modReLU_1(conv1(x)))), reference nn/fc_resnet_block.py:84-88.

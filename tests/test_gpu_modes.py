@@ -24,6 +24,7 @@ MODES = {
     'dense_rows': {'FIELDCONV_DENSE': '1'},             # FCPrecomp stencils through the dense-stencil kernels
     'generic_records': {'FIELDCONV_NO_GEO': '1'},       # 64-byte factored records in the forward pass
     'lds_staged_filter_kernel': {'FC_FILTER2': '0'},
+    'data_filter_kernel_pair_on_large_meshes': {'FC_BWD_STREAM': '0'},   # the pair instead of the gather / stream / gx arrangement
     'torch_graph_build': {'FIELDCONV_TORCH_GRAPH': '1'},
     'no_edge_split': {'FIELDCONV_NO_EDGE_SPLIT': '1'},
     'eager_stencil': {'FIELDCONV_EAGER_STENCIL': '1'},   # FCPrecomp returns the dense (E,R,F) tensor; graph built from it
@@ -45,13 +46,23 @@ MODES = {
 
 
 def _clean_env(extra):
+    from fieldconv_amd._env import LIBRARY_SWITCHES
     env = {k: v for k, v in os.environ.items() if not (k.startswith('FC_') or k.startswith('FIELDCONV_'))}
     env.update(extra)
+    if any(k in LIBRARY_SWITCHES for k in extra):
+        env['FIELDCONV_DEV'] = '1'          # the library's switches exist in the development build only, and it is loaded on request only
     env.pop('PYTEST_CURRENT_TEST', None)
     return env
 
 
-@pytest.mark.parametrize('mode', sorted(MODES))
+# The default run covers the modes that select another kernel FAMILY or another arithmetic; FC_FULL_MODES=1 sweeps every switch (each
+# mode is a fresh child process of ~16 s: the full sweep is two thirds of the suite's time)
+DEFAULT_MODES = ('fp32_mfma', 'reduced_f16', 'dense_rows', 'generic_records', 'data_filter_kernel_pair_on_large_meshes',
+                 'frequency_major_forward', 'one_call_per_kernel', 'blocks_from_per_operator_nodes')
+SWEEP = sorted(MODES) if os.environ.get('FC_FULL_MODES') == '1' else sorted(DEFAULT_MODES)
+
+
+@pytest.mark.parametrize('mode', SWEEP)
 def test_parity_subset_in_mode(mode):
     cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'),
            os.path.join(ROOT, 'tests', 'test_gpu_fullsize.py'), '-m', 'gpu', '-x', '-q', '-p', 'no:cacheprovider', '-k', SUBSET]

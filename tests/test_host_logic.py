@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in fieldconv_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), 'ctypes binding out of sync with the header'
-    assert _lib.load(path).fc_abi_version() == 10
+    assert _lib.load(path).fc_abi_version() == 11
 
 
 def test_product_library_reads_no_environment_switch():

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-prof}
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
-# build first, from a process no profiler has touched (see tools/pmc_fwd.sh; bench.py refuses to build under rocprofv3)
+# build first, from a process no profiler has touched (bench.py refuses to build under rocprofv3)
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__; __graft_entry__.build()" || exit 1
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 10"
@@ -41,8 +41,8 @@ try:
         avg_ns[r['Name'].split('(')[0].replace('void ', '')] = float(r['AverageNs'])
 except Exception:
     pass
-names = {'fc_forward': ('fc_forward_factored_kernel', 'fc_forward_ring_kernel', 'fc_forward_kernel'), 'fc_backward_data': ('fc_backward_data_kernel',),
-         'fc_backward_filter': ('fc_backward_filter_half2_kernel', 'fc_backward_filter_half_kernel', 'fc_backward_filter_kernel')}
+names = {'fc_forward': ('fc_forward_factored_kernel', 'fc_forward_ring_kernel', 'fc_forward_kernel'), 'fc_backward_data': ('fc_backward_gather_kernel', 'fc_backward_data_kernel'),
+         'fc_backward_filter': ('fc_backward_stream_kernel', 'fc_backward_filter_half2_kernel', 'fc_backward_filter_half_kernel', 'fc_backward_filter_kernel')}
 res = {}
 for short, cands in names.items():
     for k, c in kern.items():
