@@ -1273,9 +1273,13 @@ def test_lift_block_reads_the_factor_table(dev, N, k, B, R):
         y = mod(x, edges, arg)
         out.append((y.detach(),) + torch.autograd.grad(y, [x] + params, grad_outputs=gy))
     assert lift_sten._dense is None and sten._dense is None             # nothing was materialised on the way
-    for n_, (a, b) in enumerate(zip(*out)):          # (float32 rounding of the on-the-fly columns against torch's; gradients through angle())
+    # (float32 rounding of the on-the-fly columns against torch's.  The gradients go through angle() and amplify it: 1.4e-5 ... 3.4e-5 over
+    #  repeated runs of the SAME case -- FCPrecomp's area sums use float atomics, as the reference's index_add does on a GPU
+    #  (csrc/fc_precomp.hip), so the stencil itself differs by an ulp from run to run and the amplified comparison moves with it;
+    #  tools/uninit_probe.py shows the spread and that no uninitialised memory is involved)
+    for n_, (a, b) in enumerate(zip(*out)):
         err = rel_err(H(a), H(b))
-        assert err < (5e-6 if n_ == 0 else 2e-5), (n_, err)
+        assert err < (5e-6 if n_ == 0 else 1e-4), (n_, err)
     # and the stand-in still behaves like the tensor when something else asks
     assert torch.equal(lift_sten[:5], sten.columns(0, 2)[:5]) and lift_sten.abs().shape == (edges.shape[0], R, 2)
 
@@ -1513,3 +1517,41 @@ def test_echo_head_limits_fall_back_to_the_dense_layers(dev):
             a = torch.where((x.real.abs() < 1e-7) & (x.imag.abs() < 1e-7), torch.zeros_like(x.real), x.abs())
             y_ref = torch.relu(torch.relu(d @ W[0].t() + W[1]) @ W[2].t() + W[3]) @ W[4].t() + W[5] + a @ W[6].t() + W[7]
             assert rel_err(H(y_node), H(y_ref)) < 2e-6
+
+
+@pytest.mark.parametrize('N,k', [(3000, 12), (9000, 8)])
+def test_two_arithmetic_modes_in_one_process(dev, N, k):
+    """The arithmetic mode travels in the dims of every call (fc_dims::mode, ABI 11): convolutions of one process run in different
+    modes side by side -- `with fieldconv_amd.arithmetic(...)` -- and the library keeps no state between them.  At 9 000 vertices
+    the default mode's backward pass is the gather / stream / gx arrangement while fp32 runs the data / filter kernel pair: the
+    two agree to fp32 rounding (and both with the oracle elsewhere)."""
+    if os.environ.get('FC_MFMA') not in (None, '', 'split'):
+        pytest.skip('compares the modes against the default one')
+    import fieldconv_amd
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import FieldConv
+    from fieldconv_amd.transforms import FCPrecomp
+    B, R, C = 2, 6, 48
+    data = sphere_support(N, k=k, seed=4, support='p95').to(dev)
+    edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
+    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
+    gen = torch.Generator().manual_seed(N)
+    x = torch.complex(torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen)).to(dev).requires_grad_(True)
+    gy = torch.complex(torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen)).to(dev)
+
+    def step():
+        y = conv(x, edges, sten)
+        return (y.detach(),) + torch.autograd.grad(y, [x] + list(conv.parameters()), grad_outputs=gy)
+
+    first = step()
+    with fieldconv_amd.arithmetic('f32'):
+        f32 = step()
+        with fieldconv_amd.arithmetic('f16'):
+            f16 = step()
+        f32_again = step()
+    again = step()
+    H = lambda t: t.detach().cpu().numpy()
+    for a, b, c, d, e in zip(first, f32, f16, f32_again, again):
+        assert torch.equal(a, e) and torch.equal(b, d)                   # nothing of a mode lingers in the library or the plan cache
+        assert rel_err(H(a), H(b)) < 1e-5                               # split halves = fp32 MFMA to fp32 rounding
+        assert 1e-7 < rel_err(H(c), H(b)) < 5e-3                        # the reduced-precision mode really ran (and is what it claims)
