@@ -174,6 +174,23 @@ SIGNATURES = {
 _LIB = None
 
 
+def keep_mode(fn_cls):
+    """Class decorator for the autograd Functions that launch convolutions: the backward pass runs in the arithmetic mode of ITS
+    forward pass -- the autograd engine calls it from its own thread, outside any `arithmetic(...)` block of the caller, and the
+    packed filter images a forward pass saves are only valid in the mode they were packed in."""
+    fwd, bwd = fn_cls.forward, fn_cls.backward
+
+    def forward(ctx, *args):
+        ctx.fc_mode = current_mode()
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with arithmetic(ctx.fc_mode):
+            return bwd(ctx, *grads)
+    fn_cls.forward, fn_cls.backward = staticmethod(forward), staticmethod(backward)
+    return fn_cls
+
+
 class FieldConvNativeError(RuntimeError):
     pass
 
@@ -202,6 +219,9 @@ class arithmetic:
     'f16'); a forward pass and its backward pass must run in the same one (the packed filter images follow the mode)."""
 
     def __init__(self, mode):
+        if isinstance(mode, int) and mode in MFMA_MODES.values():       # (an fc_mfma_mode code: keep_mode below)
+            self.mode = mode
+            return
         if mode not in MFMA_MODES:
             raise FieldConvNativeError(f"arithmetic({mode!r}): expected one of 'split', 'f32', 'f16'")
         self.mode = MFMA_MODES[mode]

@@ -165,6 +165,7 @@ def _u8(nbytes, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------- FCResNetBlock
+@_lib.keep_mode
 class _ResnetBlockFn(torch.autograd.Function):
     """reference nn/fc_resnet_block.py:84-88 as fc_resnet_block_forward / fc_resnet_block_backward"""
 
@@ -263,6 +264,7 @@ def resnet_block(block, x, graph):
 
 
 # --------------------------------------------------------------------------------------------------------------------- ECHOBlock
+@_lib.keep_mode
 class _EchoBlockFn(torch.autograd.Function):
     """reference nn/echo_block.py:93-94: ECHO(modReLU(conv(x))) as fc_echo_block_forward / fc_echo_block_backward"""
 

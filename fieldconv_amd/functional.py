@@ -125,6 +125,7 @@ def supported(graph, I, O, B):
     return bool(_lib.load().fc_supported(ctypes.byref(make_dims(graph, I, O, B))))
 
 
+@_lib.keep_mode
 class _FieldConvFn(torch.autograd.Function):
     """y = FieldConv(x; W_eff) on a preprocessed support graph (reference nn/field_conv.py:128-137)."""
 
@@ -360,6 +361,7 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
     return gx, gw, pgrads
 
 
+@_lib.keep_mode
 class _FieldConvParamFn(torch.autograd.Function):
     """FieldConv straight from the module parameters: the filter assembly of reference
     nn/field_conv.py:10-33 and its autograd twin run as one small HIP kernel each
@@ -398,6 +400,7 @@ class _FieldConvParamFn(torch.autograd.Function):
         return gx, g_z, g_s, g_p, None, None, None
 
 
+@_lib.keep_mode
 class _FieldConvActFn(torch.autograd.Function):
     """modReLU(FieldConv(x) [+ addend]) with the residual add and the modReLU in the convolution's epilogue (SURVEY 8 row
     f4; reference nn/fc_resnet_block.py:84-88, nn/tangent_nonlin.py:24-35).  The kernel leaves the pre-activation too; the
@@ -491,6 +494,7 @@ def _cgemm(lib, A, B, C, M, N, K, sam, sak, sbk, sbn, conj_b, alpha):
     return C
 
 
+@_lib.keep_mode
 class _GenericFieldConvFn(torch.autograd.Function):
     """FieldConv for (n_rings, band_limit) pairs without specialised kernels (n_rings > 8, band_limit > 3 or 0) and for
     complex128 features of any shape (the reference's modules run under .double()): the gather and the scatter are run-time
@@ -572,6 +576,7 @@ def _compiled(graph):
 MAX_CHANNELS = 64      # one channel per lane in the kernels' gather phases (csrc/fc_kernels.hpp: kMaxChannels)
 
 
+@_lib.keep_mode
 class _WideFieldConvFn(torch.autograd.Function):
     """FieldConv wider than the kernels' channel block (reference nn/field_conv.py:62 takes any width): channel blocks enqueued
     by ONE native call per pass (csrc/fc_wide.hip: fc_forward_wide / fc_backward_wide) -- block copies, filter packing from the
