@@ -1519,25 +1519,31 @@ def test_echo_head_limits_fall_back_to_the_dense_layers(dev):
             assert rel_err(H(y_node), H(y_ref)) < 2e-6
 
 
-@pytest.mark.parametrize('N,k', [(3000, 12), (9000, 8)])
-def test_two_arithmetic_modes_in_one_process(dev, N, k):
+@pytest.mark.parametrize('N,k,I,O,B,R', [(3000, 12, 48, 48, 2, 6), (9000, 8, 48, 48, 2, 6), (8203, 9, 16, 32, 1, 4), (9000, 8, 64, 16, 2, 6),
+                                         (8500, 8, 24, 48, 1, 8)])
+def test_two_arithmetic_modes_in_one_process(dev, N, k, I, O, B, R):
     """The arithmetic mode travels in the dims of every call (fc_dims::mode, ABI 11): convolutions of one process run in different
     modes side by side -- `with fieldconv_amd.arithmetic(...)` -- and the library keeps no state between them.  At 9 000 vertices
     the default mode's backward pass is the gather / stream / gx arrangement while fp32 runs the data / filter kernel pair: the
-    two agree to fp32 rounding (and both with the oracle elsewhere)."""
+    two agree to fp32 rounding (and both with the oracle elsewhere) -- also on other shapes the arrangement takes through its run-time
+    sized instantiations (16 -> 32 channels on 4 rings: one gxt wavefront; 64 -> 16 channels: three reduction rounds; 8 rings)."""
     if os.environ.get('FC_MFMA') not in (None, '', 'split'):
         pytest.skip('compares the modes against the default one')
     import fieldconv_amd
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.nn import FieldConv
     from fieldconv_amd.transforms import FCPrecomp
-    B, R, C = 2, 6, 48
     data = sphere_support(N, k=k, seed=4, support='p95').to(dev)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
-    conv = FieldConv(C, C, band_limit=B, n_rings=R, ftype=1).to(dev)
+    conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=1).to(dev)
     gen = torch.Generator().manual_seed(N)
-    x = torch.complex(torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen)).to(dev).requires_grad_(True)
-    gy = torch.complex(torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen)).to(dev)
+    x = torch.complex(torch.randn(N, I, generator=gen), torch.randn(N, I, generator=gen)).to(dev).requires_grad_(True)
+    gy = torch.complex(torch.randn(N, O, generator=gen), torch.randn(N, O, generator=gen)).to(dev)
+    if N >= 8192:
+        import ctypes
+        from fieldconv_amd import _lib
+        d = _lib.FcDims(N, int(edges.shape[0]), I, O, R, B)
+        print('H-streaming backward:', bool(_lib.load().fc_backward_streams(ctypes.byref(d), 1)))
 
     def step():
         y = conv(x, edges, sten)
