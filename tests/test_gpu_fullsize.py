@@ -565,3 +565,69 @@ def test_config3_full_size_every_convolution_against_the_oracle(dev, monkeypatch
         worst[n] = errs
         assert max(errs) < TOL, (n, errs)
     print('config 3, per convolution (y, gx, gW) errors:', {n: tuple('%.1e' % e for e in v) for n, v in worst.items()})
+
+
+def _stream_shape_classes(N):
+    """One (I, O) per class of run-time geometry the H-streaming backward takes: rings, band limit, channel tiles, k steps, gxt wavefronts,
+    gW tiles per wavefront, ragged channel tiles (fc_backward_stream.hpp: plan_stream)."""
+    import ctypes
+    import itertools
+    from fieldconv_amd import _lib
+    lib = _lib.load()
+    classes = {}
+    for R, B in itertools.product((2, 4, 6, 8), (1, 2, 3)):
+        for I in (2, 6, 10, 16, 18, 24, 30, 32, 34, 40, 48, 50, 56, 64):
+            for O in range(1, 65):
+                d = _lib.FcDims(N, N * 8, I, O, R, B)
+                if not lib.fc_backward_streams(ctypes.byref(d), 1):
+                    continue
+                KP, NMT = R * O, (I + 15) // 16
+                KST = KP // 32
+                G = (NMT * KST + 3) // 4
+                T = -(-(KP // 16) // ((16 - G) // NMT))
+                classes.setdefault((R, B, NMT, KST, G, T, I % 16 == 0, O % 16 == 0), (I, O))
+    return sorted(classes.items())
+
+
+def test_every_shape_class_of_the_streaming_backward(dev):
+    """The gather / stream / gx arrangement against the fp32 data / filter kernel pair of the same process (fieldconv_amd.arithmetic),
+    over every class of geometry its plan accepts (294 at this size; every third one here plus the first and last of each (rings,
+    band limit) pair, all of them with FC_FULL_MODES=1): y, gx and the three parameter gradients agree to fp32 rounding."""
+    if os.environ.get('FC_MFMA') not in (None, '', 'split'):
+        pytest.skip('the arrangement exists in the default arithmetic mode only')
+    import fieldconv_amd
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.nn import FieldConv
+    from fieldconv_amd.transforms import FCPrecomp
+    N = 8203
+    classes = _stream_shape_classes(N)
+    assert len(classes) > 200
+    if os.environ.get('FC_FULL_MODES') != '1':
+        ends = {}
+        for n, (key, _) in enumerate(classes):
+            ends.setdefault(key[:2], [n, n])[1] = n
+        keep = {n for lo_hi in ends.values() for n in lo_hi} | set(range(0, len(classes), 3))
+        classes = [c for n, c in enumerate(classes) if n in keep]
+    meshes, worst = {}, 0.0
+    for n, (key, (I, O)) in enumerate(classes):
+        R, B = key[:2]
+        if (R, B) not in meshes:
+            data = sphere_support(N, k=8, seed=10 * R + B, support='p95').to(dev)
+            meshes[(R, B)] = FCPrecomp(B, R, data.epsilon)(data)[:2]
+        edges, sten = meshes[(R, B)]
+        conv = FieldConv(I, O, band_limit=B, n_rings=R, ftype=1).to(dev)
+        gen = torch.Generator().manual_seed(n)
+        x = torch.complex(torch.randn(N, I, generator=gen), torch.randn(N, I, generator=gen)).to(dev).requires_grad_(True)
+        gy = torch.complex(torch.randn(N, O, generator=gen), torch.randn(N, O, generator=gen)).to(dev)
+
+        def step():
+            y = conv(x, edges, sten)
+            return (y.detach(),) + torch.autograd.grad(y, [x] + list(conv.parameters()), grad_outputs=gy)
+
+        got = step()
+        with fieldconv_amd.arithmetic('f32'):
+            ref = step()
+        errs = [rel_err(H(a), H(b)) for a, b in zip(got, ref)]
+        assert all(np.isfinite(e) for e in errs) and max(errs) < 1e-5, (key, I, O, errs)
+        worst = max(worst, max(errs))
+    print('streaming backward: %d shape classes, worst relative difference to the fp32 kernel pair %.1e' % (len(classes), worst))
