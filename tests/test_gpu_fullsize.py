@@ -631,3 +631,55 @@ def test_every_shape_class_of_the_streaming_backward(dev):
         assert all(np.isfinite(e) for e in errs) and max(errs) < 1e-5, (key, I, O, errs)
         worst = max(worst, max(errs))
     print('streaming backward: %d shape classes, worst relative difference to the fp32 kernel pair %.1e' % (len(classes), worst))
+
+
+@pytest.mark.parametrize('N,k', [pytest.param(170_003, 12, id='170k_streaming_2GB_of_H'), pytest.param(400_003, 10, id='400k_kernel_pair_5GB_workspace')])
+def test_meshes_beyond_two_and_four_gigabytes_of_workspace(dev, N, k):
+    """One GPU holds meshes far larger than config 2 (config 4's 160 000 vertices unpartitioned, and beyond): at 170 003 vertices the
+    H-streaming backward writes and reads 2 GB of records (byte offsets past 2^31), at 400 003 the plan falls back to the kernel pair
+    with a workspace past 4 GiB.  Rows of y and gx at the start, the END and the middle of the tensors against the oracle (its own
+    FCPrecomp on the CPU, sub-edge-lists), the filter gradient through the adjoint identity on a cotangent supported on those rows
+    (oracle-evaluated) and on the whole mesh (the kernels' own forward pass)."""
+    from fieldconv_amd.data import sphere_support
+    from fieldconv_amd.functional import field_conv
+    from fieldconv_amd.graph import get_graph
+    from fieldconv_amd.transforms import FCPrecomp
+    from oracle.torch_composites import FCPrecomp as FCPrecompRef
+    if REDUCED or os.environ.get('FIELDCONV_DENSE') == '1' or os.environ.get('FIELDCONV_EAGER_STENCIL') == '1':
+        pytest.skip('record-driven kernels in the fp32-grade modes')
+    I, O, B, R = 48, 48, 2, 6
+    data = sphere_support(N, k, seed=3, support='p95')
+    e_dev, s_dev, _, _ = FCPrecomp(B, R, data.epsilon)(data.to(dev))
+    graph = get_graph(e_dev, s_dev, N)
+    edges, sten, _, _ = FCPrecompRef(B, R, data.epsilon)(data)
+    assert torch.equal(e_dev.cpu(), edges)
+    g = torch.Generator().manual_seed(N)
+    x = torch.complex(torch.randn(N, I, generator=g), torch.randn(N, I, generator=g))
+    gy = torch.complex(torch.randn(N, O, generator=g), torch.randn(N, O, generator=g))
+    W = torch.complex(torch.randn(O, I, R, 2 * B + 1, generator=g), torch.randn(O, I, R, 2 * B + 1, generator=g)) / (I * R) ** 0.5
+    torch.cuda.reset_peak_memory_stats()
+    y, gx, gW = run_conv(graph, x, W, gy, dev)
+    print('N = %d, E = %d: peak device memory of the step %.2f GB' % (N, edges.shape[0], torch.cuda.max_memory_allocated() / 2 ** 30))
+    assert bool(torch.isfinite(torch.view_as_real(y)).all()) and bool(torch.isfinite(torch.view_as_real(gx)).all())
+    sub = torch.cat([torch.arange(0, 10), torch.arange(N - 40, N), torch.randperm(N - 50, generator=g)[:60] + 10])
+    idx = sub.numpy()
+    m_in = torch.isin(edges[:, 1], sub)
+    y_ref = orc.fieldconv_forward(x.numpy(), edges[m_in].numpy(), sten[m_in].numpy(), W.numpy())[idx]
+    m_out = torch.isin(edges[:, 0], sub)
+    gx_ref = orc.fieldconv_backward(x.numpy(), edges[m_out].numpy(), sten[m_out].numpy(), W.numpy(), gy.numpy())[0][idx]
+    assert rel_err(H(y)[idx], y_ref) < TOL
+    assert rel_err(H(gx)[idx], gx_ref) < TOL
+    gy_sub = torch.zeros_like(gy)
+    gy_sub[sub] = gy[sub]
+    _, _, gW_sub = run_conv(graph, x, W, gy_sub, dev)
+    V = torch.complex(torch.randn(W.shape, generator=g), torch.randn(W.shape, generator=g)) * 0.1
+    yv = orc.fieldconv_forward(x.numpy(), edges[m_in].numpy(), sten[m_in].numpy(), V.numpy())
+    lhs = float(np.sum(np.conj(gy_sub.numpy()) * yv).real)
+    rhs = float(torch.sum(torch.conj(gW_sub.cpu()) * V).real)
+    assert abs(lhs - rhs) <= max(2e-4, TOL) * max(abs(lhs), abs(rhs), 1.0)
+    Vd = V.to(dev)
+    with torch.no_grad():
+        yv = field_conv(x.to(dev), Vd, graph)
+    lhs = torch.sum(torch.conj(gy.to(dev)) * yv).real.item()
+    rhs = torch.sum(torch.conj(gW) * Vd).real.item()
+    assert abs(lhs - rhs) <= max(2e-4, TOL) * max(abs(lhs), abs(rhs), 1.0)
