@@ -87,7 +87,7 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
             2 * 64 * 4 + (size_t)2 * p.nslots * kTile * kStreamPartStride * 4;
     if (kTile * I * 8 > kWaves * 1024 - 1024) return p;
     if ((size_t)8 * p.IP * make_mma_geom(I, R, O, 2).KP > p.lds) return p;       // (frequency f's filter planes are staged through LDS once)
-    if ((size_t)p.ntiles * p.F * p.rec_bytes >= ((size_t)1 << 32) || (size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;
+    if ((size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;            // (x rows and gxt slices are addressed with 32-bit offsets; the records with 64-bit ones)
     if (p.lds > kMaxLds) return p;
     p.hrec_bytes = (size_t)p.ntiles * p.F * p.rec_bytes + 1024;
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);

@@ -633,13 +633,23 @@ def test_every_shape_class_of_the_streaming_backward(dev):
     print('streaming backward: %d shape classes, worst relative difference to the fp32 kernel pair %.1e' % (len(classes), worst))
 
 
-@pytest.mark.parametrize('N,k', [pytest.param(170_003, 12, id='170k_streaming_2GB_of_H'), pytest.param(400_003, 10, id='400k_kernel_pair_5GB_workspace')])
-def test_meshes_beyond_two_and_four_gigabytes_of_workspace(dev, N, k):
+@pytest.mark.parametrize('N,k,mode', [pytest.param(170_003, 12, None, id='170k_2GB_of_H'), pytest.param(400_003, 10, None, id='400k_5GB_of_H'),
+                                       pytest.param(400_003, 10, 'f32', id='400k_kernel_pair_5GB_workspace')])
+def test_meshes_beyond_two_and_four_gigabytes_of_workspace(dev, N, k, mode):
     """One GPU holds meshes far larger than config 2 (config 4's 160 000 vertices unpartitioned, and beyond): at 170 003 vertices the
-    H-streaming backward writes and reads 2 GB of records (byte offsets past 2^31), at 400 003 the plan falls back to the kernel pair
-    with a workspace past 4 GiB.  Rows of y and gx at the start, the END and the middle of the tensors against the oracle (its own
-    FCPrecomp on the CPU, sub-edge-lists), the filter gradient through the adjoint identity on a cotangent supported on those rows
-    (oracle-evaluated) and on the whole mesh (the kernels' own forward pass)."""
+    H-streaming backward writes and reads 2 GB of records (byte offsets past 2^31), at 400 003 vertices 4.9 GB (past 2^32); in fp32
+    mode the same mesh takes the data / filter kernel pair with a workspace past 4 GiB.  Rows of y and gx at the start, the END and
+    the middle of the tensors against the oracle (its own FCPrecomp on the CPU, sub-edge-lists), the filter gradient through the
+    adjoint identity on a cotangent supported on those rows (oracle-evaluated) and on the whole mesh (the kernels' own forward pass)."""
+    import contextlib
+    import fieldconv_amd
+    if mode is not None and os.environ.get('FC_MFMA') not in (None, '', 'split'):
+        pytest.skip('selects its own arithmetic mode')
+    with (fieldconv_amd.arithmetic(mode) if mode else contextlib.nullcontext()):
+        _big_mesh_case(dev, N, k)
+
+
+def _big_mesh_case(dev, N, k):
     from fieldconv_amd.data import sphere_support
     from fieldconv_amd.functional import field_conv
     from fieldconv_amd.graph import get_graph
