@@ -195,16 +195,27 @@ def test_config2_fc_resnet_block_rows(dev):
     verts = torch.unique(torch.cat((edges[mask, 0], s1)))
     local = torch.full((N,), -1, dtype=torch.long)
     local[verts] = torch.arange(verts.numel())
-    e_sub, s_sub = local[edges[mask]], sten[mask]
-    ref_p = {n: p.detach().clone().requires_grad_(True) for n, p in blk.named_parameters()}
-    xr = x[verts].clone().requires_grad_(True)
+    # The yardstick in float64, and once more in float32 to measure what fp32 rounding alone does to this function: conv1's
+    # parameter gradients pass through modReLU's tangential term (f(r)/r) g_t, which amplifies the rounding of the first
+    # convolution's output wherever a channel's bias is positive and its radius small -- ANY fp32 evaluation sits 1e-5 ... 3e-5 from
+    # the float64 one there (conv2's gradients, which do not: 5e-7 ... 2e-6)
+    e_sub = local[edges[mask]]
 
-    def conv(xin, pre):
-        return port.field_conv(xin, e_sub, s_sub, ref_p[pre + '.zonal'], ref_p[pre + '.spherical'], ref_p[pre + '.phase'], 1, B)
-    h = tangent_nonlin(conv(xr, 'conv1'), ref_p['nonlin1.bias'])
-    h = conv(h, 'conv2') + tangent_lin(xr, ref_p['res.Re'], ref_p['res.Im'])
-    yr = tangent_nonlin(h, ref_p['nonlin2.bias'])
-    gr = torch.autograd.grad(yr, [xr] + [ref_p[n] for n in names], grad_outputs=gy[verts])
+    def reference(rdtype, cdtype):
+        s_sub = sten[mask].to(cdtype)
+        ref_p = {n: p.detach().to(rdtype).clone().requires_grad_(True) for n, p in blk.named_parameters()}
+        xr = x[verts].to(cdtype).clone().requires_grad_(True)
+
+        def conv(xin, pre):
+            return port.field_conv(xin, e_sub, s_sub, ref_p[pre + '.zonal'], ref_p[pre + '.spherical'], ref_p[pre + '.phase'], 1, B)
+        h = tangent_nonlin(conv(xr, 'conv1'), ref_p['nonlin1.bias'])
+        h = conv(h, 'conv2') + tangent_lin(xr, ref_p['res.Re'], ref_p['res.Im'])
+        yr = tangent_nonlin(h, ref_p['nonlin2.bias'])
+        return yr, torch.autograd.grad(yr, [xr] + [ref_p[n] for n in names], grad_outputs=gy[verts].to(cdtype))
+
+    yr, gr = reference(torch.float64, torch.cdouble)
+    _, gr32 = reference(torch.float32, torch.cfloat)
+    cond = {name: rel_err(a.numpy(), b.numpy()) for name, a, b in zip(names, gr32[1:], gr[1:])}
 
     blk = blk.to(dev)
     xd = x.to(dev).requires_grad_(True)
@@ -216,8 +227,11 @@ def test_config2_fc_resnet_block_rows(dev):
     outside[verts.numpy()] = False
     assert not gxd[outside].any()                       # nothing outside the two-hop neighbourhood receives gradient
     assert rel_err(gxd[verts.numpy()], gr[0].numpy()) < 2 * TOL
-    for name, a, b in zip(names, gd[1:], gr[1:]):
-        assert rel_err(H(a), b.numpy()) < 2 * TOL, name
+    errs = {name: rel_err(H(a), b.numpy()) for name, a, b in zip(names, gd[1:], gr[1:])}
+    print('FCResNetBlock at config 2, parameter gradients against float64:', {n: '%.1e' % e for n, e in errs.items()})
+    print('the reference-structured port in float32 against itself in float64:', {n: '%.1e' % e for n, e in cond.items()})
+    for name, e in errs.items():
+        assert e < max(2 * TOL, 4 * cond[name]), (name, e, cond[name])
 
 
 @pytest.mark.parametrize('N,k,B,R', [(6000, 9, 2, 6), (300, 20, 3, 8), (900, 12, 1, 3)])
