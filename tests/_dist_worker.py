@@ -124,8 +124,9 @@ def check_at_config4_size(rank, world, lo, n_owned, plan, fe, fs, x_all, gy_all,
           f'({100 * frac_remote:.1f} % of the sampled out-edges end on another rank); against one process on the union mesh: '
           f'y={c_y:.2e} gx={c_gx:.2e} gW={c_gw:.2e}', flush=True)
     assert plan.n_halo > 0.02 * n_owned
-    assert e_y < 1e-5 and e_gx < 1e-5
-    assert c_y < 1e-5 and c_gx < 1e-5 and c_gw < 1e-5
+    tol = 5e-3 if os.environ.get('FC_MFMA') == 'f16' else 1e-5      # f16: the opt-in reduced-precision mode
+    assert e_y < tol and e_gx < tol
+    assert c_y < tol and c_gx < tol and c_gw < tol
     dist.destroy_process_group()
 
 

@@ -179,13 +179,13 @@ def test_echo_block_and_lift_block_golden(dev):
     assert rel_err(H(y), c['y']) < 5 * TOL
     params = dict(m.named_parameters())
     grads = torch.autograd.grad(y, [x] + list(params.values()), grad_outputs=D(c['gy'], dev), allow_unused=True)
-    assert rel_err(H(grads[0]), c['gx']) < 2e-4          # histogram votes: piecewise-linear, fp32 floor/ceil sensitive
+    assert rel_err(H(grads[0]), c['gx']) < max(2e-4, 4 * TOL if REDUCED else 0.0)          # histogram votes: piecewise-linear, fp32 floor/ceil sensitive
     # all twelve parameter gradients of the block (convolution filter + phase, modReLU bias, the three MLP layers, the residual)
     worst = {}
     for (name, _), gval in zip(params.items(), grads[1:]):
         assert gval is not None, name
         worst[name] = rel_err(H(gval), c['g_' + name])
-    assert len(worst) == 12 and max(worst.values()) < 2e-4, worst
+    assert len(worst) == 12 and max(worst.values()) < max(2e-4, 4 * TOL if REDUCED else 0.0), worst       # (reduced-precision mode: its own gate)
     for ft in (0, 1):
         c = load_golden('echo_lift.npz')[f'lift_block_t{ft}']
         m = load_params(LiftBlock(int(c['Cin']), int(c['Cout']), n_rings=int(c['R']), ftype=ft), c).to(dev)
