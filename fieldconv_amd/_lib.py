@@ -115,7 +115,7 @@ SIGNATURES = {
     'fc_backward_data_factored': (ctypes.c_int, [_vp, _vp, _vp, _CP, _vp, _vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_filter': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_streams': (_c_int32, [_DP, _c_int32]),
-    'fc_backward_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _sz, _DP, _vp]),
+    'fc_backward_gather': (ctypes.c_int, [_vp, _vp, _CP, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_stream': (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _DP, _vp]),
     'fc_backward_finish': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _vp]),
     'fc_backward_finish_params': (ctypes.c_int, [_vp, _vp, _sz, _DP, _c_int32, _FP, _vp]),

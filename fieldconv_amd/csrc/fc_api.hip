@@ -190,12 +190,12 @@ int32_t fc_backward_streams(const fc_dims* dims, int32_t records) {
     return (fc::dims_supported(dims) && dims->R <= 8 && fc::rows_fit_32bit(dims) && fc::backward_streams(dims, records != 0)) ? 1 : 0;
 }
 
-int fc_backward_gather(const float* gy, const float* rec_s, const fc_csr* by_source, void* workspace, size_t workspace_bytes,
-                       const fc_dims* dims, void* stream) {
-    if (!gy || !by_source || !by_source->rowptr || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
+int fc_backward_gather(const float* gy, const float* rec_s, const fc_csr* by_source, const float* wpk_bwd, void* workspace,
+                       size_t workspace_bytes, const fc_dims* dims, void* stream) {
+    if (!gy || !by_source || !by_source->rowptr || !wpk_bwd || !fc::dims_valid(dims)) return FC_ERR_BAD_ARGUMENT;
     if (dims->E > 0 && (!rec_s || !by_source->runs)) return FC_ERR_BAD_ARGUMENT;
     if (!fc_backward_streams(dims, 1)) return FC_ERR_UNSUPPORTED;
-    return fc::backward_stream_impl(nullptr, gy, rec_s, by_source, nullptr, nullptr, workspace, workspace_bytes, dims,
+    return fc::backward_stream_impl(nullptr, gy, rec_s, by_source, wpk_bwd, nullptr, workspace, workspace_bytes, dims,
                                     static_cast<hipStream_t>(stream), 1);
 }
 

@@ -609,12 +609,12 @@ __global__ void fc_reduce_gw_kernel(const float2* __restrict__ gwp, float2* __re
 
 // ------------------------------------------------------------------------------------ H-streaming arrangement (fc_backward_stream.hpp)
 template <int R, int B>
-static int launch_gather(const float2* gy, const float* rec, const fc_csr* g, char* hrec, const StreamArgs& a, const StreamPlan& p,
-                         hipStream_t stream) {
+static int launch_gather(const float2* gy, const float* rec, const fc_csr* g, const float* wpk, char* hrec, const StreamArgs& a,
+                         const StreamPlan& p, hipStream_t stream) {
     auto kern = fc_backward_gather_kernel<R, B>;
     const size_t lds = (size_t)kWaves * kRingChunks * 1024;
     const int grid = p.ntiles < num_cus() ? p.ntiles : num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, gy, rec, g->rowptr, g->runs, hrec, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, gy, rec, g->rowptr, g->runs, wpk, hrec, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -634,16 +634,17 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
                          size_t ws_bytes, const fc_dims* d, hipStream_t stream, int stages) {
     const StreamPlan p = plan_stream(d, halves_of(d), true);
     if (!p.ok) return FC_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < p.hrec_bytes + p.gwp_bytes + p.gxt_bytes) return FC_ERR_WORKSPACE;
-    const StreamArgs a = make_stream_args(d, p);
+    if (!ws || ws_bytes < p.hrec_bytes + p.gwp_bytes + p.gxt_bytes + p.wst_bytes) return FC_ERR_WORKSPACE;
+    StreamArgs a = make_stream_args(d, p);
     char* hrec = static_cast<char*>(ws);
+    a.wst = reinterpret_cast<uint32_t*>(hrec + p.hrec_bytes + p.gwp_bytes + p.gxt_bytes);      // (16-byte aligned: the three sizes before it are)
     float2* gwp = reinterpret_cast<float2*>(hrec + p.hrec_bytes);
     float2* gxt = reinterpret_cast<float2*>(hrec + p.hrec_bytes + p.gwp_bytes);
     const float2* x2 = reinterpret_cast<const float2*>(x);
     int rc = FC_ERR_UNSUPPORTED;
     if (stages & 1) {
         const float2* gy2 = reinterpret_cast<const float2*>(gy);
-#define FC_GATHER_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_gather<RR, BB>(gy2, rec, g, hrec, a, p, stream);
+#define FC_GATHER_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_gather<RR, BB>(gy2, rec, g, wpk, hrec, a, p, stream);
         FC_GATHER_CASE(2, 1) FC_GATHER_CASE(4, 1) FC_GATHER_CASE(6, 1) FC_GATHER_CASE(8, 1)
         FC_GATHER_CASE(2, 2) FC_GATHER_CASE(4, 2) FC_GATHER_CASE(6, 2)
         FC_GATHER_CASE(2, 3) FC_GATHER_CASE(4, 3)
@@ -673,7 +674,7 @@ size_t backward_workspace_bytes(const fc_dims* d) {
     const BwdPlan p = plan_backward(d, halves_of(d));
     const size_t pair = p.hdump_bytes + p.gwp_bytes + p.gxp_bytes + 256;
     const StreamPlan sp = plan_stream(d, halves_of(d), true);          // (records or not is the launch's choice: room for either)
-    const size_t stream = sp.ok ? sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes + 256 : 0;
+    const size_t stream = sp.ok ? sp.hrec_bytes + sp.gwp_bytes + sp.gxt_bytes + sp.wst_bytes + 256 : 0;
     return pair > stream ? pair : stream;
 }
 

@@ -35,7 +35,7 @@ struct StreamPlan {
     int img_bytes;       // 16 * KSI halves
     int rec_bytes;       // image + [16] s_v + [16] 1/s_v, rounded up to whole KiB (DMA pieces)
     size_t lds;
-    size_t hrec_bytes, gwp_bytes, gxt_bytes;
+    size_t hrec_bytes, gwp_bytes, gxt_bytes, wst_bytes;
     int nt_dump;
 };
 
@@ -45,6 +45,7 @@ struct StreamArgs {
     int img_bytes, rec_bytes;
     int wKI, wKP;            // channel stride and k entries per row of the packed backward image (k = r*wKI + o)
     int nt_dump;
+    uint32_t* wst;           // [F][G][kStreamUnits][re_hi, re_lo, im_hi, im_lo][64 lanes][4 dwords]: written by the gather launch, read by the streaming one
     unsigned long long* stamps;   // development only (fc_debug_stamp_buffer, FC_STAMP_KERNEL=stream): s_memtime stamps of workgroup (0, 0)
     int dbg;                 // development only (FC_DEBUG_BWD): bit0 no walk, bit1 no gxt product, bit2 no gW product, bit3 no H stores,
                              // bit4 the stream kernel re-reads its first record (L2), bit5 H stored with the default cache policy, bit6 records last-produced first
@@ -86,12 +87,12 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     p.lds = (size_t)2 * p.rec_bytes + (size_t)2 * 4 * p.IP * kXbStride * 2 + (size_t)3 * kTile * I * 8 + 4 * 64 * 4 + 2 * 8 * 64 * 4 +
             2 * 64 * 4 + (size_t)2 * p.nslots * kTile * kStreamPartStride * 4;
     if (kTile * I * 8 > kWaves * 1024 - 1024) return p;
-    if ((size_t)8 * p.IP * make_mma_geom(I, R, O, 2).KP > p.lds) return p;       // (frequency f's filter planes are staged through LDS once)
     if ((size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;            // (x rows and gxt slices are addressed with 32-bit offsets; the records with 64-bit ones)
     if (p.lds > kMaxLds) return p;
     p.hrec_bytes = (size_t)p.ntiles * p.F * p.rec_bytes + 1024;
     p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
     p.gxt_bytes = (size_t)p.F * d->N * I * sizeof(float2);
+    p.wst_bytes = (size_t)p.F * p.G * 4 * kStreamUnits * kWave * 16;      // the gxt wavefronts' filter fragments, in the order they load them
     p.nt_dump = p.hrec_bytes > ((size_t)192 << 20) ? 1 : 0;
     p.ok = true;
     return p;
@@ -106,6 +107,7 @@ inline StreamArgs make_stream_args(const fc_dims* d, const StreamPlan& p) {
     const MmaGeom gw = make_mma_geom(d->I, d->R, d->O, 2);
     a.wKI = gw.KI; a.wKP = gw.KP;
     a.nt_dump = p.nt_dump;
+    a.wst = nullptr;         // (the caller's workspace: backward_stream_impl)
     static const int dbg = [] { const char* e = dev_env("FC_DEBUG_BWD"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     static const bool stamp_me = [] { const char* e = dev_env("FC_STAMP_KERNEL"); return e && e[0] == 's'; }();
@@ -139,7 +141,7 @@ __device__ __forceinline__ void store_plane_row(uint32_t* dst, const uint32_t (&
 template <int R, int B>
 __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
     const float2* __restrict__ ggy, const float* __restrict__ gsten, const int32_t* __restrict__ growptr,
-    const int32_t* __restrict__ gruns, char* __restrict__ hrec, const StreamArgs a) {
+    const int32_t* __restrict__ gruns, const float* __restrict__ gwpk, char* __restrict__ hrec, const StreamArgs a) {
     constexpr int F = 2 * B + 1;
     static_assert(F * R <= 32 && (R & 1) == 0, "one walk per vertex, an even ring count");
     constexpr int RECF = factored_record_floats(B);
@@ -310,6 +312,42 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
         end = nend;
 #pragma unroll
         for (int q = 0; q < R; ++q) ro[q] = nro[q];
+    }
+
+    // ---- a rider for the launch that follows: the filter fragments of the streaming kernel's gxt wavefronts, copied out of the packed
+    // backward image in the order those wavefronts load them -- entry ((f*G + g)*kStreamUnits + ui)*4 + plane, 64 lanes x 16 bytes:
+    // W_f[i = mt*16 + fr][k' = kb*32 + 8*fq + j], j = 0..7, of unit u = 4g + ui = (row tile mt, k block kb), mt-major.  The packed image is
+    // ring-major (k = r*KI + o) where the records are o-major (k' = o*R + r): picked in the streaming kernel itself -- 128 two-byte
+    // reads per lane on seven wavefronts of every one of its workgroups, behind a staging pass through LDS and two barriers -- this was
+    // 30 000 of that launch's 43 000 prologue cycles (in-kernel stamps); here one 16-byte entry per thread of the first few workgroups.
+    {
+        const int total = a.F * a.G * kStreamUnits * 4 * kWave;
+        const int NU = a.NMT * a.KST;
+        const size_t plane_sz = (size_t)a.IP * a.wKP;                               // halves per plane
+        const uint16_t* const img0 = reinterpret_cast<const uint16_t*>(gwpk + a.IP);
+        for (int e = blockIdx.x * kThreads + tid; e < total; e += gridDim.x * kThreads) {
+            const int ln = e & 63, pl = (e >> 6) & 3, ui = (e >> 8) % kStreamUnits, fg = e / (kStreamUnits * 4 * kWave);
+            const int g_ = fg % a.G, f_ = fg / a.G;
+            const int fr_ = ln & 15, fq_ = ln >> 4;
+            const int u = min(g_ * kStreamUnits + ui, NU - 1);
+            const int mt = u / a.KST, kb = u - mt * a.KST;
+            const int row = (mt * 16 + fr_) * 32;
+            const uint16_t* const img = img0 + ((size_t)f_ * 4 + pl) * plane_sz;
+            int o = (kb * 32 + 8 * fq_) / R, r = kb * 32 + 8 * fq_ - o * R;
+            uint32_t v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                uint32_t pr[2];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int kk = r * a.wKI + o;
+                    pr[e2] = img[(size_t)(kk >> 5) * a.IP * 32 + row + (kk & 31)];
+                    if (++r == R) { r = 0; ++o; }
+                }
+                v[jj] = pr[0] | (pr[1] << 16);
+            }
+            *reinterpret_cast<u32x4*>(a.wst + (size_t)e * 4) = u32x4{v[0], v[1], v[2], v[3]};
+        }
     }
 }
 
@@ -513,17 +551,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     stamp(28);
     // ---- the filter fragments of the gxt role: units u = 4*wave .. +3 of the NMT*KST (row tile mt over i, k block kb) grid, mt-major;
     // W_f[i = mt*16 + fr][k' = kb*32 + 8*fq + j] (conjugated, 1/F folded in, row-scaled halves) stay in registers for the whole launch.
-    // The packed backward image is ring-major (k = r*KI + o) where the records are o-major (k' = o*R + r): frequency f's four planes come
-    // into LDS once (whole KiB pieces, all wavefronts; nothing else lives there yet) and every lane picks its 128 halves from there --
-    // picked from global memory they were 128 two-byte requests per lane on seven wavefronts of every CU: a quarter of the launch.
-    {
-        const int wbytes = 4 * IP * a.wKP * 2;
-        const char* wsrc = reinterpret_cast<const char*>(gwpk + IP) + (size_t)f * wbytes;
-        for (int p = wave; p < (wbytes >> 10); p += kWaves) lds_dma16_saddr(wsrc + p * 1024, lane16, smem + p * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // (the gxt wavefronts pick their fragments here; then, behind one more barrier -- the LDS is free for the records -- every wavefront:)
+    // They come as sixteen 16-byte loads per lane from the copy the gather launch left in fragment order (StreamArgs::wst).
+    // (the gxt wavefronts request their fragments; then every wavefront:)
     auto first_requests = [&]() {
         __syncthreads();
         requests(0, 0, kWaves);
@@ -557,37 +586,20 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
         const int NU = a.NMT * a.KST;
         u32x4 wrh[kStreamUnits], wrl[kStreamUnits], wih[kStreamUnits], wil[kStreamUnits];
         {
-            typedef __attribute__((address_space(3))) const uint16_t lds_u16;
-            lds_u16* const wl = (lds_u16*)smem;
-            const int plane_sz = IP * a.wKP;
+            const u32x4* const ws = reinterpret_cast<const u32x4*>(a.wst) + (size_t)(f * a.G + wave) * (kStreamUnits * 4 * kWave) + lane;
 #pragma unroll
             for (int ui = 0; ui < kStreamUnits; ++ui) {
-                const int u = min(u0 + ui, NU - 1);
-                const int mt = u / a.KST, kb = u - mt * a.KST;
-                const int row = (mt * 16 + fr) * 32;
-                uint32_t v[4][4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    uint32_t pr[4][2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int kq = kb * 32 + 8 * fq + 2 * jj + e;          // k' = o*R + r
-                        const int o = kq / a.R, r = kq - o * a.R;
-                        const int kk = r * a.wKI + o;
-                        const int off = (kk >> 5) * IP * 32 + row + (kk & 31);
-#pragma unroll
-                        for (int pl = 0; pl < 4; ++pl) pr[pl][e] = wl[pl * plane_sz + off];
-                    }
-#pragma unroll
-                    for (int pl = 0; pl < 4; ++pl) v[pl][jj] = pr[pl][0] | (pr[pl][1] << 16);
-                }
-                wrh[ui] = u32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
-                wrl[ui] = u32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
-                wih[ui] = u32x4{v[2][0], v[2][1], v[2][2], v[2][3]};
-                wil[ui] = u32x4{v[3][0], v[3][1], v[3][2], v[3][3]};
+                wrh[ui] = ws[(ui * 4 + 0) * kWave];
+                wrl[ui] = ws[(ui * 4 + 1) * kWave];
+                wih[ui] = ws[(ui * 4 + 2) * kWave];
+                wil[ui] = ws[(ui * 4 + 3) * kWave];
             }
         }
         first_requests();
+        // (first_requests waited for everything this wavefront had requested: the fragments are in.  Pinned here so that the compiler's own
+        // wait for them stands in front of the loop, not at their first use inside it -- behind a record's freshly issued requests)
+#pragma unroll
+        for (int ui = 0; ui < kStreamUnits; ++ui) asm volatile("" : "+v"(wrh[ui]), "+v"(wrl[ui]), "+v"(wih[ui]), "+v"(wil[ui]));
         const int hbase = fr * KSI + 8 * fq;
         for (int k = 0; k < nrec; ++k) {
             head(k);

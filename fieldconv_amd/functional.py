@@ -335,7 +335,7 @@ def _launch_backward(lib, x, gy, graph, wpk_b, plan, wshape, st, params=None, bi
     if kernel_timer.enabled and graph.on_gx is None and graph.factored and lib.fc_backward_streams(plan.dref, plan.records):
         # the H-streaming arrangement's two halves bracketed apart (the per-kernel timing pass of bench.py): gather | stream + gx
         with _timed('fc_backward_data'):
-            check(lib.fc_backward_gather(_p(gy), _p(sten), plan.cref_s, wsp, nbytes, plan.dref, st), 'fc_backward_gather')
+            check(lib.fc_backward_gather(_p(gy), _p(sten), plan.cref_s, _p(wpk_b), wsp, nbytes, plan.dref, st), 'fc_backward_gather')
         with _timed('fc_backward_filter'):
             check(lib.fc_backward_stream(_p(x), _p(wpk_b), _p(gx), wsp, nbytes, plan.dref, st), 'fc_backward_stream')
         if fp is not None:

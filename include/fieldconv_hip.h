@@ -188,10 +188,12 @@ int fc_backward_filter(const float* x, void* workspace, size_t workspace_bytes, 
  * ONE kernel that streams H once for both products (gxt = H conj(W), gW = H^T conj(xt)) + a small kernel that forms gx; gx is complete
  * and the filter-gradient partials are in the workspace when its work is done, and fc_backward_filter has nothing left to launch.
  * fc_backward_gather / fc_backward_stream are the two halves of that fc_backward_data_factored call as entry points of their own
- * (per-kernel timing; FC_ERR_UNSUPPORTED where the arrangement does not apply).  Autograd of reference nn/field_conv.py:21,130,134. */
+ * (per-kernel timing; FC_ERR_UNSUPPORTED where the arrangement does not apply).  The gather launch also leaves, in the workspace, a
+ * copy of the packed filter in the order the streaming launch's wavefronts load their fragments: fc_backward_stream reads what the
+ * fc_backward_gather call before it wrote for the same wpk_bwd.  Autograd of reference nn/field_conv.py:21,130,134. */
 int32_t fc_backward_streams(const fc_dims* dims, int32_t records);
-int fc_backward_gather(const float* gy, const float* rec_s, const fc_csr* by_source, void* workspace, size_t workspace_bytes,
-                       const fc_dims* dims, void* stream);
+int fc_backward_gather(const float* gy, const float* rec_s, const fc_csr* by_source, const float* wpk_bwd, void* workspace,
+                       size_t workspace_bytes, const fc_dims* dims, void* stream);
 int fc_backward_stream(const float* x, const float* wpk_bwd, float* gx, void* workspace, size_t workspace_bytes, const fc_dims* dims,
                        void* stream);
 int fc_backward_finish(float* gw_eff, void* workspace, size_t workspace_bytes, const fc_dims* dims, int32_t records, void* stream);

@@ -95,6 +95,15 @@ def main():
     if all(k in ev for k in (28, 29, 30, 31)) and ev[31] > ev[29]:
         print(f'workgroup 0, wave 0: {ev[30] - ev[28]} shader cycles in {(ev[31] - ev[29]) / 100:.1f} us -> '
               f'{(ev[30] - ev[28]) / (ev[31] - ev[29]) * 0.1:.2f} GHz')
+    # from the kernel's first instruction (28) to the first phase label, and from the last phase label to the end (30), per wave
+    for w in range(16):
+        seq = [((int(v) >> 56) & 0xff, int(v) & ((1 << 56) - 1)) for v in st[w].tolist() if v]
+        seq = [(lab, t) for lab, t in seq if lab not in (29, 31)]
+        if len(seq) > 3 and seq[0][0] == 28:
+            tail = seq[-1][1] - seq[-2][1] if seq[-1][0] == 30 else 0
+            first = next(i for i, (lab, _) in enumerate(seq) if lab == 10)
+            steps = ' '.join(f'{lab}:+{seq[i][1] - seq[i - 1][1]}' for i, (lab, _) in enumerate(seq[:first + 1]) if i > 0)
+            print(f'wave {w:2d}: prologue {seq[first][1] - seq[0][1]:7d} cycles ({steps}), epilogue {tail:7d}')
     for w in args.wave:
         print(f'--- wave {w}')
         prev = None

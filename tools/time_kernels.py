@@ -91,7 +91,7 @@ def bwd_data():
 
 
 def bwd_gather():
-    lib.fc_backward_gather(_p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(ws), nb, ctypes.byref(dims), _stream())
+    lib.fc_backward_gather(_p(gy), _p(graph.rec_s), ctypes.byref(cs), _p(wb), _p(ws), nb, ctypes.byref(dims), _stream())
 
 
 def bwd_stream():
