@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--wave', type=int, nargs='*', default=[0, 7])
     ap.add_argument('--tiles', type=int, default=2)
     ap.add_argument('--warm', type=int, default=5, help='steps before the stamped one (a few hundred: the settled clock)')
+    ap.add_argument('--shape', type=int, nargs=5, default=[20000, 32, 48, 2, 6], metavar=('N', 'k', 'C', 'B', 'R'), help='mesh and layer (default: config 2; config 5: 4999 28 64 3 6)')
     args = ap.parse_args()
     if args.which in ('data', 'filter', 'stream'):                # which of the two backward kernels stamps (read once by the library)
         os.environ['FC_STAMP_KERNEL'] = args.which
@@ -42,7 +43,7 @@ def main():
     from fieldconv_amd.nn import FieldConv
     from fieldconv_amd.transforms import FCPrecomp
     dev = torch.device('cuda:0')
-    N, k, C, B, R = 20000, 32, 48, 2, 6
+    N, k, C, B, R = args.shape
     data = sphere_support(N, k, support='p95').to(dev)
     edges, sten, _, _ = FCPrecomp(B, R, data.epsilon)(data)
     conv = FieldConv(C, C, band_limit=B, n_rings=R).to(dev)
