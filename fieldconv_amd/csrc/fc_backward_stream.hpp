@@ -356,10 +356,13 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
 //
 // Timeline of record k (ONE workgroup barrier per record).  Up to the barrier a wavefront only waits for its pieces of
 // record k; everything else happens BEHIND the barrier, where it overlaps with the other wavefronts' matrix work:
-//   barrier(k) | DMA of record k+1 starts (its buffer was last read before the barrier) | x rows of record k+3 requested |
-//   gxt of record k-1 leaves (fixed-order sum of the k-partials) | second operand of record k+1 (x~ / s_v * t[i] in halves,
-//   planes [i][vertex]) from the column magnitudes written one record earlier | column magnitudes of record k+2 |
-//   products of record k (role of the wavefront) | wait for my DMA pieces | barrier(k+1)
+//   gxt role: barrier(k) | DMA of record k+1 starts (its buffer was last read before the barrier), x rows of record k+3 requested |
+//             gxt of record k-1 leaves (fixed-order sum of the k-partials) | gxt products of record k | wait for my DMA pieces | barrier(k+1)
+//   gW role:  barrier(k) | gW products of record k | second operand of record k+1 (x~ / s_v * t[i] in halves, planes [i][vertex]) from
+//             the column magnitudes written one record earlier, column magnitudes of record k+2 | barrier(k+1)
+// The two roles of a SIMD take its matrix pipe in turns: one starts the interval with requests, LDS sums and stores and ends it with
+// matrix instructions, the other starts with matrix instructions and ends with vector work (both roles vector-first, as first built:
+// 112 us for the launch + gx on one box; this order: 101.5).
 // Every LDS buffer is written in one barrier interval and read in the next, two copies each.
 // KPT / IT: k entries per row and channel count as compile-time constants (0: from the arguments) -- the fragment reads of the
 // default layer then carry their plane / row offsets as immediates instead of a vector add each.
@@ -575,8 +578,6 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
         stamp(2);
         requests(k + 1, k + 3, a.G);
         stamp(4);
-        pair_rows(k + 1);
-        pair_max(k + 2);
         stamp(1);
     };
 
@@ -603,6 +604,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
         const int hbase = fr * KSI + 8 * fq;
         for (int k = 0; k < nrec; ++k) {
             head(k);
+            // gxt of the record before leaves now -- vector, LDS and store work while the gW wavefronts of my SIMD are in their matrix
+            // products; my own products follow (the roles take the matrix pipe in turns: -6.5 us of 108 on one box, four runs each)
+            if (k > 0) reduce_gxt(k - 1);
             const lds_f16* const img = (const lds_f16*)(smem + (k & 1) * a.rec_bytes) + hbase;
             if (!(kDevSwitches && (a.dbg & 2))) {
                 float* const pp = part0 + (k & 1) * part_floats + (4 * fq) * kStreamPartStride + 2 * fr;
@@ -664,7 +668,6 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
                 put(mt_prev);
             }
             stamp(3);
-            if (k > 0) reduce_gxt(k - 1);
         }
     } else {
         // ---- gW role: my tiles all lie in ONE column tile (i0), the row tiles of that column are dealt round-robin to the wavefronts that
@@ -745,10 +748,12 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
                     }
                 }
             }
+            // the second operand of record k + 1 and the column magnitudes of record k + 2 BEHIND my matrix work, not in front of it: the gxt
+            // wavefronts of my SIMD spend the head of the interval on the requests, and two roles that both start with vector work and
+            // both end with matrix work leave each pipe idle half of the time (-4.6 us of 111 on one box, four runs each)
+            pair_rows(k + 1);
+            pair_max(k + 2);
             stamp(3);
-            // gxt of the record before leaves now, not right behind the barrier: its partials stay valid until the next barrier, and the
-            // stores find a memory pipe that the interval's requests have left
-            if (k > 0) reduce_gxt(k - 1);
         }
         // flush my gW partial
 #pragma unroll
