@@ -78,7 +78,11 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     p.nslots = p.G + p.NMT - 1;
     p.ntiles = (d->N + kTile - 1) / kTile;
     const int cus = num_cus();
-    if (p.ntiles < 2 * cus) return p;                       // (below: the edge-split / frequency-group / half-tile plans of the kernel pair)
+    // From three quarters of a tile per CU (3 072 vertices on 256 CUs): measured against the kernel pair at 48 channels, 16 ... 96
+    // neighbours (tools/time_kernels.py, data + filter launches): 1 536 / 2 048 vertices a tie (-1 ... -3 us of 50 ... 70), 3 072 /
+    // 4 096 vertices -10 us of 62 ... 92, 6 000 / 8 000 vertices -25 us of 96 ... 107; 1 024 vertices with 128 neighbours (config 3) +9:
+    // below, the kernel pair's edge-split / frequency-group / half-tile plans give the small mesh its parallelism.
+    if (4 * p.ntiles < 3 * cus) return p;
     p.P = cus / p.F;
     if (p.P < 1) p.P = 1;
     p.img_bytes = kTile * p.KSI * 2;

@@ -72,6 +72,8 @@ def run_conv(graph, x, W, gy, dev):
     (9000, 6, 16, 24, 2, 8),       # eight rings at band limit 2: groups of 3 + 2 frequencies, 563 tiles (separate work items again)
     (4200, 9, 24, 56, 1, 8),       # eight rings
     (8990, 7, 12, 16, 2, 6),       # 562 tiles: more than two workgroups per CU can hold at once (FC_RING=1: half tiles in the last round)
+    (4800, 7, 48, 48, 2, 6),       # the default layer at 300 tiles: the H-streaming backward near the smallest mesh it takes (192 tiles), 5.9 records per workgroup
+    (3100, 8, 16, 32, 1, 4),       # 194 tiles, one gxt wavefront, one gW tile per wavefront: the streaming arrangement's smallest geometry
 ], ids=lambda s: 'N%d_k%d_I%d_O%d_B%d_R%d' % s)
 def test_multi_tile_workgroups_whole_tensors(shape, dev, monkeypatch):
     """Every output of the record-driven kernels against the oracle on meshes where a workgroup walks more than one
