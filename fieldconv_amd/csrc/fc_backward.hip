@@ -624,7 +624,7 @@ static int launch_stream(const float2* x, const char* hrec, const float* wpk, fl
     auto kern = fc_backward_stream_kernel<T, KPT, IT>;
     static bool lds_ok[kMaxDevices] = {};
     if (!allow_full_lds(reinterpret_cast<const void*>(kern), p.lds, lds_ok)) return FC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(p.P, p.F), dim3(kThreads), p.lds, stream, x, hrec, wpk, gwp, gxt, a);
+    hipLaunchKernelGGL(kern, dim3(p.P, p.FS), dim3(kThreads), p.lds, stream, x, hrec, wpk, gwp, gxt, a);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -646,13 +646,13 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
         const float2* gy2 = reinterpret_cast<const float2*>(gy);
 #define FC_GATHER_CASE(RR, BB) if (d->R == RR && d->B == BB) rc = launch_gather<RR, BB>(gy2, rec, g, wpk, hrec, a, p, stream);
         FC_GATHER_CASE(2, 1) FC_GATHER_CASE(4, 1) FC_GATHER_CASE(6, 1) FC_GATHER_CASE(8, 1)
-        FC_GATHER_CASE(2, 2) FC_GATHER_CASE(4, 2) FC_GATHER_CASE(6, 2)
-        FC_GATHER_CASE(2, 3) FC_GATHER_CASE(4, 3)
+        FC_GATHER_CASE(2, 2) FC_GATHER_CASE(4, 2) FC_GATHER_CASE(6, 2) FC_GATHER_CASE(8, 2)
+        FC_GATHER_CASE(2, 3) FC_GATHER_CASE(4, 3) FC_GATHER_CASE(6, 3) FC_GATHER_CASE(8, 3)
 #undef FC_GATHER_CASE
         if (rc != FC_OK) return rc;
     }
     if (!(stages & 2)) return FC_OK;
-    if (p.T == 6 && p.KP == 288 && d->I == 48) rc = launch_stream<6, 288, 48>(x2, hrec, wpk, gwp, gxt, a, p, stream);      // the reference's default layer
+    if (p.T == 6 && p.KPS == 288 && d->I == 48) rc = launch_stream<6, 288, 48>(x2, hrec, wpk, gwp, gxt, a, p, stream);      // the reference's default layer
     else if (p.T <= 2) rc = launch_stream<2>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else if (p.T <= 4) rc = launch_stream<4>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else rc = launch_stream<6>(x2, hrec, wpk, gwp, gxt, a, p, stream);
@@ -660,9 +660,9 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
     const size_t count = (size_t)d->N * d->I;
     const dim3 grid((unsigned)((count + 255) / 256));
     float2* gx2 = reinterpret_cast<float2*>(gx);
-    if (d->B == 1) hipLaunchKernelGGL(fc_backward_gx_kernel<1>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
-    else if (d->B == 2) hipLaunchKernelGGL(fc_backward_gx_kernel<2>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
-    else hipLaunchKernelGGL(fc_backward_gx_kernel<3>, grid, dim3(256), 0, stream, x2, gxt, gx2, count);
+    if (d->B == 1) hipLaunchKernelGGL(fc_backward_gx_kernel<1>, grid, dim3(256), 0, stream, x2, gxt, gx2, count, p.KS);
+    else if (d->B == 2) hipLaunchKernelGGL(fc_backward_gx_kernel<2>, grid, dim3(256), 0, stream, x2, gxt, gx2, count, p.KS);
+    else hipLaunchKernelGGL(fc_backward_gx_kernel<3>, grid, dim3(256), 0, stream, x2, gxt, gx2, count, p.KS);
     return hipGetLastError() == hipSuccess ? FC_OK : FC_ERR_LAUNCH;
 }
 
@@ -736,7 +736,7 @@ void describe_backward(const fc_dims* d, int records, char* buf, size_t n) {
             snprintf(buf, n, "fc_backward_gather_kernel<records,split-f16> tiles=%d; fc_backward_stream_kernel (H once for gxt and gW: %d gxt + %d gW "
                      "wavefronts, W_f in registers, records by LDS-DMA) grid=%dx%d; fc_backward_gx_kernel; module parameters: "
                      "fc_backward_finish_params (sum of the partials + parameter chain) in one launch; explicit filter: fc_backward_finish; cus=%d",
-                     sp.ntiles, sp.G, sp.NW, sp.P, sp.F, num_cus());
+                     sp.ntiles, sp.G, sp.NW, sp.P, sp.FS, num_cus());
             return;
         }
     }
@@ -797,7 +797,7 @@ int backward_finish_params_impl(float* gw_eff, void* ws, size_t ws_bytes, const 
             return reduce_param_grads_impl(gwp, (size_t)sp.F * sp.KP * sp.IP, (size_t)sp.IP, (size_t)sp.KP * sp.IP, (size_t)d->R * sp.IP, false, sp.P,
                                            gw_eff, fp->zonal, fp->spherical, fp->phase, fp->ftype, fp->g_zonal, fp->g_spherical, fp->g_phase, d,
                                            stream, o0, i0, Ifull, fp->bias_partials, fp->bias_nparts, fp->g_bias, ride ? gxt : nullptr,
-                                           ride ? gx_deferred : nullptr, (size_t)d->N * d->I, 0, ride ? -d->B : 0, ride ? x_for_gx : nullptr);
+                                           ride ? gx_deferred : nullptr, (size_t)d->N * d->I, 0, ride ? -(d->B + 4 * (sp.KS - 1)) : 0, ride ? x_for_gx : nullptr);
         }
     }
     const BwdPlan p = plan_backward(d, halves_of(d));

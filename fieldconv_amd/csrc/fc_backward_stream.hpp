@@ -32,6 +32,9 @@ constexpr int kStreamPartStride = 2 * kTile + 4;     // floats per row of a gxt 
 struct StreamPlan {
     bool ok;
     int F, KP, IP, NMT, KST, KSI, NU, G, NW, T, ntiles, P, nslots;
+    int KS;              // slices per frequency: the o-major k range in one piece or in two halves (lanes [0, O/2) | [O/2, O) of the gather)
+    int FS, KPS;         // F * KS slices of KPS = KP / KS entries: what one workgroup of the streaming kernel takes (KST, KSI, NU, G, NW, T: per slice)
+    int NG;              // walks per vertex of the gather kernel (at most 32 ring x frequency sums per lane and walk)
     int img_bytes;       // 16 * KSI halves
     int rec_bytes;       // image + [16] s_v + [16] 1/s_v, rounded up to whole KiB (DMA pieces)
     size_t lds;
@@ -41,7 +44,8 @@ struct StreamPlan {
 
 struct StreamArgs {
     int N, I, O, R, F, B;
-    int KP, IP, NMT, KST, KSI, G, NW, ntiles, P, nslots;
+    int KP, IP, NMT, KST, KSI, G, NW, ntiles, P, nslots;      // F, KP, KST, KSI: of a SLICE (StreamPlan::FS, KPS)
+    int KS;                  // slices per frequency
     int img_bytes, rec_bytes;
     int wKI, wKP;            // channel stride and k entries per row of the packed backward image (k = r*wKI + o)
     int nt_dump;
@@ -61,20 +65,32 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     if (off || !factored || halves != 2 || d->N <= 0) return p;
     const int R = d->R, O = d->O, I = d->I;
     p.F = 2 * d->B + 1;
-    if (R < 2 || R > 8 || (R & 1) || p.F * R > 32 || (R * O) % 32 != 0 || I > 64 || O > 64 || d->B > 3) return p;
+    if (R < 2 || R > 8 || (R & 1) || (R * O) % 32 != 0 || I > 64 || O > 64 || d->B < 1 || d->B > 3) return p;
+    p.NG = (p.F * R + 31) / 32;                               // (42 sums at 6 rings and band limit 3: two walks, 4 + 3 frequencies)
+    if (p.NG > 2) return p;
     p.KP = R * O;
     p.IP = round_up(I, 16);
     p.NMT = p.IP / 16;
-    p.KST = p.KP / 32;
-    if (p.KST < 3) return p;
-    p.KSI = filter_image_stride(p.KP);
-    p.NU = p.NMT * p.KST;
-    p.G = (p.NU + kStreamUnits - 1) / kStreamUnits;
-    p.NW = kWaves - p.G;
-    if (p.NW < p.NMT || p.NW < 8 || p.G < 1) return p;        // (eight gW wavefronts build the row pairs of the second operand)
-    const int row_tiles = p.KP / 16, min_ct_waves = p.NW / p.NMT;
-    p.T = (row_tiles + min_ct_waves - 1) / min_ct_waves;
-    if (p.T > 6) return p;
+    // the k range whole, else in two halves: the first that gives the two roles their wavefronts (64 -> 64 channels on 6 rings: 48 units
+    // = 12 gxt wavefronts whole, 24 = 6 in halves)
+    bool fits = false;
+    for (p.KS = 1; p.KS <= 2 && !fits; ++p.KS) {
+        if (p.KS == 2 && ((O & 1) || (p.KP / 2) % 32 != 0)) break;
+        p.KPS = p.KP / p.KS;
+        p.KST = p.KPS / 32;
+        if (p.KST < 3) break;
+        p.NU = p.NMT * p.KST;
+        p.G = (p.NU + kStreamUnits - 1) / kStreamUnits;
+        p.NW = kWaves - p.G;
+        if (p.NW < p.NMT || p.NW < 8 || p.G < 1) continue;   // (eight gW wavefronts build the row pairs of the second operand)
+        const int row_tiles = p.KPS / 16, min_ct_waves = p.NW / p.NMT;
+        p.T = (row_tiles + min_ct_waves - 1) / min_ct_waves;
+        fits = p.T <= 6;
+        if (fits) break;
+    }
+    if (!fits) return p;
+    p.FS = p.F * p.KS;
+    p.KSI = filter_image_stride(p.KPS);
     p.nslots = p.G + p.NMT - 1;
     p.ntiles = (d->N + kTile - 1) / kTile;
     const int cus = num_cus();
@@ -83,7 +99,7 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     // 4 096 vertices -10 us of 62 ... 92, 6 000 / 8 000 vertices -25 us of 96 ... 107; 1 024 vertices with 128 neighbours (config 3) +9:
     // below, the kernel pair's edge-split / frequency-group / half-tile plans give the small mesh its parallelism.
     if (4 * p.ntiles < 3 * cus) return p;
-    p.P = cus / p.F;
+    p.P = cus / p.FS;
     if (p.P < 1) p.P = 1;
     p.img_bytes = kTile * p.KSI * 2;
     p.rec_bytes = round_up(p.img_bytes + 2 * kTile * 4, 1024);
@@ -93,10 +109,10 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
     if (kTile * I * 8 > kWaves * 1024 - 1024) return p;
     if ((size_t)d->N * I * 8 >= ((size_t)1 << 32)) return p;            // (x rows and gxt slices are addressed with 32-bit offsets; the records with 64-bit ones)
     if (p.lds > kMaxLds) return p;
-    p.hrec_bytes = (size_t)p.ntiles * p.F * p.rec_bytes + 1024;
-    p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);
-    p.gxt_bytes = (size_t)p.F * d->N * I * sizeof(float2);
-    p.wst_bytes = (size_t)p.F * p.G * 4 * kStreamUnits * kWave * 16;      // the gxt wavefronts' filter fragments, in the order they load them
+    p.hrec_bytes = (size_t)p.ntiles * p.FS * p.rec_bytes + 1024;
+    p.gwp_bytes = (size_t)p.P * p.F * p.KP * p.IP * sizeof(float2);       // [P][F][KP][IP] = [P][slice][KPS][IP]
+    p.gxt_bytes = (size_t)p.FS * d->N * I * sizeof(float2);
+    p.wst_bytes = (size_t)p.FS * p.G * 4 * kStreamUnits * kWave * 16;     // the gxt wavefronts' filter fragments, in the order they load them
     p.nt_dump = p.hrec_bytes > ((size_t)192 << 20) ? 1 : 0;
     p.ok = true;
     return p;
@@ -104,8 +120,8 @@ inline StreamPlan plan_stream(const fc_dims* d, int halves, bool factored) {
 
 inline StreamArgs make_stream_args(const fc_dims* d, const StreamPlan& p) {
     StreamArgs a;
-    a.N = d->N; a.I = d->I; a.O = d->O; a.R = d->R; a.F = p.F; a.B = d->B;
-    a.KP = p.KP; a.IP = p.IP; a.NMT = p.NMT; a.KST = p.KST; a.KSI = p.KSI; a.G = p.G; a.NW = p.NW; a.ntiles = p.ntiles; a.P = p.P;
+    a.N = d->N; a.I = d->I; a.O = d->O; a.R = d->R; a.F = p.FS; a.B = d->B; a.KS = p.KS;
+    a.KP = p.KPS; a.IP = p.IP; a.NMT = p.NMT; a.KST = p.KST; a.KSI = p.KSI; a.G = p.G; a.NW = p.NW; a.ntiles = p.ntiles; a.P = p.P;
     a.nslots = p.nslots;
     a.img_bytes = p.img_bytes; a.rec_bytes = p.rec_bytes;
     const MmaGeom gw = make_mma_geom(d->I, d->R, d->O, 2);
@@ -147,7 +163,9 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
     const float2* __restrict__ ggy, const float* __restrict__ gsten, const int32_t* __restrict__ growptr,
     const int32_t* __restrict__ gruns, const float* __restrict__ gwpk, char* __restrict__ hrec, const StreamArgs a) {
     constexpr int F = 2 * B + 1;
-    static_assert(F * R <= 32 && (R & 1) == 0, "one walk per vertex, an even ring count");
+    static_assert(F * R <= 64 && (R & 1) == 0, "at most two walks per vertex, an even ring count");
+    constexpr int NG = (F * R + 31) / 32;             // walks per vertex
+    constexpr int FG = (F + NG - 1) / NG;             // frequencies per walk (7 at 6 rings: 4 + 3)
     constexpr int RECF = factored_record_floats(B);
     constexpr int LOG_CR = factored_log_chunk_records(B);
     constexpr int CR = 1 << LOG_CR;
@@ -189,129 +207,146 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
         const int nch = (end - beg + CR - 1) >> LOG_CR;
         for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
     }
+    // lanes of a vertex's row: output channel o = lane; with two slices per frequency the lanes [0, O/2) and [O/2, O) store into the
+    // records of the first and of the second half of the o-major k range
+    const int OH = O / a.KS;
+    const int half = (lane >= OH && a.KS == 2) ? 1 : 0;
+    const int lane_in_half = lane - half * OH;
     for (int tile = first_tile_of_block(); tile < a.ntiles; tile += grid) {
         int nbeg = 0, nend = 0, nro[R];
         slot_range(tile + grid, nbeg, nend, nro);
         const int nslots = end - beg;
         const int nch = (nslots + CR - 1) >> LOG_CR;
-        f32x2 h[R][F];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int f = 0; f < F; ++f) h[r][f] = f32x2{0.f, 0.f};
+        char* const rec0 = hrec + (size_t)tile * a.F * a.rec_bytes;          // (a.F: slices per tile)
+        const int row_off = wave * a.KSI * 2 + lane_in_half * R * 2;         // bytes: my vertex's row, my R entries of a plane
 
-        // ---------------------------------------------------------------- the walk (fc_backward_data_kernel's, one group)
-        float2 ga = make_float2(0.f, 0.f), gb = ga;
-        if (nslots > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
-            const int d0 = __float_as_int(rec_ptr(0)[3]);
-            const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
-            ga = gather_row(ggy, d0, 8u * O, 8u * ol);
-            gb = gather_row(ggy, d1, 8u * O, 8u * ol);
-        }
-        auto slot = [&](auto qc, const int s, float2& gcur) {
-            constexpr int Q = decltype(qc)::value;
-            const float* rp = rec_ptr(s);
-            const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
-            const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
-            const f32x2 gv = f32x2{gcur.x, gcur.y};
-            gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
-            const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
-            f32x2 ph[F], z[F];
+        // one walk per group of NF frequencies [F0, F0 + NF): at most 32 ring x frequency sums per lane and walk
+        static_for<0, NG>([&](auto gc) {
+            constexpr int GI = decltype(gc)::value;
+            constexpr int F0 = GI * FG;
+            constexpr int NF = (F - F0) < FG ? (F - F0) : FG;
+            f32x2 h[R][NF];
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                ph[f] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * f);
-                z[f] = cmul_conj_pk_step1(gv, ph[f]);
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) h[r][f] = f32x2{0.f, 0.f};
+
+            // ---------------------------------------------------------------- the walk (fc_backward_data_kernel's, one group)
+            float2 ga = make_float2(0.f, 0.f), gb = ga;
+            if (nslots > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first chunks have landed
+                const int d0 = __float_as_int(rec_ptr(0)[3]);
+                const int d1 = __float_as_int(rec_ptr(min(1, nslots - 1))[3]);
+                ga = gather_row(ggy, d0, 8u * O, 8u * ol);
+                gb = gather_row(ggy, d1, 8u * O, 8u * ol);
             }
-#pragma unroll
-            for (int f = 0; f < F; ++f) z[f] = cmul_conj_pk_step2(gv, ph[f], z[f]);
-#pragma unroll
-            for (int f = 0; f < F; ++f) h[Q][f] = __builtin_elementwise_fma(w0v, z[f], h[Q][f]);
-#pragma unroll
-            for (int f = 0; f < F; ++f) h[Q + 1][f] = __builtin_elementwise_fma(w1v, z[f], h[Q + 1][f]);
-        };
-        if (!(kDevSwitches && (a.dbg & 1))) {
-            static_for<0, R - 1>([&](auto qc) {
+            auto slot = [&](auto qc, const int s, float2& gcur) {
                 constexpr int Q = decltype(qc)::value;
-                int s = ro[Q];
-                const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
-                while (s < run_end) {
-                    const int m = s & (CR - 1);
-                    if (m == 0 && s > 0) {       // entering a chunk: the one before it is consumed, its ring slot refilled
-                        const int ch = s >> LOG_CR;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
-                    }
-                    const int stop = min(run_end, s - m + CR);
-                    if ((s & 1) && s < stop) {
-                        slot(qc, s, gb);
-                        ++s;
-                    }
-                    for (; s + 1 < stop; s += 2) {
-                        slot(qc, s, ga);
-                        slot(qc, s + 1, gb);
-                    }
-                    if (s < stop) {
-                        slot(qc, s, ga);
-                        ++s;
-                    }
+                const float* rp = rec_ptr(s);
+                const f32x4 head = *reinterpret_cast<const f32x4*>(rp);
+                const int d2 = __float_as_int(rec_ptr(min(s + 2, nslots - 1))[3]);
+                const f32x2 gv = f32x2{gcur.x, gcur.y};
+                gcur = gather_row(ggy, d2, 8u * O, 8u * ol);
+                const f32x2 w0v = f32x2{head.y, head.y}, w1v = f32x2{head.z, head.z};
+                f32x2 ph[NF], z[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    ph[f] = *reinterpret_cast<const f32x2*>(rp + 4 + 2 * (F0 + f));
+                    z[f] = cmul_conj_pk_step1(gv, ph[f]);
                 }
-            });
-        }
-        {   // my source is done: stream the first record chunks of my next tile's source
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
-            for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
-        }
-
-        // ---------------------------------------------------------------- scale, split, store
-        float mx = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+                for (int f = 0; f < NF; ++f) z[f] = cmul_conj_pk_step2(gv, ph[f], z[f]);
 #pragma unroll
-            for (int f = 0; f < F; ++f) mx = fmaxf(mx, fmaxf(fabsf(h[r][f].x), fabsf(h[r][f].y)));
-        mx = wave_max_nonneg(mx);
-        float scale, inv_scale;
-        split_scale(mx, scale, inv_scale);
-        if (mx == 0.f) inv_scale = 0.f;           // an all-zero row drops out of the second operand x~ / s_v and its column scales
-        char* const rec0 = hrec + (size_t)tile * F * a.rec_bytes;
-        const int row_off = wave * a.KSI * 2 + lane * R * 2;       // bytes: my vertex's row, my R entries of a plane
-        auto rows = [&](auto nt_c) {
-            constexpr bool NT = decltype(nt_c)::value;
+                for (int f = 0; f < NF; ++f) h[Q][f] = __builtin_elementwise_fma(w0v, z[f], h[Q][f]);
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                uint32_t hi[R], lo[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    f16x2 h2, l2;
-                    split_halves2(h[r][f], scale, h2, l2);
-                    hi[r] = __builtin_bit_cast(uint32_t, h2);
-                    lo[r] = __builtin_bit_cast(uint32_t, l2);
-                }
-                constexpr uint32_t kLow = 0x05040100u, kHigh = 0x07060302u;      // (b.lo16, a.lo16) / (b.hi16, a.hi16) of perm(a, b)
-                uint32_t p0[R / 2], p1[R / 2], p2[R / 2], p3[R / 2];
-#pragma unroll
-                for (int dd = 0; dd < R / 2; ++dd) {
-                    p0[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kLow);       // re_hi
-                    p1[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kLow);       // re_lo
-                    p2[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kHigh);      // im_hi
-                    p3[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kHigh);      // im_lo
-                }
-                if (lane < O && !(kDevSwitches && (a.dbg & 8))) {
-                    char* const dst = rec0 + (size_t)f * a.rec_bytes + row_off;
-                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst), p0);
-                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 2), p1);
-                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 4), p2);
-                    store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 6), p3);
-                }
-                if (lane == 0) {
-                    float* tail = reinterpret_cast<float*>(rec0 + (size_t)f * a.rec_bytes + a.img_bytes);
-                    tail[wave] = scale;
-                    tail[kTile + wave] = inv_scale;
+                for (int f = 0; f < NF; ++f) h[Q + 1][f] = __builtin_elementwise_fma(w1v, z[f], h[Q + 1][f]);
+            };
+            if (!(kDevSwitches && (a.dbg & 1))) {
+                static_for<0, R - 1>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    int s = ro[Q];
+                    const int run_end = (Q + 1 < R - 1) ? ro[Q + 1] : nslots;
+                    while (s < run_end) {
+                        const int m = s & (CR - 1);
+                        if (m == 0 && s > 0) {       // entering a chunk: the one before it is consumed, its ring slot refilled
+                            const int ch = s >> LOG_CR;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (ch - 1 + NR < nch) dma_chunk(beg, ch - 1 + NR);
+                        }
+                        const int stop = min(run_end, s - m + CR);
+                        if ((s & 1) && s < stop) {
+                            slot(qc, s, gb);
+                            ++s;
+                        }
+                        for (; s + 1 < stop; s += 2) {
+                            slot(qc, s, ga);
+                            slot(qc, s + 1, gb);
+                        }
+                        if (s < stop) {
+                            slot(qc, s, ga);
+                            ++s;
+                        }
+                    }
+                });
+            }
+            {   // this walk is done: stream the first record chunks of the next one -- my source again, or my next tile's source
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (GI + 1 < NG) {
+                    for (int ch = 0; ch < min(nch, NR); ++ch) dma_chunk(beg, ch);
+                } else {
+                    const int nnch = (nend - nbeg + CR - 1) >> LOG_CR;
+                    for (int ch = 0; ch < min(nnch, NR); ++ch) dma_chunk(nbeg, ch);
                 }
             }
-        };
-        if (a.nt_dump && !(kDevSwitches && (a.dbg & 32))) rows(std::true_type{}); else rows(std::false_type{});
+
+            // ---------------------------------------------------------------- scale, split, store (this group's frequencies)
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) mx = fmaxf(mx, fmaxf(fabsf(h[r][f].x), fabsf(h[r][f].y)));
+            mx = wave_max_nonneg(mx);
+            float scale, inv_scale;
+            split_scale(mx, scale, inv_scale);
+            if (mx == 0.f) inv_scale = 0.f;           // an all-zero row drops out of the second operand x~ / s_v and its column scales
+            auto rows = [&](auto nt_c) {
+                constexpr bool NT = decltype(nt_c)::value;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    uint32_t hi[R], lo[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        f16x2 h2, l2;
+                        split_halves2(h[r][f], scale, h2, l2);
+                        hi[r] = __builtin_bit_cast(uint32_t, h2);
+                        lo[r] = __builtin_bit_cast(uint32_t, l2);
+                    }
+                    constexpr uint32_t kLow = 0x05040100u, kHigh = 0x07060302u;      // (b.lo16, a.lo16) / (b.hi16, a.hi16) of perm(a, b)
+                    uint32_t p0[R / 2], p1[R / 2], p2[R / 2], p3[R / 2];
+#pragma unroll
+                    for (int dd = 0; dd < R / 2; ++dd) {
+                        p0[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kLow);       // re_hi
+                        p1[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kLow);       // re_lo
+                        p2[dd] = __builtin_amdgcn_perm(hi[2 * dd + 1], hi[2 * dd], kHigh);      // im_hi
+                        p3[dd] = __builtin_amdgcn_perm(lo[2 * dd + 1], lo[2 * dd], kHigh);      // im_lo
+                    }
+                    char* const recf = rec0 + (size_t)((F0 + f) * a.KS + half) * a.rec_bytes;     // the record of slice (frequency, my half)
+                    if (lane < O && !(kDevSwitches && (a.dbg & 8))) {
+                        char* const dst = recf + row_off;
+                        store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst), p0);
+                        store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 2), p1);
+                        store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 4), p2);
+                        store_plane_row<R, NT>(reinterpret_cast<uint32_t*>(dst + a.KP * 6), p3);
+                    }
+                    if (lane_in_half == 0 && lane < O) {
+                        float* tail = reinterpret_cast<float*>(recf + a.img_bytes);
+                        tail[wave] = scale;
+                        tail[kTile + wave] = inv_scale;
+                    }
+                }
+            };
+            if (a.nt_dump && !(kDevSwitches && (a.dbg & 32))) rows(std::true_type{}); else rows(std::false_type{});
+        });
         beg = nbeg;
         end = nend;
 #pragma unroll
@@ -331,13 +366,14 @@ __global__ __launch_bounds__(kThreads) void fc_backward_gather_kernel(
         const uint16_t* const img0 = reinterpret_cast<const uint16_t*>(gwpk + a.IP);
         for (int e = blockIdx.x * kThreads + tid; e < total; e += gridDim.x * kThreads) {
             const int ln = e & 63, pl = (e >> 6) & 3, ui = (e >> 8) % kStreamUnits, fg = e / (kStreamUnits * 4 * kWave);
-            const int g_ = fg % a.G, f_ = fg / a.G;
+            const int g_ = fg % a.G, sl = fg / a.G;              // slice = (frequency, half of the k range)
+            const int f_ = sl / a.KS, k0 = (sl - f_ * a.KS) * a.KP;
             const int fr_ = ln & 15, fq_ = ln >> 4;
             const int u = min(g_ * kStreamUnits + ui, NU - 1);
             const int mt = u / a.KST, kb = u - mt * a.KST;
             const int row = (mt * 16 + fr_) * 32;
             const uint16_t* const img = img0 + ((size_t)f_ * 4 + pl) * plane_sz;
-            int o = (kb * 32 + 8 * fq_) / R, r = kb * 32 + 8 * fq_ - o * R;
+            int o = (k0 + kb * 32 + 8 * fq_) / R, r = k0 + kb * 32 + 8 * fq_ - o * R;
             uint32_t v[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -391,8 +427,8 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = blockIdx.y;
-    const int m = f - a.B;
+    const int f = blockIdx.y;                    // my slice: frequency f / KS, half f % KS of the k range (records, fragments, gxt, partials: per slice)
+    const int m = f / a.KS - a.B;
     const int fr = lane & 15, fq = lane >> 4;
     const bool is_gxt = wave < a.G;
     // The launch is bound by the instructions its wavefronts issue (every vector instruction holds a SIMD for four cycles; a SIMD runs
@@ -783,10 +819,10 @@ __global__ __launch_bounds__(kThreads) void fc_backward_stream_kernel(
 // fc_backward_all with module parameters the same arithmetic rides in the launch that finishes the pass (fc_pack.hip)
 template <int B>
 __global__ __launch_bounds__(256) void fc_backward_gx_kernel(const float2* __restrict__ gx_, const float2* __restrict__ ggxt,
-                                                             float2* __restrict__ ggx, const size_t count /* N*I */) {
+                                                             float2* __restrict__ ggx, const size_t count /* N*I */, const int ks) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
-    ggx[idx] = gx_from_slices<B>(gx_[idx], ggxt, idx, count);
+    ggx[idx] = gx_from_slices<B>(gx_[idx], ggxt, idx, count, ks);
 }
 
 }  // namespace fc

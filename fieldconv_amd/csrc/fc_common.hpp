@@ -273,12 +273,21 @@ __device__ __forceinline__ float2 unit_power(float2 u, int m) {
 // gx[j,i] = sum_f gxt_f conj(u^m) + [x != 0] (i x / |x|^2) sum_f m Im(conj(gxt_f) x u^m),  u = exp(-i angle(x))  (1 inside the origin box):
 // the input gradient from the F slices gxt_f (complex numbers `stride` apart) of the adjoint of the rotated copies
 // (autograd of reference nn/field_conv.py:128-130)
+// ks: slices per frequency (the streaming arrangement's halves of the k range, fc_backward_stream.hpp), summed first
 template <int B>
-__device__ __forceinline__ float2 gx_from_slices(const float2 x, const float2* __restrict__ gxt, const size_t idx, const size_t stride) {
+__device__ __forceinline__ float2 gx_from_slices(const float2 x, const float2* __restrict__ gxt, const size_t idx, const size_t stride,
+                                                 const int ks = 1) {
     constexpr int F = 2 * B + 1;
     float2 z[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) z[f] = gxt[(size_t)f * stride + idx];
+    for (int f = 0; f < F; ++f) {
+        z[f] = gxt[(size_t)(f * ks) * stride + idx];
+        if (ks == 2) {
+            const float2 z2 = gxt[(size_t)(f * ks + 1) * stride + idx];
+            z[f].x += z2.x;
+            z[f].y += z2.y;
+        }
+    }
     const float2 u1 = unit_conj(x);
     float2 up[B + 1];
     up[0] = make_float2(1.f, 0.f);

@@ -363,8 +363,10 @@ __global__ __launch_bounds__(kRpThreads) void fc_reduce_param_grads_kernel(
         const float2* gxt = reinterpret_cast<const float2*>(gx_parts);
         float2* out = reinterpret_cast<float2*>(gx);
         const float2 xv = gx_x[idx];
-        out[idx] = gx_nparts == -1 ? gx_from_slices<1>(xv, gxt, idx, gx_count4)
-                 : gx_nparts == -2 ? gx_from_slices<2>(xv, gxt, idx, gx_count4) : gx_from_slices<3>(xv, gxt, idx, gx_count4);
+        // (-gx_nparts = band limit + 4 * (slices per frequency - 1))
+        const int bl = (-gx_nparts) & 3, ks = 1 + ((-gx_nparts) >> 2);
+        out[idx] = bl == 1 ? gx_from_slices<1>(xv, gxt, idx, gx_count4, ks)
+                 : bl == 2 ? gx_from_slices<2>(xv, gxt, idx, gx_count4, ks) : gx_from_slices<3>(xv, gxt, idx, gx_count4, ks);
         return;
     }
     if ((int)blockIdx.x >= gx_block0) {

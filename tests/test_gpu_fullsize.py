@@ -68,7 +68,7 @@ def run_conv(graph, x, W, gy, dev):
     (4400, 6, 40, 40, 2, 6),       # k = 6*40 = 240 padded to 256: stale bytes in the padding would poison later tiles
     (4400, 6, 48, 48, 2, 5),       # k = 5*48 = 240 padded to 256
     (4400, 6, 8, 16, 1, 3),        # narrow layer: k = 24 padded to 32
-    (5000, 7, 64, 64, 3, 6),       # FAUST shape (C=64, B=3): two frequency groups, run as separate work items in the backward data kernel (313 tiles)
+    (5000, 7, 64, 64, 3, 6),       # FAUST shape (C=64, B=3), 313 tiles: the H-streaming backward with two walks per vertex (4 + 3 frequencies) and the k range in two halves (14 slices); in fp32 mode the data kernel's two frequency groups as separate work items
     (9000, 6, 16, 24, 2, 8),       # eight rings at band limit 2: groups of 3 + 2 frequencies, 563 tiles (separate work items again)
     (4200, 9, 24, 56, 1, 8),       # eight rings
     (8990, 7, 12, 16, 2, 6),       # 562 tiles: more than two workgroups per CU can hold at once (FC_RING=1: half tiles in the last round)
@@ -597,18 +597,30 @@ def _stream_shape_classes(N):
                 d = _lib.FcDims(N, N * 8, I, O, R, B)
                 if not lib.fc_backward_streams(ctypes.byref(d), 1):
                     continue
-                KP, NMT = R * O, (I + 15) // 16
-                KST = KP // 32
-                G = (NMT * KST + 3) // 4
-                T = -(-(KP // 16) // ((16 - G) // NMT))
-                classes.setdefault((R, B, NMT, KST, G, T, I % 16 == 0, O % 16 == 0), (I, O))
+                # (plan_stream's geometry: walks per vertex, the k range whole or in two halves, units, wavefronts per role, tiles per gW wavefront)
+                KP, NMT, NG = R * O, (I + 15) // 16, ((2 * B + 1) * R + 31) // 32
+                key = None
+                for KS in (1, 2):
+                    KPS = KP // KS
+                    KST = KPS // 32
+                    G = (NMT * KST + 3) // 4
+                    NW = 16 - G
+                    if KST < 3 or NW < NMT or NW < 8:
+                        continue
+                    T = -(-(KPS // 16) // (NW // NMT))
+                    if T <= 6:
+                        key = (R, B, NG, KS, NMT, KST, G, T, I % 16 == 0, O % 16 == 0)
+                        break
+                assert key is not None, (R, B, I, O)
+                classes.setdefault(key, (I, O))
     return sorted(classes.items())
 
 
 def test_every_shape_class_of_the_streaming_backward(dev):
     """The gather / stream / gx arrangement against the fp32 data / filter kernel pair of the same process (fieldconv_amd.arithmetic),
-    over every class of geometry its plan accepts (294 at this size; every third one here plus the first and last of each (rings,
-    band limit) pair, all of them with FC_FULL_MODES=1): y, gx and the three parameter gradients agree to fp32 rounding."""
+    over every class of geometry its plan accepts -- rings x band limit (one or two walks per vertex) x the k range whole or in halves x
+    channel tiles x k steps x wavefronts per role x tiles per gW wavefront x ragged tiles (several hundred at this size; every third one
+    here plus the first and last of each (rings, band limit) pair, all of them with FC_FULL_MODES=1): y, gx and the three parameter gradients agree to fp32 rounding."""
     if os.environ.get('FC_MFMA') not in (None, '', 'split'):
         pytest.skip('the arrangement exists in the default arithmetic mode only')
     import fieldconv_amd

@@ -403,9 +403,15 @@ def test_kernel_description_and_gpu_count_need_no_gpu():
         assert 'fc_forward_ring_kernel<geometric records,split-f16>' in text, text
         if os.environ.get('FC_BWD_STREAM') in (None, ''):         # config 2 runs the H-streaming arrangement
             assert 'fc_backward_gather_kernel' in text and 'fc_backward_stream_kernel' in text and 'fc_backward_gx_kernel' in text, text
-        # a FAUST-sized mesh (313 tiles) keeps the data / filter kernel pair
-        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(4999, 150000, 48, 48, 6, 2)), 2, buf, len(buf)) == 0
+        # config 3's mesh (64 tiles) keeps the data / filter kernel pair; a FAUST-sized one (313 tiles) streams, also at config 5's layer
+        # (64 channels, band limit 3: two walks per vertex, the k range in two halves: 14 slices)
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(1024, 131072, 48, 48, 6, 2)), 2, buf, len(buf)) == 0
         assert b'fc_backward_filter_half2_kernel' in buf.value, buf.value
+        if os.environ.get('FC_BWD_STREAM') in (None, ''):
+            for dims in (_lib.FcDims(4999, 150000, 48, 48, 6, 2), _lib.FcDims(4999, 132150, 64, 64, 6, 3)):
+                assert lib.fc_describe_kernels(ctypes.byref(dims), 2, buf, len(buf)) == 0
+                assert b'fc_backward_stream_kernel' in buf.value, buf.value
+            assert b'x14;' in buf.value, buf.value
     small = _lib.FcDims(1024, 131072, 48, 48, 6, 2)
     assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and b'frequency-major' in buf.value
     assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(100, 10, 48, 48, 9, 2)), 1, buf, len(buf)) == -2
@@ -418,10 +424,11 @@ def test_kernel_description_and_gpu_count_need_no_gpu():
         # 2 parts, not 4) -- and not config 2 (1 250 tiles: five rounds either way)
         groups = b'frequency groups of a tile as separate work items'
         assert lib.fc_describe_kernels(ctypes.byref(d), 2, buf, len(buf)) == 0 and groups not in buf.value
-        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(4999, 132257, 64, 64, 6, 3)), 2, buf, len(buf)) == 0 and groups in buf.value
+        # (in fp32 mode: the default mode streams such a mesh)
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(4999, 132257, 64, 64, 6, 3, mode=1)), 2, buf, len(buf)) == 0 and groups in buf.value
         assert b'tiles=313 parts=1' in buf.value, buf.value
         assert lib.fc_describe_kernels(ctypes.byref(small), 1, buf, len(buf)) == 0 and groups in buf.value and b'parts=2' in buf.value, buf.value
-        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(7500, 200000, 64, 64, 6, 3)), 2, buf, len(buf)) == 0 and groups not in buf.value
+        assert lib.fc_describe_kernels(ctypes.byref(_lib.FcDims(7500, 200000, 64, 64, 6, 3, mode=1)), 2, buf, len(buf)) == 0 and groups not in buf.value
     import importlib.util
     spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
