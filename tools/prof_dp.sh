@@ -11,7 +11,8 @@ cp /tmp/dp_prof/*kernel_stats.csv "$ROOT/gpurun_out/dp_prof/"
 python3 - "$ROOT/gpurun_out/dp_prof/dp_kernel_stats.csv" "${1:-70}" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-convs = max(int(r['Calls']) for r in rows if 'fc_backward_data_kernel' in r['Name'])
+# one finishing launch per convolution whatever the backward arrangement (17 convolutions per step)
+convs = sum(int(r['Calls']) for r in rows if 'fc_reduce_param_grads_kernel' in r['Name'])
 steps = convs / 17.0
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 calls = sum(int(r['Calls']) for r in rows)
