@@ -653,6 +653,7 @@ int backward_stream_impl(const float* x, const float* gy, const float* rec, cons
     }
     if (!(stages & 2)) return FC_OK;
     if (p.T == 6 && p.KPS == 288 && d->I == 48) rc = launch_stream<6, 288, 48>(x2, hrec, wpk, gwp, gxt, a, p, stream);      // the reference's default layer
+    else if (p.T == 6 && p.KPS == 192 && d->I == 64) rc = launch_stream<6, 192, 64>(x2, hrec, wpk, gwp, gxt, a, p, stream);  // config 5's layer: a half of 64 x 6 entries
     else if (p.T <= 2) rc = launch_stream<2>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else if (p.T <= 4) rc = launch_stream<4>(x2, hrec, wpk, gwp, gxt, a, p, stream);
     else rc = launch_stream<6>(x2, hrec, wpk, gwp, gxt, a, p, stream);
